@@ -1,0 +1,102 @@
+/*
+ * umx.h -- C ABI of the MI355X-native UMA (eSCN-MD) energy/force engine (libumx.so).
+ *
+ * This is the drop-in boundary underneath the reference's calculator
+ * (pdb2reaction/uma_pysis.py).  Each entry point names the reference interface it replaces
+ * (file:line relative to the reference repository root).  Plain pointers and sizes only; no
+ * torch types.  One engine per GPU/process; an engine is NOT thread-safe (the reference shares
+ * one calculator strictly serially, path_opt.py:822-823,949-954).
+ *
+ * Units at this boundary are the model's native ones, exactly what the reference receives from
+ * fairchem before its own conversion (uma_pysis.py:387-389, 506-513): positions in Angstrom
+ * (float32, AtomicData.pos), energies in eV (float64), forces in eV/Angstrom (float32).
+ *
+ * All functions return 0 on success or a negative umx_status; umx_last_error() gives the text.
+ */
+#ifndef UMX_H
+#define UMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct umx_engine umx_engine;
+
+enum umx_status {
+  UMX_OK = 0,
+  UMX_ERR_ARG = -1,      /* bad argument / call order                         */
+  UMX_ERR_HIP = -2,      /* HIP runtime failure (text has the hipError name)  */
+  UMX_ERR_WEIGHTS = -3,  /* malformed or incomplete weight blob               */
+  UMX_ERR_CAPACITY = -4, /* neighbour cap exceeded / workspace cannot be sized */
+  UMX_ERR_NO_DEVICE = -5 /* no usable gfx950 device                           */
+};
+
+/* Version of this ABI (bumped on any signature change). */
+int umx_abi_version(void);
+
+/* Create / destroy an engine bound to HIP device `device_ordinal`.
+ * Replaces: UMAcore.__init__ device selection, uma_pysis.py:200-203.                           */
+int umx_create(umx_engine** out, int device_ordinal);
+int umx_destroy(umx_engine* eng);
+
+/* Text of the last error on this engine (or of the last failed umx_create when eng == NULL).   */
+const char* umx_last_error(const umx_engine* eng);
+
+/* Load a merged UMA-S parameter set from a host-memory UMXW0001 blob
+ * (pdb2reaction_amd/weights.py documents the layout).
+ * Replaces: pretrained_mlip.get_predict_unit(model, device), uma_pysis.py:246-250.             */
+int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes);
+
+/* Bind the chemical system shared by every image: atomic numbers, total charge, spin
+ * multiplicity, task ("dataset") index into {oc20, omol, omat, odac, omc}; cutoff radius in
+ * Angstrom (<=0: model default 6.0) and neighbour cap (<=0: model default 300).
+ * Replaces: UMAcore.__init__ elem/charge/spin/task (uma_pysis.py:266-273) and the per-call
+ * AtomicData.from_ase(...)/data.dataset/collate of _ase_to_batch (uma_pysis.py:312-322).       */
+int umx_set_system(umx_engine* eng, int n_atoms, const int32_t* atomic_numbers, int charge,
+                   int spin, int task_index, float radius, int max_neigh);
+
+/* Optional: cap the device workspace (bytes; 0 = automatic from free HBM).                     */
+int umx_set_workspace_limit(umx_engine* eng, size_t bytes);
+
+/* Energy (+ forces) of `n_images` geometries of the bound system in ONE batched evaluation.
+ * pos_ang: [n_images][n_atoms][3] float32 Angstrom; energy_ev: [n_images] float64 (total energy
+ * incl. element references); forces_ev_ang: [n_images][n_atoms][3] float32 or NULL.
+ * Host-pointer form (copies in/out, synchronises before returning).
+ * Replaces: self.predict.predict(batch) + result pulls, uma_pysis.py:373-389 -- called once per
+ * image by the reference, here once for all images of the string.                              */
+int umx_energy_forces(umx_engine* eng, int n_images, const float* pos_ang, double* energy_ev,
+                      float* forces_ev_ang);
+
+/* Same, with DEVICE pointers; work is enqueued on `hip_stream` (a hipStream_t, NULL = the
+ * engine's own stream) and the call returns after enqueueing the final kernels (one small
+ * device-to-host read of per-image edge counts happens inside for workspace planning).         */
+int umx_energy_forces_dev(umx_engine* eng, int n_images, const float* d_pos_ang,
+                          double* d_energy_ev, float* d_forces_ev_ang, void* hip_stream);
+
+/* Block until all work enqueued by this engine has finished.                                   */
+int umx_synchronize(umx_engine* eng);
+
+/* Graph statistics of the most recent evaluation: total directed edges over all images, and
+ * the maximum in-degree.  (Diagnostics for roofline accounting)         */
+int umx_last_graph_stats(const umx_engine* eng, int64_t* n_edges_total, int32_t* max_degree);
+
+/* Accumulated device time (ms, HIP events on the engine's launch stream) and launch count of
+ * the dominant kernel family (the SO(2)/radial fp32-MFMA GEMM) since the last reset, plus the
+ * FLOPs those launches performed.  bench.py uses this for the live roofline figure.            */
+int umx_profile_enable(umx_engine* eng, int on);
+int umx_profile_read(umx_engine* eng, double* gemm_ms, int64_t* gemm_launches, double* gemm_flops,
+                     int reset);
+
+/* Test hook: copy a named intermediate buffer of the most recent evaluation's last chunk to the
+ * host.  Returns the buffer size in bytes through *nbytes_out when host_buf == NULL.           */
+int umx_debug_fetch(umx_engine* eng, const char* name, void* host_buf, size_t capacity,
+                    size_t* nbytes_out);
+int umx_debug_keep(umx_engine* eng, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UMX_H */

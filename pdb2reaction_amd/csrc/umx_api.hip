@@ -1,0 +1,852 @@
+// umx_api.hip -- host orchestration and C ABI (include/umx.h) of the UMA-S engine for gfx950.
+//
+// One engine = one GPU.  umx_energy_forces[_dev] evaluates K images of one system as a block
+// diagonal graph: K1 radius graph -> K2 frames -> K4/K5 node init + edge-degree embedding ->
+// 4 x (K6 norm, K7 edgewise SO(2) message passing, K8 atom-wise FF) -> K9 readout -> K10 analytic
+// reverse pass (no autograd) -> K11 normaliser/element references.  Images are processed in
+// chunks sized to the HBM workspace budget; activations needed by the reverse pass stay resident
+// in HBM (the 288 GB part makes store-not-recompute the cheaper choice).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/umx.h"
+#include "umx_common.h"
+#include "umx_gemm.h"
+#include "umx_kernels.h"
+
+using namespace umx;
+
+namespace {
+
+std::string g_create_err;
+
+struct Tensor { size_t off = 0; std::vector<int> shape; size_t count = 0; };
+
+struct RadialW {          // one RadialMLP (forward + transposed copies)
+  const float *w1g, *w1gT, *ts, *tt, *ln1w, *ln1b, *w2, *w2T, *b2, *ln2w, *ln2b, *w3, *w3T, *b3;
+  int out;
+};
+struct LayerW {
+  const float *n1w, *n1b, *n2w, *n2b;
+  const float *c1m0, *c1m0b, *c1m0T, *c1m1, *c1m1T, *c1m2, *c1m2T;
+  const float *c2m0, *c2m0b, *c2m0T, *c2m1, *c2m1T, *c2m2, *c2m2T;
+  const float *smlp, *smlpb, *smlpT, *l1w, *l1b, *l1T, *l2w, *l2b, *l2T;
+  RadialW rad;
+};
+
+struct ProfRec { hipEvent_t a, b; double flops; };
+
+}  // namespace
+
+struct umx_engine {
+  int dev = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // weights
+  bool have_weights = false;
+  float* d_w = nullptr;          // raw blob data section
+  float* d_dw = nullptr;         // derived weights
+  std::map<std::string, Tensor> wt;
+  std::vector<float> h_w;        // host copy of the data section (needed to build derived weights)
+  RadialW rdeg{};
+  LayerW lw[NL]{};
+  const float *emb_sphere = nullptr, *normw = nullptr, *normb = nullptr, *e0 = nullptr, *e0b = nullptr, *e0T = nullptr,
+              *e2 = nullptr, *e2b = nullptr, *e2T = nullptr, *e4 = nullptr, *e4b = nullptr;
+  double rmsd = 1.0;
+  std::vector<double> elem_refs;
+  // system
+  bool have_system = false;
+  int natoms = 0;
+  float cutoff = 6.0f;
+  int max_neigh = 300;
+  int* d_z = nullptr;
+  float* d_sysemb = nullptr;
+  double refsum = 0.0;
+  // workspace
+  size_t ws_limit = 0;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  long cap_nodes = 0, cap_edges = 0;
+  int* d_deg_all = nullptr; long deg_all_cap = 0;
+  int* d_img_edges = nullptr; long img_edges_cap = 0;
+  // host io staging for the host-pointer entry point
+  float* d_io_pos = nullptr; double* d_io_e = nullptr; float* d_io_f = nullptr; long io_cap = 0;
+  // stats / profiling / debug
+  int64_t last_edges = 0; int32_t last_maxdeg = 0;
+  bool prof_on = false;
+  std::vector<ProfRec> prof;
+  size_t prof_used = 0;
+  bool dbg_on = false;
+  std::map<std::string, std::vector<char>> dbg;
+};
+
+namespace {
+
+#define HIPCHK(eng, expr)                                                                         \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) {                                                                       \
+      (eng)->err = std::string(#expr) + ": " + hipGetErrorName(_e) + " (" + hipGetErrorString(_e) + ")"; \
+      return UMX_ERR_HIP;                                                                         \
+    }                                                                                             \
+  } while (0)
+
+#define CHK(expr) do { int _s = (expr); if (_s != UMX_OK) return _s; } while (0)
+
+int fail(umx_engine* e, int code, const std::string& msg) { e->err = msg; return code; }
+
+inline unsigned nblk(long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+// ---- GEMM launcher -----------------------------------------------------------------------------
+GemmP gp_zero() { GemmP p; std::memset(&p, 0, sizeof(p)); p.conj = 1.0f; return p; }
+
+int launch_gemm(umx_engine* eng, const GemmP& p, int amode, int cplx, int epi, int gz = 1) {
+  if (p.M <= 0) return UMX_OK;
+  if (p.K % G_BK != 0) return fail(eng, UMX_ERR_ARG, "gemm: K not a multiple of 32");
+  const int bmr = cplx ? 64 : 128, bnc = cplx ? 64 : 128;
+  const long nM = (p.M + bmr - 1) / bmr, nN = (p.N + bnc - 1) / bnc;
+  const long blocks = ((nM + 7) / 8) * 8 * nN;
+  dim3 grid((unsigned)blocks, 1, (unsigned)gz), block(256);
+  ProfRec* pr = nullptr;
+  if (eng->prof_on) {
+    if (eng->prof_used == eng->prof.size()) {
+      ProfRec r; HIPCHK(eng, hipEventCreate(&r.a)); HIPCHK(eng, hipEventCreate(&r.b)); r.flops = 0; eng->prof.push_back(r);
+    }
+    pr = &eng->prof[eng->prof_used++];
+    pr->flops = cplx ? 8.0 * p.M * (double)p.N * p.K : 2.0 * p.M * (double)p.N * p.K * gz;
+    HIPCHK(eng, hipEventRecord(pr->a, eng->stream));
+  }
+  const int key = amode * 100 + cplx * 10 + epi;
+  switch (key) {
+    case A_PLAIN * 100 + 0 + E_BIAS: hipLaunchKernelGGL((umx_gemm_kernel<A_PLAIN, 0, E_BIAS>), grid, block, 0, eng->stream, p); break;
+    case A_PLAIN * 100 + 10 + E_BIAS: hipLaunchKernelGGL((umx_gemm_kernel<A_PLAIN, 1, E_BIAS>), grid, block, 0, eng->stream, p); break;
+    case A_MODUL * 100 + 0 + E_BIAS: hipLaunchKernelGGL((umx_gemm_kernel<A_MODUL, 0, E_BIAS>), grid, block, 0, eng->stream, p); break;
+    case A_MODUL * 100 + 10 + E_BIAS: hipLaunchKernelGGL((umx_gemm_kernel<A_MODUL, 1, E_BIAS>), grid, block, 0, eng->stream, p); break;
+    case A_GAUSS * 100 + 0 + E_TABLES: hipLaunchKernelGGL((umx_gemm_kernel<A_GAUSS, 0, E_TABLES>), grid, block, 0, eng->stream, p); break;
+    case A_SILU * 100 + 0 + E_BIAS: hipLaunchKernelGGL((umx_gemm_kernel<A_SILU, 0, E_BIAS>), grid, block, 0, eng->stream, p); break;
+    default: return fail(eng, UMX_ERR_ARG, "gemm: variant not instantiated");
+  }
+  HIPCHK(eng, hipGetLastError());
+  if (pr) HIPCHK(eng, hipEventRecord(pr->b, eng->stream));
+  return UMX_OK;
+}
+
+// plain C = A . B^T (+bias, +resid)
+int gemm_plain(umx_engine* eng, const float* A, long lda, int offA, const float* B, long ldb, const float* bias, float* Cp,
+               long ldc, int offC, long M, int N, int K, int amode = A_PLAIN, int gz = 1, long zA = 0, long zC = 0,
+               const float* resid = nullptr, long ldres = 0, int offRes = 0, long zRes = 0) {
+  GemmP p = gp_zero();
+  p.A = A; p.lda = lda; p.offA0 = offA; p.B = B; p.ldb = ldb; p.bias = bias; p.Cp = Cp; p.ldc = ldc; p.offC = offC;
+  p.M = (int)M; p.N = N; p.K = K; p.zA = zA; p.zC = zC; p.resid = resid; p.ldres = ldres; p.offRes = offRes; p.zRes = zRes;
+  return launch_gemm(eng, p, amode, 0, E_BIAS, gz);
+}
+
+// SO(2) complex linear on (edge, re/im) rows
+int gemm_cplx(umx_engine* eng, const float* A, long lda, int offRe, int offIm, const float* R, long ldr, int offR, const float* B,
+              long ldb, int bHalf, float* Cp, long ldc, int offCre, int offCim, long M, int N, int K, float conj) {
+  GemmP p = gp_zero();
+  p.A = A; p.lda = lda; p.offA0 = offRe; p.offA1 = offIm; p.R = R; p.ldr = ldr; p.offR = offR; p.B = B; p.ldb = ldb; p.bHalf = bHalf;
+  p.Cp = Cp; p.ldc = ldc; p.offC = offCre; p.offCi = offCim; p.M = (int)M; p.N = N; p.K = K; p.conj = conj;
+  return launch_gemm(eng, p, R ? A_MODUL : A_PLAIN, 1, E_BIAS);
+}
+
+// ---- workspace ---------------------------------------------------------------------------------
+struct WS {
+  // node level
+  int *deg, *row_ptr, *stats;
+  float* xs[2 * NL + 1];
+  float* xn[NL];
+  float *xn2, *ffhg, *xf, *pre1, *pre2, *enode;
+  float* gspre[NL];
+  float* ffh[NL];
+  float *G0, *G1, *G2, *ggs, *n128a, *n128b;
+  // edge level
+  int *esrc, *edst, *rev;
+  float *evec, *frame, *dedd, *tau, *gvec;
+  float* h1pre[NL + 1];
+  float* h2pre[NL + 1];
+  float *ra, *rad_deg;
+  float* rad[NL];
+  float* hg[NL];
+  float* msg[NL];
+  float *xrot, *hid, *gmsg, *ghg, *gy1, *grad, *e128a, *e128b, *ggauss;
+};
+
+struct Bump {
+  char* base; size_t off = 0;
+  template <class T> T* take(size_t n) {
+    off = (off + 255) & ~size_t(255);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+size_t carve(char* base, long nn, long ne, WS* w) {
+  Bump b{base};
+  WS t;
+  t.deg = nullptr;  // deg comes from the per-call array
+  t.row_ptr = b.take<int>(nn + 1); t.stats = b.take<int>(4);
+  for (auto& x : t.xs) x = b.take<float>(nn * ROW);
+  for (auto& x : t.xn) x = b.take<float>(nn * ROW);
+  t.xn2 = b.take<float>(nn * ROW); t.ffhg = b.take<float>(nn * ROW); t.xf = b.take<float>(nn * ROW);
+  t.pre1 = b.take<float>(nn * H); t.pre2 = b.take<float>(nn * H); t.enode = b.take<float>(nn);
+  for (auto& x : t.gspre) x = b.take<float>(nn * 2 * H);
+  for (auto& x : t.ffh) x = b.take<float>(nn * ROW);
+  t.G0 = b.take<float>(nn * ROW); t.G1 = b.take<float>(nn * ROW); t.G2 = b.take<float>(nn * ROW);
+  t.ggs = b.take<float>(nn * 2 * H); t.n128a = b.take<float>(nn * H); t.n128b = b.take<float>(nn * H);
+  t.esrc = b.take<int>(ne); t.edst = b.take<int>(ne); t.rev = b.take<int>(ne);
+  t.evec = b.take<float>(ne * 4); t.frame = b.take<float>(ne * FRAME); t.dedd = b.take<float>(ne);
+  t.tau = b.take<float>(ne * 4); t.gvec = b.take<float>(ne * 4);
+  for (auto& x : t.h1pre) x = b.take<float>(ne * RH);
+  for (auto& x : t.h2pre) x = b.take<float>(ne * RH);
+  t.ra = b.take<float>(ne * RH); t.rad_deg = b.take<float>(ne * 3 * C);
+  for (auto& x : t.rad) x = b.take<float>(ne * RAD);
+  for (auto& x : t.hg) x = b.take<float>(ne * HG);
+  for (auto& x : t.msg) x = b.take<float>(ne * ROW);
+  t.xrot = b.take<float>(ne * XROT); t.hid = b.take<float>(ne * ROW); t.gmsg = b.take<float>(ne * ROW);
+  t.ghg = b.take<float>(ne * HG); t.gy1 = b.take<float>(ne * XROT); t.grad = b.take<float>(ne * RAD);
+  t.e128a = b.take<float>(ne * RH); t.e128b = b.take<float>(ne * RH); t.ggauss = b.take<float>(ne * NG);
+  if (w) *w = t;
+  return (b.off + 255) & ~size_t(255);
+}
+
+int dbg_capture(umx_engine* eng, const std::string& name, const void* dptr, size_t bytes) {
+  if (!eng->dbg_on) return UMX_OK;
+  std::vector<char>& v = eng->dbg[name];
+  v.resize(bytes);
+  HIPCHK(eng, hipStreamSynchronize(eng->stream));
+  if (bytes) HIPCHK(eng, hipMemcpy(v.data(), dptr, bytes, hipMemcpyDeviceToHost));
+  return UMX_OK;
+}
+#define DBG(name, ptr, count) CHK(dbg_capture(eng, name, ptr, (size_t)(count) * sizeof(*(ptr))))
+
+// ---- radial MLP forward / backward -------------------------------------------------------------
+int radial_fwd(umx_engine* eng, const WS& w, const RadialW& r, int slot, long ne, float* rad_out) {
+  hipStream_t s = eng->stream;
+  const float gdelta = eng->cutoff / (NG - 1);
+  const float gcoef = -0.5f / ((2.0f * gdelta) * (2.0f * gdelta));
+  GemmP p = gp_zero();
+  p.evec = w.evec; p.gcoef = gcoef; p.gdelta = gdelta; p.B = r.w1g; p.ldb = NG; p.Cp = w.h1pre[slot]; p.ldc = RH;
+  p.TS = r.ts; p.TT = r.tt; p.esrc = w.esrc; p.edst = w.edst; p.znode = eng->d_z; p.natoms = eng->natoms;
+  p.M = (int)ne; p.N = RH; p.K = NG;
+  CHK(launch_gemm(eng, p, A_GAUSS, 0, E_TABLES));
+  hipLaunchKernelGGL(k_ln_silu_fwd, dim3(nblk(ne, 4)), dim3(256), 0, s, w.h1pre[slot], r.ln1w, r.ln1b, w.ra, ne);
+  CHK(gemm_plain(eng, w.ra, RH, 0, r.w2, RH, r.b2, w.h2pre[slot], RH, 0, ne, RH, RH));
+  hipLaunchKernelGGL(k_ln_silu_fwd, dim3(nblk(ne, 4)), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.ra, ne);
+  CHK(gemm_plain(eng, w.ra, RH, 0, r.w3, RH, r.b3, rad_out, r.out, 0, ne, r.out, RH));
+  HIPCHK(eng, hipGetLastError());
+  return UMX_OK;
+}
+
+int radial_bwd(umx_engine* eng, const WS& w, const RadialW& r, int slot, long ne, const float* grad) {
+  hipStream_t s = eng->stream;
+  const float gdelta = eng->cutoff / (NG - 1);
+  const float gcoef = -0.5f / ((2.0f * gdelta) * (2.0f * gdelta));
+  CHK(gemm_plain(eng, grad, r.out, 0, r.w3T, r.out, nullptr, w.e128a, RH, 0, ne, RH, r.out));
+  hipLaunchKernelGGL(k_ln_silu_bwd, dim3(nblk(ne, 4)), dim3(256), 0, s, w.e128a, w.h2pre[slot], r.ln2w, r.ln2b, w.e128b, ne);
+  CHK(gemm_plain(eng, w.e128b, RH, 0, r.w2T, RH, nullptr, w.e128a, RH, 0, ne, RH, RH));
+  hipLaunchKernelGGL(k_ln_silu_bwd, dim3(nblk(ne, 4)), dim3(256), 0, s, w.e128a, w.h1pre[slot], r.ln1w, r.ln1b, w.e128b, ne);
+  CHK(gemm_plain(eng, w.e128b, RH, 0, r.w1gT, RH, nullptr, w.ggauss, NG, 0, ne, NG, RH));
+  hipLaunchKernelGGL(k_radial_dd, dim3(nblk(ne, 4)), dim3(256), 0, s, w.ggauss, w.evec, gcoef, gdelta, w.dedd, ne);
+  HIPCHK(eng, hipGetLastError());
+  return UMX_OK;
+}
+
+// SO(3) linear on l-primary node rows: per degree l one GEMM with gridDim.z = 2l+1
+int so3_linear(umx_engine* eng, const float* A, const float* Wl, const float* bias, float* Cp, long nn, const float* resid) {
+  for (int l = 0; l < 3; ++l)
+    CHK(gemm_plain(eng, A, ROW, l * l * C, Wl + (long)l * C * C, C, l == 0 ? bias : nullptr, Cp, ROW, l * l * C, nn, C, C, A_PLAIN,
+                   2 * l + 1, C, C, resid, ROW, l * l * C, C));
+  return UMX_OK;
+}
+
+// ---- one chunk: nn nodes (= images * natoms), edges counted on the fly --------------------------
+int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, long nimg, long ne, double* d_energy, float* d_forces) {
+  hipStream_t s = eng->stream;
+  const int N = eng->natoms;
+  const long nn = nimg * N;
+  const float rc2 = eng->cutoff * eng->cutoff;
+  const dim3 B256(256);
+  // K1 graph
+  hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, d_deg, nn, w.row_ptr, w.stats);
+  hipLaunchKernelGGL(k_graph_fill, dim3(nblk(nn, 4)), B256, 0, s, d_pos, N, nn, rc2, w.row_ptr, w.esrc, w.edst, w.evec);
+  if (ne > 0) {
+    hipLaunchKernelGGL(k_rev, dim3(nblk(ne, 256)), B256, 0, s, w.esrc, w.edst, w.row_ptr, ne, w.rev);
+    hipLaunchKernelGGL(k_edge_geom, dim3(nblk(ne, 256)), B256, 0, s, w.evec, ne, eng->cutoff, w.frame);
+  }
+  HIPCHK(eng, hipGetLastError());
+  DBG("row_ptr", w.row_ptr, nn + 1); DBG("src", w.esrc, ne); DBG("dst", w.edst, ne); DBG("rev", w.rev, ne);
+  DBG("evec", w.evec, ne * 4); DBG("frame", w.frame, ne * FRAME);
+  // K4 + K5
+  hipLaunchKernelGGL(k_node_init, dim3(nblk(nn * ROW, 256)), B256, 0, s, eng->d_z, N, nn, eng->emb_sphere, eng->d_sysemb, w.xs[0]);
+  if (ne > 0) CHK(radial_fwd(eng, w, eng->rdeg, NL, ne, w.rad_deg));
+  hipLaunchKernelGGL(k_rotate_back_reduce<3>, dim3(nblk(nn, 4)), B256, 0, s, w.rad_deg, w.frame, w.row_ptr, w.xs[0], w.xs[0], nn,
+                     1.0f / DEG_RESCALE);
+  HIPCHK(eng, hipGetLastError());
+  DBG("rad.deg", w.rad_deg, ne * 3 * C); DBG("x0", w.xs[0], nn * ROW);
+
+  for (int i = 0; i < NL; ++i) {
+    const LayerW& L = eng->lw[i];
+    const std::string t = "." + std::to_string(i);
+    float* xin = w.xs[2 * i];
+    float* xmid = w.xs[2 * i + 1];
+    float* xout = w.xs[2 * i + 2];
+    hipLaunchKernelGGL(k_norm_fwd, dim3(nblk(nn, 4)), B256, 0, s, xin, L.n1w, L.n1b, eng->d_sysemb, w.xn[i], nn);
+    if (ne > 0) {
+      hipLaunchKernelGGL(k_gather_rotate, dim3(nblk(ne, 4)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.xrot, ne);
+      CHK(radial_fwd(eng, w, L.rad, i, ne, w.rad[i]));
+      // SO(2) conv 1 (radially modulated) -> hg = [gate | hpre]
+      {
+        GemmP p = gp_zero();
+        p.A = w.xrot; p.lda = XROT; p.R = w.rad[i]; p.ldr = RAD; p.B = L.c1m0; p.ldb = 3 * 2 * C; p.bias = L.c1m0b;
+        p.Cp = w.hg[i]; p.ldc = HG; p.M = (int)ne; p.N = 2 * H + 3 * H; p.K = 3 * 2 * C;
+        CHK(launch_gemm(eng, p, A_MODUL, 0, E_BIAS));
+      }
+      CHK(gemm_cplx(eng, w.xrot, XROT, 768, 1280, w.rad[i], RAD, 768, L.c1m1, 512, 256, w.hg[i], HG, 640, 896, ne, 256, 512, 1.0f));
+      CHK(gemm_cplx(eng, w.xrot, XROT, 1792, 2048, w.rad[i], RAD, 1280, L.c1m2, 256, 128, w.hg[i], HG, 1152, 1280, ne, 128, 256, 1.0f));
+      hipLaunchKernelGGL(k_gate_edge_fwd, dim3(nblk(ne * (H / 4), 256)), B256, 0, s, w.hg[i], w.hid, ne);
+      // SO(2) conv 2 -> msg
+      CHK(gemm_plain(eng, w.hid, ROW, 0, L.c2m0, 3 * H, L.c2m0b, w.msg[i], ROW, 0, ne, 3 * C, 3 * H));
+      CHK(gemm_cplx(eng, w.hid, ROW, 384, 640, nullptr, 0, 0, L.c2m1, 256, 256, w.msg[i], ROW, 384, 640, ne, 256, 256, 1.0f));
+      CHK(gemm_cplx(eng, w.hid, ROW, 896, 1024, nullptr, 0, 0, L.c2m2, 128, 128, w.msg[i], ROW, 896, 1024, ne, 128, 128, 1.0f));
+    }
+    hipLaunchKernelGGL(k_rotate_back_reduce<9>, dim3(nblk(nn, 4)), B256, 0, s, w.msg[i], w.frame, w.row_ptr, xin, xmid, nn, 1.0f);
+    HIPCHK(eng, hipGetLastError());
+    DBG("xn" + t, w.xn[i], nn * ROW); DBG("xrot" + t, w.xrot, ne * XROT); DBG("rad" + t, w.rad[i], ne * RAD);
+    DBG("hg" + t, w.hg[i], ne * HG); DBG("hid" + t, w.hid, ne * ROW); DBG("msg" + t, w.msg[i], ne * ROW); DBG("xmid" + t, xmid, nn * ROW);
+    // K8 atom-wise
+    hipLaunchKernelGGL(k_norm_fwd, dim3(nblk(nn, 4)), B256, 0, s, xmid, L.n2w, L.n2b, (const float*)nullptr, w.xn2, nn);
+    CHK(gemm_plain(eng, w.xn2, ROW, 0, L.smlp, C, L.smlpb, w.gspre[i], 2 * H, 0, nn, 2 * H, C));
+    CHK(so3_linear(eng, w.xn2, L.l1w, L.l1b, w.ffh[i], nn, nullptr));
+    hipLaunchKernelGGL(k_gate_node_fwd, dim3(nblk(nn * H, 256)), B256, 0, s, w.ffh[i], w.gspre[i], w.ffhg, nn);
+    CHK(so3_linear(eng, w.ffhg, L.l2w, L.l2b, xout, nn, xmid));
+    HIPCHK(eng, hipGetLastError());
+    DBG("xn2" + t, w.xn2, nn * ROW); DBG("gspre" + t, w.gspre[i], nn * 2 * H); DBG("ffh" + t, w.ffh[i], nn * ROW); DBG("x" + t, xout, nn * ROW);
+  }
+  // K9 readout
+  float* xlast = w.xs[2 * NL];
+  hipLaunchKernelGGL(k_norm_fwd, dim3(nblk(nn, 4)), B256, 0, s, xlast, eng->normw, eng->normb, (const float*)nullptr, w.xf, nn);
+  CHK(gemm_plain(eng, w.xf, ROW, 0, eng->e0, C, eng->e0b, w.pre1, H, 0, nn, H, C));
+  CHK(gemm_plain(eng, w.pre1, H, 0, eng->e2, H, eng->e2b, w.pre2, H, 0, nn, H, H, A_SILU));
+  hipLaunchKernelGGL(k_energy, dim3((unsigned)nimg), B256, 0, s, w.pre2, eng->e4, eng->e4b, N, eng->rmsd, eng->refsum, d_energy, w.enode);
+  HIPCHK(eng, hipGetLastError());
+  DBG("e_node", w.enode, nn); DBG("pre1", w.pre1, nn * H); DBG("pre2", w.pre2, nn * H);
+  if (!d_forces) return UMX_OK;
+
+  // ---------------- K10: analytic reverse pass ----------------
+  if (ne > 0) {
+    HIPCHK(eng, hipMemsetAsync(w.dedd, 0, ne * sizeof(float), s));
+    HIPCHK(eng, hipMemsetAsync(w.tau, 0, ne * 4 * sizeof(float), s));
+  }
+  hipLaunchKernelGGL(k_silu_bwd, dim3(nblk(nn * H, 256)), B256, 0, s, eng->e4, 0L, w.pre2, w.n128a, nn, H);
+  CHK(gemm_plain(eng, w.n128a, H, 0, eng->e2T, H, nullptr, w.n128b, H, 0, nn, H, H));
+  hipLaunchKernelGGL(k_silu_bwd, dim3(nblk(nn * H, 256)), B256, 0, s, w.n128b, (long)H, w.pre1, w.n128a, nn, H);
+  HIPCHK(eng, hipMemsetAsync(w.G1, 0, nn * ROW * sizeof(float), s));
+  CHK(gemm_plain(eng, w.n128a, H, 0, eng->e0T, H, nullptr, w.G1, ROW, 0, nn, C, H));
+  hipLaunchKernelGGL(k_norm_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.G1, xlast, eng->normw, (const float*)nullptr, w.G0, nn);
+  HIPCHK(eng, hipGetLastError());
+  DBG("g_xfinal", w.G0, nn * ROW);
+  for (int i = NL - 1; i >= 0; --i) {
+    const LayerW& L = eng->lw[i];
+    const std::string t = "." + std::to_string(i);
+    float* xin = w.xs[2 * i];
+    float* xmid = w.xs[2 * i + 1];
+    // atom-wise backward: G0 = dE/dx_out
+    CHK(so3_linear(eng, w.G0, L.l2T, nullptr, w.G1, nn, nullptr));                         // G1 = g_ffhg
+    hipLaunchKernelGGL(k_gate_node_bwd, dim3(nblk(nn * H, 256)), B256, 0, s, w.G1, w.ffh[i], w.gspre[i], w.G2, w.ggs, nn);
+    CHK(so3_linear(eng, w.G2, L.l1T, nullptr, w.G1, nn, nullptr));                         // G1 = g_xn2
+    CHK(gemm_plain(eng, w.ggs, 2 * H, 0, L.smlpT, 2 * H, nullptr, w.G1, ROW, 0, nn, C, 2 * H, A_PLAIN, 1, 0, 0, w.G1, ROW, 0, 0));
+    hipLaunchKernelGGL(k_norm_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.G1, xmid, L.n2w, w.G0, w.G2, nn);   // G2 = g_xmid
+    HIPCHK(eng, hipGetLastError());
+    DBG("g_xmid" + t, w.G2, nn * ROW);
+    if (ne > 0) {
+      hipLaunchKernelGGL(k_rotate_back_bwd<9>, dim3(nblk(ne, 4)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsg, w.dedd, w.tau, ne, 1.0f);
+      CHK(gemm_plain(eng, w.gmsg, ROW, 0, L.c2m0T, 3 * C, nullptr, w.hid, ROW, 0, ne, 3 * H, 3 * C));
+      CHK(gemm_cplx(eng, w.gmsg, ROW, 384, 640, nullptr, 0, 0, L.c2m1T, 256, 256, w.hid, ROW, 384, 640, ne, 256, 256, -1.0f));
+      CHK(gemm_cplx(eng, w.gmsg, ROW, 896, 1024, nullptr, 0, 0, L.c2m2T, 128, 128, w.hid, ROW, 896, 1024, ne, 128, 128, -1.0f));
+      DBG("g_msg" + t, w.gmsg, ne * ROW); DBG("g_hid" + t, w.hid, ne * ROW);
+      hipLaunchKernelGGL(k_gate_edge_bwd, dim3(nblk(ne * H, 256)), B256, 0, s, w.hid, w.hg[i], w.ghg, ne);
+      CHK(gemm_plain(eng, w.ghg, HG, 0, L.c1m0T, 640, nullptr, w.gy1, XROT, 0, ne, 768, 640));
+      CHK(gemm_cplx(eng, w.ghg, HG, 640, 896, nullptr, 0, 0, L.c1m1T, 256, 512, w.gy1, XROT, 768, 1280, ne, 512, 256, -1.0f));
+      CHK(gemm_cplx(eng, w.ghg, HG, 1152, 1280, nullptr, 0, 0, L.c1m2T, 128, 256, w.gy1, XROT, 1792, 2048, ne, 256, 128, -1.0f));
+      DBG("g_hg" + t, w.ghg, ne * HG);
+      hipLaunchKernelGGL(k_gather_rotate, dim3(nblk(ne, 4)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.xrot, ne);
+      hipLaunchKernelGGL(k_modulate_bwd, dim3(nblk(ne, 4)), B256, 0, s, w.gy1, w.xrot, w.rad[i], w.grad, w.tau, ne);
+      DBG("g_xrot" + t, w.gy1, ne * XROT); DBG("g_rad" + t, w.grad, ne * RAD);
+      CHK(radial_bwd(eng, w, L.rad, i, ne, w.grad));
+    }
+    hipLaunchKernelGGL(k_gather_rotate_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.gy1, w.frame, w.row_ptr, w.rev, w.G1, nn);   // G1 = g_xn
+    hipLaunchKernelGGL(k_norm_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.G1, xin, L.n1w, w.G2, w.G0, nn);                      // G0 = g_xin
+    HIPCHK(eng, hipGetLastError());
+    DBG("g_xn" + t, w.G1, nn * ROW); DBG("g_xin" + t, w.G0, nn * ROW);
+  }
+  if (ne > 0) {
+    hipLaunchKernelGGL(k_rotate_back_bwd<3>, dim3(nblk(ne, 4)), B256, 0, s, w.G0, w.rad_deg, w.frame, w.edst, w.gmsg, w.dedd, w.tau, ne,
+                       1.0f / DEG_RESCALE);
+    CHK(radial_bwd(eng, w, eng->rdeg, NL, ne, w.gmsg));
+    hipLaunchKernelGGL(k_force_edge, dim3(nblk(ne, 256)), B256, 0, s, w.dedd, w.tau, w.frame, w.evec, w.gvec, ne);
+  }
+  hipLaunchKernelGGL(k_force_node, dim3(nblk(nn, 4)), B256, 0, s, w.gvec, w.row_ptr, w.rev, (float)eng->rmsd, d_forces, nn);
+  HIPCHK(eng, hipGetLastError());
+  DBG("dedd", w.dedd, ne); DBG("tau", w.tau, ne * 4); DBG("gvec", w.gvec, ne * 4);
+  return UMX_OK;
+}
+
+// per-image edge totals from the per-node degrees
+__global__ void k_image_edges(const int* __restrict__ deg, int natoms, int* __restrict__ out, int* __restrict__ maxdeg) {
+  __shared__ int part[256];
+  __shared__ int pm[256];
+  const int img = blockIdx.x;
+  int s = 0, m = 0;
+  for (int a = threadIdx.x; a < natoms; a += 256) { const int d = deg[(long)img * natoms + a]; s += d; m = d > m ? d : m; }
+  part[threadIdx.x] = s; pm[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { part[threadIdx.x] += part[threadIdx.x + o]; pm[threadIdx.x] = max(pm[threadIdx.x], pm[threadIdx.x + o]); }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[img] = part[0]; atomicMax(maxdeg, pm[0]); }
+}
+
+// ---- weights -----------------------------------------------------------------------------------
+std::vector<float> transpose(const float* src, int rows, int cols) {
+  std::vector<float> t((size_t)rows * cols);
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) t[(size_t)c * rows + r] = src[(size_t)r * cols + c];
+  return t;
+}
+
+}  // namespace
+
+// ================================================================================================
+//                                           C ABI
+// ================================================================================================
+extern "C" {
+
+int umx_abi_version(void) { return 1; }
+
+const char* umx_last_error(const umx_engine* eng) { return eng ? eng->err.c_str() : g_create_err.c_str(); }
+
+int umx_create(umx_engine** out, int device_ordinal) {
+  if (!out) { g_create_err = "umx_create: null out pointer"; return UMX_ERR_ARG; }
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_create_err = "umx_create: no HIP device visible"; return UMX_ERR_NO_DEVICE; }
+  if (device_ordinal < 0 || device_ordinal >= n) { g_create_err = "umx_create: device ordinal out of range"; return UMX_ERR_ARG; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) { g_create_err = "umx_create: hipGetDeviceProperties failed"; return UMX_ERR_HIP; }
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+    g_create_err = std::string("umx_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+    return UMX_ERR_NO_DEVICE;
+  }
+  umx_engine* e = new umx_engine();
+  e->dev = device_ordinal;
+  if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+    g_create_err = "umx_create: hipSetDevice/hipStreamCreate failed";
+    delete e;
+    return UMX_ERR_HIP;
+  }
+  *out = e;
+  return UMX_OK;
+}
+
+int umx_destroy(umx_engine* eng) {
+  if (!eng) return UMX_OK;
+  (void)hipSetDevice(eng->dev);
+  (void)hipStreamSynchronize(eng->stream);
+  for (auto& r : eng->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  void* ptrs[] = {eng->d_w, eng->d_dw, eng->d_z, eng->d_sysemb, eng->arena, eng->d_deg_all, eng->d_img_edges, eng->d_io_pos, eng->d_io_e, eng->d_io_f};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  (void)hipStreamDestroy(eng->stream);
+  delete eng;
+  return UMX_OK;
+}
+
+int umx_set_workspace_limit(umx_engine* eng, size_t bytes) {
+  if (!eng) return UMX_ERR_ARG;
+  eng->ws_limit = bytes;
+  return UMX_OK;
+}
+
+int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes) {
+  if (!eng || !blob) return UMX_ERR_ARG;
+  HIPCHK(eng, hipSetDevice(eng->dev));
+  const char* b = static_cast<const char*>(blob);
+  if (nbytes < 16 || std::memcmp(b, "UMXW0001", 8) != 0) return fail(eng, UMX_ERR_WEIGHTS, "weight blob: bad magic");
+  uint32_t n;
+  std::memcpy(&n, b + 8, 4);
+  const size_t esz = 96 + 4 + 16 + 8 + 8;
+  if (nbytes < 16 + (size_t)n * esz) return fail(eng, UMX_ERR_WEIGHTS, "weight blob: truncated table");
+  size_t pos = 16;
+  eng->wt.clear();
+  size_t max_end = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    char name[97]; std::memcpy(name, b + pos, 96); name[96] = 0;
+    uint32_t ndim, dims[4]; uint64_t off, nb;
+    std::memcpy(&ndim, b + pos + 96, 4); std::memcpy(dims, b + pos + 100, 16);
+    std::memcpy(&off, b + pos + 116, 8); std::memcpy(&nb, b + pos + 124, 8);
+    if (ndim < 1 || ndim > 4) return fail(eng, UMX_ERR_WEIGHTS, std::string("weight blob: bad ndim for ") + name);
+    Tensor t; t.off = off / 4; t.count = nb / 4;
+    size_t cnt = 1;
+    for (uint32_t d = 0; d < ndim; ++d) { t.shape.push_back((int)dims[d]); cnt *= dims[d]; }
+    if (cnt != t.count) return fail(eng, UMX_ERR_WEIGHTS, std::string("weight blob: size mismatch for ") + name);
+    eng->wt[name] = t;
+    max_end = std::max(max_end, (size_t)(off + nb));
+    pos += esz;
+  }
+  const size_t data0 = (pos + 63) & ~size_t(63);
+  if (nbytes < data0 + max_end) return fail(eng, UMX_ERR_WEIGHTS, "weight blob: truncated data");
+  eng->h_w.assign(reinterpret_cast<const float*>(b + data0), reinterpret_cast<const float*>(b + data0) + (max_end + 3) / 4);
+
+  auto need = [&](const std::string& nm, std::vector<int> shape) -> const Tensor* {
+    auto it = eng->wt.find(nm);
+    if (it == eng->wt.end() || it->second.shape != shape) { eng->err = "weight blob: missing or mis-shaped tensor " + nm; return nullptr; }
+    return &it->second;
+  };
+  // ---- derived weights (host) ----
+  std::vector<float> dw;
+  auto push = [&](const std::vector<float>& v) -> size_t {
+    size_t o = (dw.size() + 63) & ~size_t(63);
+    dw.resize(o + v.size());
+    std::copy(v.begin(), v.end(), dw.begin() + o);
+    return o;
+  };
+  const float* hw = eng->h_w.data();
+  struct RadOff { size_t w1g, w1gT, ts, tt, w2T, w3T; };
+  std::map<std::string, RadOff> roff;
+  const Tensor* tsrc = need("source_embedding.weight", {NZ, 128});
+  const Tensor* ttgt = need("target_embedding.weight", {NZ, 128});
+  if (!tsrc || !ttgt) return UMX_ERR_WEIGHTS;
+  auto radial_derive = [&](const std::string& pre, int out) -> int {
+    const Tensor* w1 = need(pre + ".fc1.weight", {RH, NG + 256});
+    const Tensor* b1 = need(pre + ".fc1.bias", {RH});
+    const Tensor* w2 = need(pre + ".fc2.weight", {RH, RH});
+    const Tensor* w3 = need(pre + ".fc3.weight", {out, RH});
+    for (const char* s : {".fc2.bias", ".ln1.weight", ".ln1.bias", ".ln2.weight", ".ln2.bias"})
+      if (!need(pre + s, {RH})) return UMX_ERR_WEIGHTS;
+    if (!w1 || !b1 || !w2 || !w3 || !need(pre + ".fc3.bias", {out})) return UMX_ERR_WEIGHTS;
+    const float* W1 = hw + w1->off;
+    std::vector<float> w1g((size_t)RH * NG), ts((size_t)NZ * RH), tt((size_t)NZ * RH);
+    for (int h = 0; h < RH; ++h)
+      for (int k = 0; k < NG; ++k) w1g[(size_t)h * NG + k] = W1[(size_t)h * (NG + 256) + k];
+    for (int z = 0; z < NZ; ++z)
+      for (int h = 0; h < RH; ++h) {
+        double a = 0.0, c = hw[b1->off + h];
+        for (int k = 0; k < 128; ++k) {
+          a += (double)W1[(size_t)h * (NG + 256) + NG + k] * hw[tsrc->off + (size_t)z * 128 + k];
+          c += (double)W1[(size_t)h * (NG + 256) + NG + 128 + k] * hw[ttgt->off + (size_t)z * 128 + k];
+        }
+        ts[(size_t)z * RH + h] = (float)a;
+        tt[(size_t)z * RH + h] = (float)c;
+      }
+    RadOff o;
+    o.w1g = push(w1g); o.w1gT = push(transpose(w1g.data(), RH, NG)); o.ts = push(ts); o.tt = push(tt);
+    o.w2T = push(transpose(hw + w2->off, RH, RH)); o.w3T = push(transpose(hw + w3->off, out, RH));
+    roff[pre] = o;
+    return UMX_OK;
+  };
+  CHK(radial_derive("edge_degree_embedding.rad_func", 3 * C));
+  struct LayOff { size_t c1m0T, c1m1T, c1m2T, c2m0T, c2m1T, c2m2T, smlpT, l1T, l2T; };
+  LayOff loff[NL];
+  auto half_T = [&](const float* src, int half, int kin) {   // W (2*half x kin) -> (2, kin, half)
+    std::vector<float> t((size_t)2 * half * kin);
+    for (int ab = 0; ab < 2; ++ab)
+      for (int hh = 0; hh < half; ++hh)
+        for (int k = 0; k < kin; ++k) t[((size_t)ab * kin + k) * half + hh] = src[((size_t)ab * half + hh) * kin + k];
+    return t;
+  };
+  auto per_l_T = [&](const float* src) {                     // (3, out, in) -> (3, in, out)
+    std::vector<float> t((size_t)3 * C * C);
+    for (int l = 0; l < 3; ++l)
+      for (int o = 0; o < C; ++o)
+        for (int i = 0; i < C; ++i) t[((size_t)l * C + i) * C + o] = src[((size_t)l * C + o) * C + i];
+    return t;
+  };
+  for (int i = 0; i < NL; ++i) {
+    const std::string bpre = "blocks." + std::to_string(i);
+    const std::string c1 = bpre + ".edge_wise.so2_conv_1", c2 = bpre + ".edge_wise.so2_conv_2", aw = bpre + ".atom_wise";
+    const Tensor *a = need(c1 + ".fc_m0.weight", {640, 768}), *b1m = need(c1 + ".so2_m_conv.0.fc.weight", {512, 512}),
+                 *c = need(c1 + ".so2_m_conv.1.fc.weight", {256, 256}), *d = need(c2 + ".fc_m0.weight", {384, 384}),
+                 *e = need(c2 + ".so2_m_conv.0.fc.weight", {512, 256}), *f = need(c2 + ".so2_m_conv.1.fc.weight", {256, 128}),
+                 *g = need(aw + ".scalar_mlp.weight", {256, 128}), *h1 = need(aw + ".so3_linear_1.weight", {3, 128, 128}),
+                 *h2 = need(aw + ".so3_linear_2.weight", {3, 128, 128});
+    if (!a || !b1m || !c || !d || !e || !f || !g || !h1 || !h2) return UMX_ERR_WEIGHTS;
+    if (!need(c1 + ".fc_m0.bias", {640}) || !need(c2 + ".fc_m0.bias", {384}) || !need(aw + ".scalar_mlp.bias", {256}) ||
+        !need(aw + ".so3_linear_1.bias", {128}) || !need(aw + ".so3_linear_2.bias", {128}) ||
+        !need(bpre + ".norm_1.affine_weight", {3, 128}) || !need(bpre + ".norm_1.affine_bias", {128}) ||
+        !need(bpre + ".norm_2.affine_weight", {3, 128}) || !need(bpre + ".norm_2.affine_bias", {128}))
+      return UMX_ERR_WEIGHTS;
+    CHK(radial_derive(c1 + ".rad_func", RAD));
+    loff[i].c1m0T = push(transpose(hw + a->off, 640, 768));
+    loff[i].c1m1T = push(half_T(hw + b1m->off, 256, 512));
+    loff[i].c1m2T = push(half_T(hw + c->off, 128, 256));
+    loff[i].c2m0T = push(transpose(hw + d->off, 384, 384));
+    loff[i].c2m1T = push(half_T(hw + e->off, 256, 256));
+    loff[i].c2m2T = push(half_T(hw + f->off, 128, 128));
+    loff[i].smlpT = push(transpose(hw + g->off, 256, 128));
+    loff[i].l1T = push(per_l_T(hw + h1->off));
+    loff[i].l2T = push(per_l_T(hw + h2->off));
+  }
+  const Tensor *te0 = need("energy_block.0.weight", {128, 128}), *te2 = need("energy_block.2.weight", {128, 128}),
+               *te4 = need("energy_block.4.weight", {1, 128});
+  if (!te0 || !te2 || !te4 || !need("energy_block.0.bias", {128}) || !need("energy_block.2.bias", {128}) ||
+      !need("energy_block.4.bias", {1}) || !need("norm.affine_weight", {3, 128}) || !need("norm.affine_bias", {128}) ||
+      !need("sphere_embedding.weight", {NZ, 128}) || !need("charge_embedding.weight", {201, 128}) ||
+      !need("spin_embedding.weight", {101, 128}) || !need("dataset_embedding.weight", {5, 128}) ||
+      !need("mix_csd.weight", {128, 384}) || !need("mix_csd.bias", {128}) || !need("normalizer.rmsd", {1}) ||
+      !need("element_refs", {NZ}))
+    return UMX_ERR_WEIGHTS;
+  const size_t oe0T = push(transpose(hw + te0->off, 128, 128)), oe2T = push(transpose(hw + te2->off, 128, 128));
+
+  // ---- upload ----
+  if (eng->d_w) { HIPCHK(eng, hipFree(eng->d_w)); eng->d_w = nullptr; }
+  if (eng->d_dw) { HIPCHK(eng, hipFree(eng->d_dw)); eng->d_dw = nullptr; }
+  HIPCHK(eng, hipMalloc(&eng->d_w, eng->h_w.size() * sizeof(float)));
+  HIPCHK(eng, hipMemcpy(eng->d_w, eng->h_w.data(), eng->h_w.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(eng, hipMalloc(&eng->d_dw, dw.size() * sizeof(float)));
+  HIPCHK(eng, hipMemcpy(eng->d_dw, dw.data(), dw.size() * sizeof(float), hipMemcpyHostToDevice));
+  auto W = [&](const std::string& nm) -> const float* { return eng->d_w + eng->wt[nm].off; };
+  auto D = [&](size_t o) -> const float* { return eng->d_dw + o; };
+  auto fill_rad = [&](RadialW& r, const std::string& pre, int out) {
+    const RadOff& o = roff[pre];
+    r.w1g = D(o.w1g); r.w1gT = D(o.w1gT); r.ts = D(o.ts); r.tt = D(o.tt); r.w2T = D(o.w2T); r.w3T = D(o.w3T);
+    r.ln1w = W(pre + ".ln1.weight"); r.ln1b = W(pre + ".ln1.bias"); r.w2 = W(pre + ".fc2.weight"); r.b2 = W(pre + ".fc2.bias");
+    r.ln2w = W(pre + ".ln2.weight"); r.ln2b = W(pre + ".ln2.bias"); r.w3 = W(pre + ".fc3.weight"); r.b3 = W(pre + ".fc3.bias");
+    r.out = out;
+  };
+  fill_rad(eng->rdeg, "edge_degree_embedding.rad_func", 3 * C);
+  for (int i = 0; i < NL; ++i) {
+    const std::string bpre = "blocks." + std::to_string(i);
+    const std::string c1 = bpre + ".edge_wise.so2_conv_1", c2 = bpre + ".edge_wise.so2_conv_2", aw = bpre + ".atom_wise";
+    LayerW& L = eng->lw[i];
+    L.n1w = W(bpre + ".norm_1.affine_weight"); L.n1b = W(bpre + ".norm_1.affine_bias");
+    L.n2w = W(bpre + ".norm_2.affine_weight"); L.n2b = W(bpre + ".norm_2.affine_bias");
+    L.c1m0 = W(c1 + ".fc_m0.weight"); L.c1m0b = W(c1 + ".fc_m0.bias"); L.c1m0T = D(loff[i].c1m0T);
+    L.c1m1 = W(c1 + ".so2_m_conv.0.fc.weight"); L.c1m1T = D(loff[i].c1m1T);
+    L.c1m2 = W(c1 + ".so2_m_conv.1.fc.weight"); L.c1m2T = D(loff[i].c1m2T);
+    L.c2m0 = W(c2 + ".fc_m0.weight"); L.c2m0b = W(c2 + ".fc_m0.bias"); L.c2m0T = D(loff[i].c2m0T);
+    L.c2m1 = W(c2 + ".so2_m_conv.0.fc.weight"); L.c2m1T = D(loff[i].c2m1T);
+    L.c2m2 = W(c2 + ".so2_m_conv.1.fc.weight"); L.c2m2T = D(loff[i].c2m2T);
+    L.smlp = W(aw + ".scalar_mlp.weight"); L.smlpb = W(aw + ".scalar_mlp.bias"); L.smlpT = D(loff[i].smlpT);
+    L.l1w = W(aw + ".so3_linear_1.weight"); L.l1b = W(aw + ".so3_linear_1.bias"); L.l1T = D(loff[i].l1T);
+    L.l2w = W(aw + ".so3_linear_2.weight"); L.l2b = W(aw + ".so3_linear_2.bias"); L.l2T = D(loff[i].l2T);
+    fill_rad(L.rad, c1 + ".rad_func", RAD);
+  }
+  eng->emb_sphere = W("sphere_embedding.weight");
+  eng->normw = W("norm.affine_weight"); eng->normb = W("norm.affine_bias");
+  eng->e0 = W("energy_block.0.weight"); eng->e0b = W("energy_block.0.bias"); eng->e0T = D(oe0T);
+  eng->e2 = W("energy_block.2.weight"); eng->e2b = W("energy_block.2.bias"); eng->e2T = D(oe2T);
+  eng->e4 = W("energy_block.4.weight"); eng->e4b = W("energy_block.4.bias");
+  eng->rmsd = (double)hw[eng->wt["normalizer.rmsd"].off];
+  eng->elem_refs.assign(NZ, 0.0);
+  for (int z = 0; z < NZ; ++z) eng->elem_refs[z] = (double)hw[eng->wt["element_refs"].off + z];
+  eng->have_weights = true;
+  eng->have_system = false;
+  return UMX_OK;
+}
+
+int umx_set_system(umx_engine* eng, int n_atoms, const int32_t* z, int charge, int spin, int task_index, float radius, int max_neigh) {
+  if (!eng) return UMX_ERR_ARG;
+  if (!eng->have_weights) return fail(eng, UMX_ERR_ARG, "umx_set_system: load weights first");
+  if (n_atoms <= 0 || !z) return fail(eng, UMX_ERR_ARG, "umx_set_system: empty system");
+  if (charge < -100 || charge > 100) return fail(eng, UMX_ERR_ARG, "umx_set_system: charge outside [-100, 100]");
+  if (spin < 0 || spin > 100) return fail(eng, UMX_ERR_ARG, "umx_set_system: spin multiplicity outside [0, 100]");
+  if (task_index < 0 || task_index > 4) return fail(eng, UMX_ERR_ARG, "umx_set_system: task index outside [0, 4]");
+  HIPCHK(eng, hipSetDevice(eng->dev));
+  double rs = 0.0;
+  for (int i = 0; i < n_atoms; ++i) {
+    if (z[i] < 0 || z[i] >= NZ) return fail(eng, UMX_ERR_ARG, "umx_set_system: atomic number outside [0, 99]");
+    rs += eng->elem_refs[z[i]];
+  }
+  HIPCHK(eng, hipStreamSynchronize(eng->stream));
+  if (eng->d_z) { HIPCHK(eng, hipFree(eng->d_z)); eng->d_z = nullptr; }
+  HIPCHK(eng, hipMalloc(&eng->d_z, n_atoms * sizeof(int)));
+  HIPCHK(eng, hipMemcpy(eng->d_z, z, n_atoms * sizeof(int), hipMemcpyHostToDevice));
+  if (!eng->d_sysemb) HIPCHK(eng, hipMalloc(&eng->d_sysemb, C * sizeof(float)));
+  auto W = [&](const std::string& nm) -> const float* { return eng->d_w + eng->wt[nm].off; };
+  hipLaunchKernelGGL(k_sys_emb, dim3(1), dim3(C), 0, eng->stream, W("charge_embedding.weight") + (long)(charge + 100) * C,
+                     W("spin_embedding.weight") + (long)spin * C, W("dataset_embedding.weight") + (long)task_index * C,
+                     W("mix_csd.weight"), W("mix_csd.bias"), eng->d_sysemb);
+  HIPCHK(eng, hipGetLastError());
+  HIPCHK(eng, hipStreamSynchronize(eng->stream));
+  eng->natoms = n_atoms;
+  eng->refsum = rs;
+  eng->cutoff = radius > 0.f ? radius : 6.0f;
+  eng->max_neigh = max_neigh > 0 ? max_neigh : 300;
+  eng->have_system = true;
+  return UMX_OK;
+}
+
+int umx_synchronize(umx_engine* eng) {
+  if (!eng) return UMX_ERR_ARG;
+  HIPCHK(eng, hipStreamSynchronize(eng->stream));
+  return UMX_OK;
+}
+
+int umx_energy_forces_dev(umx_engine* eng, int n_images, const float* d_pos, double* d_energy, float* d_forces, void* hip_stream) {
+  if (!eng) return UMX_ERR_ARG;
+  if (!eng->have_system) return fail(eng, UMX_ERR_ARG, "umx_energy_forces: bind a system first (umx_set_system)");
+  if (n_images <= 0 || !d_pos || !d_energy) return fail(eng, UMX_ERR_ARG, "umx_energy_forces: bad arguments");
+  HIPCHK(eng, hipSetDevice(eng->dev));
+  hipStream_t user = static_cast<hipStream_t>(hip_stream);
+  hipStream_t own = eng->stream;
+  if (user) eng->stream = user;
+  struct Restore { umx_engine* e; hipStream_t s; ~Restore() { e->stream = s; } } restore{eng, own};
+  hipStream_t s = eng->stream;
+  const int N = eng->natoms;
+  const long K = n_images, nt = K * N;
+  // pass 1: degrees of every node of every image, per-image edge totals
+  if (eng->deg_all_cap < nt) {
+    HIPCHK(eng, hipStreamSynchronize(s));
+    if (eng->d_deg_all) HIPCHK(eng, hipFree(eng->d_deg_all));
+    HIPCHK(eng, hipMalloc(&eng->d_deg_all, nt * sizeof(int)));
+    eng->deg_all_cap = nt;
+  }
+  if (eng->img_edges_cap < K + 1) {
+    HIPCHK(eng, hipStreamSynchronize(s));
+    if (eng->d_img_edges) HIPCHK(eng, hipFree(eng->d_img_edges));
+    HIPCHK(eng, hipMalloc(&eng->d_img_edges, (K + 1) * sizeof(int)));
+    eng->img_edges_cap = K + 1;
+  }
+  HIPCHK(eng, hipMemsetAsync(eng->d_img_edges + K, 0, sizeof(int), s));
+  hipLaunchKernelGGL(k_graph_count, dim3(nblk(nt, 4)), dim3(256), 0, s, d_pos, N, nt, eng->cutoff * eng->cutoff, eng->d_deg_all);
+  hipLaunchKernelGGL(k_image_edges, dim3((unsigned)K), dim3(256), 0, s, eng->d_deg_all, N, eng->d_img_edges, eng->d_img_edges + K);
+  HIPCHK(eng, hipGetLastError());
+  std::vector<int> img_edges(K + 1);
+  HIPCHK(eng, hipMemcpyAsync(img_edges.data(), eng->d_img_edges, (K + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(eng, hipStreamSynchronize(s));
+  eng->last_maxdeg = img_edges[K];
+  eng->last_edges = 0;
+  for (long k = 0; k < K; ++k) eng->last_edges += img_edges[k];
+  if (eng->last_maxdeg > eng->max_neigh)
+    return fail(eng, UMX_ERR_CAPACITY, "neighbour count " + std::to_string(eng->last_maxdeg) + " exceeds max_neigh " +
+                                           std::to_string(eng->max_neigh) + " (nearest-M truncation is not implemented)");
+  // chunk planning under the workspace budget
+  size_t budget = eng->ws_limit;
+  if (!budget) {
+    size_t fr = 0, tot = 0;
+    HIPCHK(eng, hipMemGetInfo(&fr, &tot));
+    budget = (size_t)((fr + eng->arena_bytes) * 0.85);
+  }
+  long max_chunk = K;
+  if (const char* ev = std::getenv("UMX_MAX_CHUNK_IMAGES")) { long v = std::atol(ev); if (v > 0) max_chunk = std::min(max_chunk, v); }
+  std::vector<std::pair<long, long>> chunks;   // [k0, k1)
+  long need_nodes = 0, need_edges = 0;
+  for (long k0 = 0; k0 < K;) {
+    long k1 = k0, e = 0;
+    while (k1 < K && (k1 - k0) < max_chunk) {
+      const long e2 = e + img_edges[k1];
+      if (k1 > k0 && carve(nullptr, (k1 - k0 + 1) * N, e2, nullptr) > budget) break;
+      e = e2; ++k1;
+    }
+    if (carve(nullptr, (k1 - k0) * N, e, nullptr) > budget)
+      return fail(eng, UMX_ERR_CAPACITY, "one image needs " + std::to_string(carve(nullptr, N, e, nullptr) >> 20) + " MiB of workspace, budget is " +
+                                             std::to_string(budget >> 20) + " MiB");
+    chunks.push_back({k0, k1});
+    need_nodes = std::max(need_nodes, (k1 - k0) * N);
+    need_edges = std::max(need_edges, e);
+    k0 = k1;
+  }
+  if (need_nodes > eng->cap_nodes || need_edges > eng->cap_edges) {
+    HIPCHK(eng, hipStreamSynchronize(s));
+    if (eng->arena) { HIPCHK(eng, hipFree(eng->arena)); eng->arena = nullptr; eng->arena_bytes = 0; }
+    const long cn = std::max(need_nodes, eng->cap_nodes), ce = std::max(need_edges + need_edges / 50 + 1024, eng->cap_edges);
+    size_t bytes = carve(nullptr, cn, ce, nullptr);
+    long ce2 = ce;
+    if (bytes > budget) { ce2 = std::max(need_edges, 1L); bytes = carve(nullptr, cn, ce2, nullptr); }
+    HIPCHK(eng, hipMalloc(&eng->arena, bytes));
+    eng->arena_bytes = bytes; eng->cap_nodes = cn; eng->cap_edges = ce2;
+  }
+  WS w;
+  carve(eng->arena, eng->cap_nodes, eng->cap_edges, &w);
+  if (eng->dbg_on) eng->dbg.clear();
+  for (auto& ch : chunks) {
+    const long k0 = ch.first, k1 = ch.second;
+    long e = 0;
+    for (long k = k0; k < k1; ++k) e += img_edges[k];
+    CHK(run_chunk(eng, w, d_pos + k0 * N * 3, eng->d_deg_all + k0 * N, k1 - k0, e, d_energy + k0, d_forces ? d_forces + k0 * N * 3 : nullptr));
+  }
+  return UMX_OK;
+}
+
+int umx_energy_forces(umx_engine* eng, int n_images, const float* pos, double* energy, float* forces) {
+  if (!eng) return UMX_ERR_ARG;
+  if (!eng->have_system) return fail(eng, UMX_ERR_ARG, "umx_energy_forces: bind a system first (umx_set_system)");
+  if (n_images <= 0 || !pos || !energy) return fail(eng, UMX_ERR_ARG, "umx_energy_forces: bad arguments");
+  HIPCHK(eng, hipSetDevice(eng->dev));
+  const long nt = (long)n_images * eng->natoms;
+  if (eng->io_cap < nt) {
+    HIPCHK(eng, hipStreamSynchronize(eng->stream));
+    for (void* p : {(void*)eng->d_io_pos, (void*)eng->d_io_e, (void*)eng->d_io_f}) if (p) HIPCHK(eng, hipFree(p));
+    eng->d_io_pos = nullptr; eng->d_io_e = nullptr; eng->d_io_f = nullptr;
+    HIPCHK(eng, hipMalloc(&eng->d_io_pos, nt * 3 * sizeof(float)));
+    HIPCHK(eng, hipMalloc(&eng->d_io_f, nt * 3 * sizeof(float)));
+    HIPCHK(eng, hipMalloc(&eng->d_io_e, (size_t)n_images * sizeof(double)));
+    eng->io_cap = nt;
+  }
+  HIPCHK(eng, hipMemcpyAsync(eng->d_io_pos, pos, nt * 3 * sizeof(float), hipMemcpyHostToDevice, eng->stream));
+  CHK(umx_energy_forces_dev(eng, n_images, eng->d_io_pos, eng->d_io_e, forces ? eng->d_io_f : nullptr, nullptr));
+  HIPCHK(eng, hipMemcpyAsync(energy, eng->d_io_e, (size_t)n_images * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
+  if (forces) HIPCHK(eng, hipMemcpyAsync(forces, eng->d_io_f, nt * 3 * sizeof(float), hipMemcpyDeviceToHost, eng->stream));
+  HIPCHK(eng, hipStreamSynchronize(eng->stream));
+  return UMX_OK;
+}
+
+int umx_last_graph_stats(const umx_engine* eng, int64_t* n_edges_total, int32_t* max_degree) {
+  if (!eng) return UMX_ERR_ARG;
+  if (n_edges_total) *n_edges_total = eng->last_edges;
+  if (max_degree) *max_degree = eng->last_maxdeg;
+  return UMX_OK;
+}
+
+int umx_profile_enable(umx_engine* eng, int on) {
+  if (!eng) return UMX_ERR_ARG;
+  eng->prof_on = on != 0;
+  return UMX_OK;
+}
+
+int umx_profile_read(umx_engine* eng, double* gemm_ms, int64_t* gemm_launches, double* gemm_flops, int reset) {
+  if (!eng) return UMX_ERR_ARG;
+  HIPCHK(eng, hipSetDevice(eng->dev));
+  HIPCHK(eng, hipStreamSynchronize(eng->stream));
+  double ms = 0.0, fl = 0.0;
+  for (size_t i = 0; i < eng->prof_used; ++i) {
+    float t = 0.f;
+    HIPCHK(eng, hipEventElapsedTime(&t, eng->prof[i].a, eng->prof[i].b));
+    ms += t; fl += eng->prof[i].flops;
+  }
+  if (gemm_ms) *gemm_ms = ms;
+  if (gemm_launches) *gemm_launches = (int64_t)eng->prof_used;
+  if (gemm_flops) *gemm_flops = fl;
+  if (reset) eng->prof_used = 0;
+  return UMX_OK;
+}
+
+int umx_debug_keep(umx_engine* eng, int on) {
+  if (!eng) return UMX_ERR_ARG;
+  eng->dbg_on = on != 0;
+  if (!on) eng->dbg.clear();
+  return UMX_OK;
+}
+
+int umx_debug_fetch(umx_engine* eng, const char* name, void* host_buf, size_t capacity, size_t* nbytes_out) {
+  if (!eng || !name) return UMX_ERR_ARG;
+  auto it = eng->dbg.find(name);
+  if (it == eng->dbg.end()) return fail(eng, UMX_ERR_ARG, std::string("umx_debug_fetch: no buffer named ") + name);
+  if (nbytes_out) *nbytes_out = it->second.size();
+  if (host_buf) {
+    if (capacity < it->second.size()) return fail(eng, UMX_ERR_ARG, "umx_debug_fetch: buffer too small");
+    std::memcpy(host_buf, it->second.data(), it->second.size());
+  }
+  return UMX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+// umx_common.h -- shared constants and device helpers of the UMA-S engine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace umx {
+
+// UMA-S shapes (pdb2reaction_amd/weights.py)
+constexpr int C = 128;            // sphere channels
+constexpr int H = 128;            // hidden channels
+constexpr int S = 9;              // (lmax+1)^2
+constexpr int NL = 4;             // layers
+constexpr int NG = 64;            // gaussian basis
+constexpr int NZ = 100;           // max elements
+constexpr int RH = 128;           // radial hidden
+constexpr int ROW = S * C;        // 1152 floats: one node / one local-frame message
+constexpr int XROT = S * 2 * C;   // 2304 floats: rotated [src|dst] message
+constexpr int RAD = 1536;         // radial weights of SO(2) conv 1
+constexpr int HG = 2 * H + ROW;   // 1408 floats: [gate scalars (256) | conv-1 output (9x128)]
+constexpr int FRAME = 36;         // per-edge frame record: R[9], D2[25], env, denv
+constexpr float NORM_EPS = 1e-5f;
+constexpr float LN_EPS = 1e-5f;
+constexpr float DEG_RESCALE = 5.0f;
+constexpr float SQRT3 = 1.7320508075688772f;
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_grad_f(float x) {
+  const float s = 1.0f / (1.0f + __expf(-x));
+  return s * (1.0f + x * (1.0f - s));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- frame application: W (rows m-primary, cols l-primary) and its transpose -------------------
+// f[0..8] = R row-major (R nhat = +y), f[9..33] = D2 row-major.  m-primary row r holds l-primary
+// coefficient TO_M[r] = {0,2,6,3,7,1,5,8,4}.
+__device__ __forceinline__ void rot_fwd(const float* __restrict__ f, const float x[9], float v[9]) {
+  v[0] = x[0];
+  v[5] = f[0] * x[1] + f[1] * x[2] + f[2] * x[3];   // lp1
+  v[1] = f[3] * x[1] + f[4] * x[2] + f[5] * x[3];   // lp2
+  v[3] = f[6] * x[1] + f[7] * x[2] + f[8] * x[3];   // lp3
+  float t[5];
+#pragma unroll
+  for (int a = 0; a < 5; ++a) {
+    const float* d = f + 9 + a * 5;
+    t[a] = d[0] * x[4] + d[1] * x[5] + d[2] * x[6] + d[3] * x[7] + d[4] * x[8];
+  }
+  v[8] = t[0]; v[6] = t[1]; v[2] = t[2]; v[4] = t[3]; v[7] = t[4];
+}
+// x += scale * W^T v
+__device__ __forceinline__ void rot_bwd_acc(const float* __restrict__ f, const float v[9], float scale, float x[9]) {
+  x[0] += scale * v[0];
+  const float u0 = scale * v[5], u1 = scale * v[1], u2 = scale * v[3];
+  x[1] += f[0] * u0 + f[3] * u1 + f[6] * u2;
+  x[2] += f[1] * u0 + f[4] * u1 + f[7] * u2;
+  x[3] += f[2] * u0 + f[5] * u1 + f[8] * u2;
+  const float w0 = scale * v[8], w1 = scale * v[6], w2 = scale * v[2], w3 = scale * v[4], w4 = scale * v[7];
+  const float* d = f + 9;
+#pragma unroll
+  for (int b = 0; b < 5; ++b)
+    x[4 + b] += d[b] * w0 + d[5 + b] * w1 + d[10 + b] * w2 + d[15 + b] * w3 + d[20 + b] * w4;
+}
+// per-channel torque partials tau_k += <g, L_k a> (m-primary rows); generators from
+// tools/gen_generators.py (L_x, L_z; L_y only for the gauge check)
+__device__ __forceinline__ void torque_acc(const float g[9], const float a[9], float sgn, float& tx, float& ty, float& tz) {
+  tx += sgn * (-g[1] * a[3] + g[3] * a[1] + SQRT3 * (g[4] * a[2] - g[2] * a[4]) - g[4] * a[7] + g[7] * a[4] - g[6] * a[8] + g[8] * a[6]);
+  ty += sgn * (-g[3] * a[5] + g[5] * a[3] - g[4] * a[6] + g[6] * a[4] + 2.0f * (g[8] * a[7] - g[7] * a[8]));
+  tz += sgn * (g[1] * a[5] - g[5] * a[1] + SQRT3 * (g[2] * a[6] - g[6] * a[2]) + g[4] * a[8] - g[8] * a[4] - g[6] * a[7] + g[7] * a[6]);
+}
+
+}  // namespace umx

@@ -1,0 +1,203 @@
+// umx_gemm.h -- fp32-input MFMA GEMM family for the SO(2) / radial / atom-wise linears.
+//
+// C[M x N] = epilogue( prologue(A)[M x K] . B[N x K]^T ),  B = nn.Linear weight layout [out][in].
+//
+// gfx950 design notes (MI355X_MICROARCH.md / cdna_hip_programming.md section 3):
+//  * v_mfma_f32_32x32x2_f32: exact f32 (k-ordered fmaf chain), 64 FLOP/clk/SIMD.  A/B operands
+//    are one VGPR per lane: lane l holds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31].  Because the sum
+//    over k is order-free, an 8-wide K chunk is fed as 4 MFMAs where lane-half h supplies
+//    k = 4h + r (r = 0..3): ONE ds_read_b128 per lane yields the operands of 4 MFMAs.
+//  * 128x128x32 block tile, 4 waves as 2x2, each wave a 64x64 C tile = 2x2 MFMA tiles
+//    (64 accumulator VGPRs).  LDS rows are padded to 36 floats so the 16-lane groups of
+//    ds_read_b128 hit 16 distinct 4-bank slots (conflict free).  Double-buffered LDS
+//    (73,728 B -> 2 blocks/CU), register-staged global loads because the prologue
+//    (radial modulation / gaussian basis / SiLU) runs on the staged registers.
+//  * XCD-aware block -> tile map: the 8 XCDs walk 8 different M tiles while consecutive blocks
+//    of one XCD sweep the N tiles of the SAME M tile, so an A tile is fetched from HBM once and
+//    re-read from that XCD's L2; weights (<= 2 MB per GEMM) stay L2 resident on every XCD.
+//  * CPLX=1 implements the SO(2) m>0 "complex" linear without doubling K: rows are
+//    (edge, re/im), weight rows are (A-half, B-half); each wave owns the 2x2 MFMA tiles
+//    {re,im} x {A,B} of the same 32 edges x 32 channels, so y_re = P[re][A] - s P[im][B] and
+//    y_im = P[im][A] + s P[re][B] combine element-wise in the accumulators (s=+1 forward,
+//    s=-1 for the transposed/backward product).
+#pragma once
+#include "umx_common.h"
+
+namespace umx {
+
+enum AMode { A_PLAIN = 0, A_MODUL = 1, A_GAUSS = 2, A_SILU = 3 };
+enum EMode { E_BIAS = 0, E_TABLES = 1 };
+
+struct GemmP {
+  // A operand: row r at A + r*lda + offA{0,1} (+ blockIdx.z * zA); offA1 = imaginary rows (CPLX)
+  const float* A; long lda; int offA0, offA1;
+  const float* R; long ldr; int offR;            // A_MODUL: A .* R
+  const float* evec; float gcoef, gdelta;        // A_GAUSS: exp(gcoef (d - k*gdelta)^2), d = evec[4r+3]
+  // B operand: weights [rows][ldb]; CPLX row of kind ab: ab*bHalf + n
+  const float* B; long ldb; int bHalf;
+  // C: row r at C + r*ldc + offC (+ blockIdx.z * zC); offCi = imaginary output (CPLX)
+  float* Cp; long ldc; int offC, offCi;
+  const float* bias;                             // [N] or null
+  const float* resid; long ldres; int offRes;    // optional residual added to the output (plain)
+  const float* TS; const float* TT;              // E_TABLES: + TS[z_src][col] + TT[z_dst][col]
+  const int* esrc; const int* edst; const int* znode; int natoms;
+  float conj;                                    // CPLX combine sign
+  long zA, zC, zRes;
+  int M, N, K;                                   // CPLX: M = edges, N = channels per half
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int G_BK = 32;
+constexpr int G_LDK = 36;   // padded LDS row (floats)
+
+template <int AMODE, int CPLX, int EPI>
+__global__ __launch_bounds__(256, 2) void umx_gemm_kernel(const GemmP p) {
+  __shared__ __attribute__((aligned(16))) float lds[2][2][128][G_LDK];
+  constexpr int BMR = CPLX ? 64 : 128;   // logical rows (edges) per block
+  constexpr int BNC = CPLX ? 64 : 128;   // logical cols (channels) per block
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const int nN = (p.N + BNC - 1) / BNC;
+  const int nM = (p.M + BMR - 1) / BMR;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int mt = (slot / nN) * 8 + xcd, nt = slot % nN;
+  if (mt >= nM) return;
+  const long zoffA = (long)blockIdx.z * p.zA;
+
+  // ---- staging assignment: thread -> 4 rows x one float4 of A and of B ------------------------
+  const int k4 = (tid & 7) * 4;
+  const int trow0 = tid >> 3;   // + 32*r
+  float4 ra[4], rb[4];
+
+  auto gload = [&](int kt) {
+    const int k0 = kt * G_BK + k4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int trow = trow0 + 32 * r;
+      long grow; int offA;
+      if (CPLX) { grow = (long)mt * 64 + (trow & 63); offA = (trow >> 6) ? p.offA1 : p.offA0; }
+      else      { grow = (long)mt * 128 + trow;       offA = p.offA0; }
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (grow < p.M) {
+        if (AMODE == A_GAUSS) {
+          const float d = p.evec[grow * 4 + 3];
+          float t;
+          t = d - (float)(k0 + 0) * p.gdelta; v.x = __expf(p.gcoef * t * t);
+          t = d - (float)(k0 + 1) * p.gdelta; v.y = __expf(p.gcoef * t * t);
+          t = d - (float)(k0 + 2) * p.gdelta; v.z = __expf(p.gcoef * t * t);
+          t = d - (float)(k0 + 3) * p.gdelta; v.w = __expf(p.gcoef * t * t);
+        } else {
+          v = *reinterpret_cast<const float4*>(p.A + grow * p.lda + offA + zoffA + k0);
+          if (AMODE == A_MODUL) {
+            const float4 m = *reinterpret_cast<const float4*>(p.R + grow * p.ldr + p.offR + k0);
+            v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+          }
+          if (AMODE == A_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+        }
+      }
+      ra[r] = v;
+      int brow; bool ok;
+      if (CPLX) { const int c = nt * 64 + (trow & 63); ok = c < p.N; brow = (trow >> 6) * p.bHalf + c; }
+      else      { brow = nt * 128 + trow; ok = brow < p.N; }
+      rb[r] = ok ? *reinterpret_cast<const float4*>(p.B + (long)brow * p.ldb + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int trow = trow0 + 32 * r;
+      *reinterpret_cast<float4*>(&lds[buf][0][trow][k4]) = ra[r];
+      *reinterpret_cast<float4*>(&lds[buf][1][trow][k4]) = rb[r];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int arow[2], brow_l[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    arow[t]   = CPLX ? (t * 64 + wm * 32 + l31) : (wm * 64 + t * 32 + l31);
+    brow_l[t] = CPLX ? (t * 64 + wn * 32 + l31) : (wn * 64 + t * 32 + l31);
+  }
+
+  const int nk = p.K / G_BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      float4 a[2], b[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = *reinterpret_cast<const float4*>(&lds[buf][0][arow[t]][kc * 8 + 4 * h]);
+        b[t] = *reinterpret_cast<const float4*>(&lds[buf][1][brow_l[t]][kc * 8 + 4 * h]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D map of 32x32 tiles: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  if (CPLX) {
+    const int chan = nt * 64 + wn * 32 + l31;
+    if (chan < p.N) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long e = (long)mt * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (e < p.M) {
+          const float yr = acc[0][0][r] - p.conj * acc[1][1][r];
+          const float yi = acc[1][0][r] + p.conj * acc[0][1][r];
+          float* c = p.Cp + e * p.ldc + chan;
+          c[p.offC] = yr;
+          c[p.offCi] = yi;
+        }
+      }
+    }
+  } else {
+    const long zoffC = (long)blockIdx.z * p.zC, zoffR = (long)blockIdx.z * p.zRes;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = nt * 128 + wn * 64 + j * 32 + l31;
+        if (col >= p.N) continue;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long row = (long)mt * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < p.M) {
+            float v = acc[i][j][r] + bv;
+            if (EPI == E_TABLES) {
+              const int zs = p.znode[p.esrc[row] % p.natoms], zd = p.znode[p.edst[row] % p.natoms];
+              v += p.TS[zs * RH + col] + p.TT[zd * RH + col];
+            }
+            if (p.resid) v += p.resid[row * p.ldres + p.offRes + zoffR + col];
+            p.Cp[row * p.ldc + p.offC + zoffC + col] = v;
+          }
+        }
+      }
+  }
+}
+
+}  // namespace umx

@@ -1,0 +1,629 @@
+// umx_kernels.h -- HBM-bound stages of the UMA-S engine: radius graph, edge frames, gather/rotate,
+// rotate-back + segmented reduction, norms, gates, radial LayerNorm, readout and force assembly.
+//
+// Conventions: one 64-lane wave per edge or per node, 4 waves per 256-thread block; a lane owns 2
+// (or 4) adjacent channels so every row access is a coalesced 512-B (1-KiB) segment; edges are
+// sorted by target so reductions over incoming edges are deterministic segmented sums (no float
+// atomics); contributions that flow to an edge's SOURCE node are collected through the reverse
+// edge index rev[e] (the graph is symmetric).  Per-edge frame records are wave-uniform.
+#pragma once
+#include "umx_common.h"
+
+namespace umx {
+
+#define UMX_WAVE_ITEM(idx, count)                                                     \
+  const int lane = threadIdx.x & 63;                                                  \
+  const long idx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))); \
+  if (idx >= (count)) return;
+
+// ------------------------------------------------------------------------------------------------
+// K1 radius graph: brute force inside each image, wave per target, ballot compaction (ascending
+// source order => CSR rows sorted by source).  pos: [NT][3] f32.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_graph_count(const float* __restrict__ pos, int natoms, long nt, float rc2,
+                                                     int* __restrict__ deg) {
+  UMX_WAVE_ITEM(node, nt)
+  const long base = (node / natoms) * natoms;
+  const float xi = pos[node * 3 + 0], yi = pos[node * 3 + 1], zi = pos[node * 3 + 2];
+  int cnt = 0;
+  for (int j0 = 0; j0 < natoms; j0 += 64) {
+    const int j = j0 + lane;
+    bool ok = false;
+    if (j < natoms) {
+      const float dx = pos[(base + j) * 3 + 0] - xi, dy = pos[(base + j) * 3 + 1] - yi, dz = pos[(base + j) * 3 + 2] - zi;
+      const float d2 = dx * dx + dy * dy + dz * dz;
+      ok = (d2 <= rc2) && (base + j != node);
+    }
+    cnt += __popcll(__ballot(ok));
+  }
+  if (lane == 0) deg[node] = cnt;
+}
+
+// exclusive scan of deg[0..n) into row_ptr[0..n]; single block of 1024 threads; also max degree
+__global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ deg, long n, int* __restrict__ row_ptr,
+                                               int* __restrict__ stats /*[0]=total,[1]=maxdeg*/) {
+  __shared__ int part[1024];
+  __shared__ int pmax[1024];
+  const int t = threadIdx.x;
+  const long chunk = (n + 1023) / 1024;
+  const long lo = t * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+  int s = 0, mx = 0;
+  for (long i = lo; i < hi; ++i) { s += deg[i]; mx = deg[i] > mx ? deg[i] : mx; }
+  part[t] = s; pmax[t] = mx;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int v = (t >= off) ? part[t - off] : 0;
+    int m = (t >= off) ? pmax[t - off] : 0;
+    __syncthreads();
+    part[t] += v; pmax[t] = pmax[t] > m ? pmax[t] : m;
+    __syncthreads();
+  }
+  int run = (t == 0) ? 0 : part[t - 1];
+  for (long i = lo; i < hi; ++i) { row_ptr[i] = run; run += deg[i]; }
+  if (t == 1023) { row_ptr[n] = part[1023]; stats[0] = part[1023]; stats[1] = pmax[1023]; }
+}
+
+__global__ __launch_bounds__(256) void k_graph_fill(const float* __restrict__ pos, int natoms, long nt, float rc2,
+                                                    const int* __restrict__ row_ptr, int* __restrict__ esrc,
+                                                    int* __restrict__ edst, float* __restrict__ evec) {
+  UMX_WAVE_ITEM(node, nt)
+  const long base = (node / natoms) * natoms;
+  const float xi = pos[node * 3 + 0], yi = pos[node * 3 + 1], zi = pos[node * 3 + 2];
+  int w = row_ptr[node];
+  for (int j0 = 0; j0 < natoms; j0 += 64) {
+    const int j = j0 + lane;
+    bool ok = false;
+    float dx = 0.f, dy = 0.f, dz = 0.f, d2 = 0.f;
+    if (j < natoms) {
+      dx = pos[(base + j) * 3 + 0] - xi; dy = pos[(base + j) * 3 + 1] - yi; dz = pos[(base + j) * 3 + 2] - zi;
+      d2 = dx * dx + dy * dy + dz * dz;
+      ok = (d2 <= rc2) && (base + j != node);
+    }
+    const unsigned long long m = __ballot(ok);
+    if (ok) {
+      const int slot = w + __popcll(m & ((1ull << lane) - 1ull));
+      const float d = sqrtf(d2), inv = 1.0f / d;
+      esrc[slot] = (int)(base + j);
+      edst[slot] = (int)node;
+      *reinterpret_cast<float4*>(evec + (long)slot * 4) = make_float4(dx * inv, dy * inv, dz * inv, d);
+    }
+    w += __popcll(m);
+  }
+}
+
+// reverse edge: position of (dst -> src) in row src (rows sorted by source)
+__global__ void k_rev(const int* __restrict__ esrc, const int* __restrict__ edst, const int* __restrict__ row_ptr,
+                      long ne, int* __restrict__ rev) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  const int j = esrc[e], i = edst[e];
+  int lo = row_ptr[j], hi = row_ptr[j + 1] - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (esrc[mid] < i) lo = mid + 1; else hi = mid;
+  }
+  rev[e] = lo;
+}
+
+// K2 edge frames: R (R nhat = +y, minimal rotation, flipped branch for nhat_y < -0.9), D2, envelope
+__global__ void k_edge_geom(const float* __restrict__ evec, long ne, float cutoff, float* __restrict__ frame) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  const float4 v = *reinterpret_cast<const float4*>(evec + e * 4);
+  const float sg = (v.y < -0.9f) ? -1.0f : 1.0f;
+  const float nx = v.x, ny = v.y * sg, nz = v.z * sg;
+  const float k = 1.0f / (1.0f + ny);
+  float R[9] = {1.0f - k * nx * nx, -nx * sg, -k * nx * nz * sg,
+                nx,                 ny * sg,  nz * sg,
+                -k * nx * nz,       -nz * sg, (1.0f - k * nz * nz) * sg};
+  float* f = frame + e * FRAME;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) f[i] = R[i];
+  // D2[a][b] = (2/3) <A_a, R A_b R^T>; columns c_k = R e_k
+  const float c0[3] = {R[0], R[3], R[6]}, c1[3] = {R[1], R[4], R[7]}, c2[3] = {R[2], R[5], R[8]};
+  const float hs3 = 0.5f * SQRT3;
+#pragma unroll
+  for (int b = 0; b < 5; ++b) {
+    float M[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float m;
+        if (b == 0) m = hs3 * (c0[i] * c2[j] + c2[i] * c0[j]);
+        else if (b == 1) m = hs3 * (c0[i] * c1[j] + c1[i] * c0[j]);
+        else if (b == 2) m = -0.5f * c0[i] * c0[j] + c1[i] * c1[j] - 0.5f * c2[i] * c2[j];
+        else if (b == 3) m = hs3 * (c1[i] * c2[j] + c2[i] * c1[j]);
+        else m = hs3 * (c2[i] * c2[j] - c0[i] * c0[j]);
+        M[i][j] = m;
+      }
+    const float t23 = 2.0f / 3.0f;
+    f[9 + 0 * 5 + b] = t23 * SQRT3 * M[0][2];
+    f[9 + 1 * 5 + b] = t23 * SQRT3 * M[0][1];
+    f[9 + 2 * 5 + b] = t23 * (-0.5f * M[0][0] + M[1][1] - 0.5f * M[2][2]);
+    f[9 + 3 * 5 + b] = t23 * SQRT3 * M[1][2];
+    f[9 + 4 * 5 + b] = t23 * hs3 * (M[2][2] - M[0][0]);
+  }
+  const float u = v.w / cutoff;
+  float env = 0.f, denv = 0.f;
+  if (u < 1.0f) {
+    const float u2 = u * u, u4 = u2 * u2, u5 = u4 * u;
+    env = 1.0f + u5 * (-21.0f + u * (35.0f - 15.0f * u));
+    denv = u4 * (-105.0f + u * (210.0f - 105.0f * u)) / cutoff;
+  }
+  f[34] = env;
+  f[35] = denv;
+}
+
+// ------------------------------------------------------------------------------------------------
+// node-level kernels
+// ------------------------------------------------------------------------------------------------
+// system embedding: silu(mix_csd [chg | spin | dataset])
+__global__ void k_sys_emb(const float* __restrict__ chg, const float* __restrict__ spin, const float* __restrict__ ds,
+                          const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out) {
+  const int o = threadIdx.x;   // 128 threads
+  float acc = b[o];
+  for (int k = 0; k < C; ++k) acc += w[o * 3 * C + k] * chg[k];
+  for (int k = 0; k < C; ++k) acc += w[o * 3 * C + C + k] * spin[k];
+  for (int k = 0; k < C; ++k) acc += w[o * 3 * C + 2 * C + k] * ds[k];
+  out[o] = silu_f(acc);
+}
+
+__global__ void k_node_init(const int* __restrict__ znode, int natoms, long nt, const float* __restrict__ emb,
+                            const float* __restrict__ sysemb, float* __restrict__ x) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nt * ROW) return;
+  const long node = i / ROW;
+  const int r = (int)(i % ROW);
+  x[i] = (r < C) ? emb[znode[node % natoms] * C + r] + sysemb[r] : 0.f;
+}
+
+// K6 RMS-norm-SH forward: wave per node, lane owns channels 2l, 2l+1
+__global__ __launch_bounds__(256) void k_norm_fwd(const float* __restrict__ x, const float* __restrict__ aw,
+                                                  const float* __restrict__ ab, const float* __restrict__ sysemb,
+                                                  float* __restrict__ y, long nt) {
+  UMX_WAVE_ITEM(node, nt)
+  const int c0 = lane * 2;
+  float2 v[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) v[r] = *reinterpret_cast<const float2*>(x + node * ROW + r * C + c0);
+  const float mean0 = wave_sum(v[0].x + v[0].y) * (1.0f / C);
+  v[0].x -= mean0; v[0].y -= mean0;
+  float q = (v[0].x * v[0].x + v[0].y * v[0].y) * (1.0f / 3.0f);
+#pragma unroll
+  for (int r = 1; r < 4; ++r) q += (v[r].x * v[r].x + v[r].y * v[r].y) * (1.0f / 9.0f);
+#pragma unroll
+  for (int r = 4; r < 9; ++r) q += (v[r].x * v[r].x + v[r].y * v[r].y) * (1.0f / 15.0f);
+  q = wave_sum(q) * (1.0f / C);
+  const float s = rsqrtf(q + NORM_EPS);
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const int l = (r == 0) ? 0 : (r < 4 ? 1 : 2);
+    const float2 w = *reinterpret_cast<const float2*>(aw + l * C + c0);
+    float2 o = make_float2(v[r].x * s * w.x, v[r].y * s * w.y);
+    if (r == 0) {
+      const float2 b = *reinterpret_cast<const float2*>(ab + c0);
+      o.x += b.x; o.y += b.y;
+      if (sysemb) { o.x += sysemb[c0]; o.y += sysemb[c0 + 1]; }
+    }
+    *reinterpret_cast<float2*>(y + node * ROW + r * C + c0) = o;
+  }
+}
+
+// backward: gx = gres + d(norm)/dx^T gy   (gres may be null)
+__global__ __launch_bounds__(256) void k_norm_bwd(const float* __restrict__ gy, const float* __restrict__ x,
+                                                  const float* __restrict__ aw, const float* __restrict__ gres,
+                                                  float* __restrict__ gx, long nt) {
+  UMX_WAVE_ITEM(node, nt)
+  const int c0 = lane * 2;
+  float2 v[9], g[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    v[r] = *reinterpret_cast<const float2*>(x + node * ROW + r * C + c0);
+    g[r] = *reinterpret_cast<const float2*>(gy + node * ROW + r * C + c0);
+  }
+  const float mean0 = wave_sum(v[0].x + v[0].y) * (1.0f / C);
+  v[0].x -= mean0; v[0].y -= mean0;
+  float q = 0.f, dot = 0.f;
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const int l = (r == 0) ? 0 : (r < 4 ? 1 : 2);
+    const float bal = (l == 0) ? (1.0f / 3.0f) : (l == 1 ? (1.0f / 9.0f) : (1.0f / 15.0f));
+    const float2 w = *reinterpret_cast<const float2*>(aw + l * C + c0);
+    g[r].x *= w.x; g[r].y *= w.y;
+    q += (v[r].x * v[r].x + v[r].y * v[r].y) * bal;
+    dot += g[r].x * v[r].x + g[r].y * v[r].y;
+  }
+  q = wave_sum(q) * (1.0f / C);
+  dot = wave_sum(dot);
+  const float s = rsqrtf(q + NORM_EPS);
+  const float k = s * s * s * dot * (1.0f / C);
+  float2 o[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const int l = (r == 0) ? 0 : (r < 4 ? 1 : 2);
+    const float bal = (l == 0) ? (1.0f / 3.0f) : (l == 1 ? (1.0f / 9.0f) : (1.0f / 15.0f));
+    o[r].x = g[r].x * s - k * bal * v[r].x;
+    o[r].y = g[r].y * s - k * bal * v[r].y;
+  }
+  const float gm = wave_sum(o[0].x + o[0].y) * (1.0f / C);
+  o[0].x -= gm; o[0].y -= gm;
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    if (gres) {
+      const float2 rr = *reinterpret_cast<const float2*>(gres + node * ROW + r * C + c0);
+      o[r].x += rr.x; o[r].y += rr.y;
+    }
+    *reinterpret_cast<float2*>(gx + node * ROW + r * C + c0) = o[r];
+  }
+}
+
+// LayerNorm(128) + SiLU on rows of the radial MLP
+__global__ __launch_bounds__(256) void k_ln_silu_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ b, float* __restrict__ y, long rows) {
+  UMX_WAVE_ITEM(row, rows)
+  const int c0 = lane * 2;
+  float2 v = *reinterpret_cast<const float2*>(x + row * RH + c0);
+  const float mu = wave_sum(v.x + v.y) * (1.0f / RH);
+  v.x -= mu; v.y -= mu;
+  const float var = wave_sum(v.x * v.x + v.y * v.y) * (1.0f / RH);
+  const float rstd = rsqrtf(var + LN_EPS);
+  const float2 ww = *reinterpret_cast<const float2*>(w + c0), bb = *reinterpret_cast<const float2*>(b + c0);
+  *reinterpret_cast<float2*>(y + row * RH + c0) =
+      make_float2(silu_f(v.x * rstd * ww.x + bb.x), silu_f(v.y * rstd * ww.y + bb.y));
+}
+
+__global__ __launch_bounds__(256) void k_ln_silu_bwd(const float* __restrict__ gout, const float* __restrict__ x,
+                                                     const float* __restrict__ w, const float* __restrict__ b,
+                                                     float* __restrict__ gx, long rows) {
+  UMX_WAVE_ITEM(row, rows)
+  const int c0 = lane * 2;
+  float2 v = *reinterpret_cast<const float2*>(x + row * RH + c0);
+  const float2 go = *reinterpret_cast<const float2*>(gout + row * RH + c0);
+  const float mu = wave_sum(v.x + v.y) * (1.0f / RH);
+  v.x -= mu; v.y -= mu;
+  const float var = wave_sum(v.x * v.x + v.y * v.y) * (1.0f / RH);
+  const float rstd = rsqrtf(var + LN_EPS);
+  const float2 ww = *reinterpret_cast<const float2*>(w + c0), bb = *reinterpret_cast<const float2*>(b + c0);
+  const float xh0 = v.x * rstd, xh1 = v.y * rstd;
+  const float gw0 = go.x * silu_grad_f(xh0 * ww.x + bb.x) * ww.x;
+  const float gw1 = go.y * silu_grad_f(xh1 * ww.y + bb.y) * ww.y;
+  const float m1 = wave_sum(gw0 + gw1) * (1.0f / RH);
+  const float m2 = wave_sum(gw0 * xh0 + gw1 * xh1) * (1.0f / RH);
+  *reinterpret_cast<float2*>(gx + row * RH + c0) =
+      make_float2(rstd * (gw0 - m1 - xh0 * m2), rstd * (gw1 - m1 - xh1 * m2));
+}
+
+// atom-wise gate (l-primary rows): row 0 SiLU, rows of degree l>0 * sigmoid(silu(gs_pre[l-1]))
+__global__ void k_gate_node_fwd(const float* __restrict__ h, const float* __restrict__ gspre, float* __restrict__ hg, long nt) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nt * H) return;
+  const long node = i / H;
+  const int c = (int)(i % H);
+  const float s1 = sigmoid_f(silu_f(gspre[node * 2 * H + c])), s2 = sigmoid_f(silu_f(gspre[node * 2 * H + H + c]));
+  const float* hp = h + node * ROW + c;
+  float* op = hg + node * ROW + c;
+  op[0] = silu_f(hp[0]);
+#pragma unroll
+  for (int r = 1; r < 4; ++r) op[r * H] = hp[r * H] * s1;
+#pragma unroll
+  for (int r = 4; r < 9; ++r) op[r * H] = hp[r * H] * s2;
+}
+
+__global__ void k_gate_node_bwd(const float* __restrict__ ghg, const float* __restrict__ h, const float* __restrict__ gspre,
+                                float* __restrict__ gh, float* __restrict__ ggspre, long nt) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nt * H) return;
+  const long node = i / H;
+  const int c = (int)(i % H);
+  const float p1 = gspre[node * 2 * H + c], p2 = gspre[node * 2 * H + H + c];
+  const float s1 = sigmoid_f(silu_f(p1)), s2 = sigmoid_f(silu_f(p2));
+  const float* hp = h + node * ROW + c;
+  const float* gp = ghg + node * ROW + c;
+  float* op = gh + node * ROW + c;
+  op[0] = gp[0] * silu_grad_f(hp[0]);
+  float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+  for (int r = 1; r < 4; ++r) { op[r * H] = gp[r * H] * s1; a1 += gp[r * H] * hp[r * H]; }
+#pragma unroll
+  for (int r = 4; r < 9; ++r) { op[r * H] = gp[r * H] * s2; a2 += gp[r * H] * hp[r * H]; }
+  ggspre[node * 2 * H + c] = a1 * s1 * (1.0f - s1) * silu_grad_f(p1);
+  ggspre[node * 2 * H + H + c] = a2 * s2 * (1.0f - s2) * silu_grad_f(p2);
+}
+
+// out = g .* silu'(pre)  (g may be a broadcast row vector when gstride == 0)
+__global__ void k_silu_bwd(const float* __restrict__ g, long gstride, const float* __restrict__ pre, float* __restrict__ out,
+                           long rows, int width) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * width) return;
+  const long r = i / width;
+  const int c = (int)(i % width);
+  out[i] = g[r * gstride + c] * silu_grad_f(pre[i]);
+}
+
+// K9/K11 readout: per image E = rmsd * sum_i (silu(pre2_i) . w3 + b3) + refsum   (f64 accumulate)
+__global__ __launch_bounds__(256) void k_energy(const float* __restrict__ pre2, const float* __restrict__ w3,
+                                                const float* __restrict__ b3, int natoms, double rmsd, double refsum,
+                                                double* __restrict__ e_img, float* __restrict__ e_node) {
+  __shared__ double part[4];
+  const int img = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float2 w = *reinterpret_cast<const float2*>(w3 + lane * 2);
+  double acc = 0.0;
+  for (int a = wave; a < natoms; a += 4) {
+    const long node = (long)img * natoms + a;
+    const float2 v = *reinterpret_cast<const float2*>(pre2 + node * H + lane * 2);
+    const float en = wave_sum(silu_f(v.x) * w.x + silu_f(v.y) * w.y) + b3[0];
+    if (e_node && lane == 0) e_node[node] = en;
+    acc += (double)en;
+  }
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) e_img[img] = (part[0] + part[1] + part[2] + part[3]) * rmsd + refsum;
+}
+
+// ------------------------------------------------------------------------------------------------
+// edge-level kernels
+// ------------------------------------------------------------------------------------------------
+// K7a gather + rotate: xrot[e] = W_e [xn[src] | xn[dst]]   (m-primary rows, 256 channels)
+__global__ __launch_bounds__(256) void k_gather_rotate(const float* __restrict__ xn, const int* __restrict__ esrc,
+                                                       const int* __restrict__ edst, const float* __restrict__ frame,
+                                                       float* __restrict__ xrot, long ne) {
+  UMX_WAVE_ITEM(e, ne)
+  const int c0 = lane * 2;
+  const float* f = frame + e * FRAME;
+  const long js = esrc[e], jd = edst[e];
+  float sx[9], sy[9], dx[9], dy[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const float2 a = *reinterpret_cast<const float2*>(xn + js * ROW + r * C + c0);
+    const float2 b = *reinterpret_cast<const float2*>(xn + jd * ROW + r * C + c0);
+    sx[r] = a.x; sy[r] = a.y; dx[r] = b.x; dy[r] = b.y;
+  }
+  float* out = xrot + e * XROT;
+  float p[9], q[9];
+  rot_fwd(f, sx, p); rot_fwd(f, sy, q);
+#pragma unroll
+  for (int r = 0; r < 9; ++r) *reinterpret_cast<float2*>(out + r * 2 * C + c0) = make_float2(p[r], q[r]);
+  rot_fwd(f, dx, p); rot_fwd(f, dy, q);
+#pragma unroll
+  for (int r = 0; r < 9; ++r) *reinterpret_cast<float2*>(out + r * 2 * C + C + c0) = make_float2(p[r], q[r]);
+}
+
+// SO(2) gate on the edge hidden state hg = [gate(256) | hpre(9x128)] -> hid (9x128)
+__global__ void k_gate_edge_fwd(const float* __restrict__ hg, float* __restrict__ hid, long ne) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ne * (H / 4)) return;
+  const long e = i / (H / 4);
+  const int c = (int)(i % (H / 4)) * 4;
+  const float* p = hg + e * HG;
+  const float4 g1 = *reinterpret_cast<const float4*>(p + c), g2 = *reinterpret_cast<const float4*>(p + H + c);
+  const float4 s1 = make_float4(sigmoid_f(g1.x), sigmoid_f(g1.y), sigmoid_f(g1.z), sigmoid_f(g1.w));
+  const float4 s2 = make_float4(sigmoid_f(g2.x), sigmoid_f(g2.y), sigmoid_f(g2.z), sigmoid_f(g2.w));
+  float* o = hid + e * ROW + c;
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const float4 v = *reinterpret_cast<const float4*>(p + 2 * H + r * H + c);
+    float4 w;
+    if (r == 0) w = make_float4(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w));
+    else {
+      // m-primary degrees: rows {1,3,5} -> l=1, rows {2,4,6,7,8} -> l=2
+      const bool l1 = (r == 1 || r == 3 || r == 5);
+      const float4 s = l1 ? s1 : s2;
+      w = make_float4(v.x * s.x, v.y * s.y, v.z * s.z, v.w * s.w);
+    }
+    *reinterpret_cast<float4*>(o + r * H) = w;
+  }
+}
+
+// backward of the edge gate: ghid (9x128), hg (forward) -> ghg = [ggate | ghpre]
+__global__ void k_gate_edge_bwd(const float* __restrict__ ghid, const float* __restrict__ hg, float* __restrict__ ghg, long ne) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ne * H) return;
+  const long e = i / H;
+  const int c = (int)(i % H);
+  const float* p = hg + e * HG;
+  const float s1 = sigmoid_f(p[c]), s2 = sigmoid_f(p[H + c]);
+  const float* g = ghid + e * ROW + c;
+  const float* hp = p + 2 * H + c;
+  float* o = ghg + e * HG;
+  o[2 * H + c] = g[0] * silu_grad_f(hp[0]);
+  float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+  for (int r = 1; r < 9; ++r) {
+    const bool l1 = (r == 1 || r == 3 || r == 5);
+    const float gv = g[r * H], hv = hp[r * H];
+    o[2 * H + r * H + c] = gv * (l1 ? s1 : s2);
+    if (l1) a1 += gv * hv; else a2 += gv * hv;
+  }
+  o[c] = a1 * s1 * (1.0f - s1);
+  o[H + c] = a2 * s2 * (1.0f - s2);
+}
+
+// K7b rotate back + segmented reduction over incoming edges: xout[n] = xin[n] + sum_e env_e W_e^T msg_e
+// NROWS = 9 (SO(2) messages, ROW floats per edge) or 3 (edge-degree embedding, m=0 rows only, /5)
+template <int NROWS>
+__global__ __launch_bounds__(256) void k_rotate_back_reduce(const float* __restrict__ msg, const float* __restrict__ frame,
+                                                            const int* __restrict__ row_ptr, const float* xin,
+                                                            float* xout, long nt, float scale) {
+  UMX_WAVE_ITEM(node, nt)
+  const int c0 = lane * 2;
+  float ax[9], ay[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) { ax[r] = 0.f; ay[r] = 0.f; }
+  const int e0 = row_ptr[node], e1 = row_ptr[node + 1];
+  for (int e = e0; e < e1; ++e) {
+    const float* f = frame + (long)e * FRAME;
+    const float* m = msg + (long)e * (NROWS * C) + c0;
+    float vx[9], vy[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      if (r < NROWS) { const float2 t = *reinterpret_cast<const float2*>(m + r * C); vx[r] = t.x; vy[r] = t.y; }
+      else { vx[r] = 0.f; vy[r] = 0.f; }
+    }
+    const float sc = f[34] * scale;
+    rot_bwd_acc(f, vx, sc, ax);
+    rot_bwd_acc(f, vy, sc, ay);
+  }
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const float2 b = *reinterpret_cast<const float2*>(xin + node * ROW + r * C + c0);
+    *reinterpret_cast<float2*>(xout + node * ROW + r * C + c0) = make_float2(b.x + ax[r], b.y + ay[r]);
+  }
+}
+
+// backward of K7b: g_msg[e] = scale env_e (W_e g[dst e]) ; dedd[e] += denv_e scale <W g, msg>;
+// tau[e] -= <g_msg, L msg>.   msg has NROWS rows (rows >= NROWS are zero); g_msg stores NROWS rows.
+template <int NROWS>
+__global__ __launch_bounds__(256) void k_rotate_back_bwd(const float* __restrict__ gnode, const float* __restrict__ msg,
+                                                         const float* __restrict__ frame, const int* __restrict__ edst,
+                                                         float* __restrict__ gmsg, float* __restrict__ dedd,
+                                                         float* __restrict__ tau, long ne, float scale) {
+  UMX_WAVE_ITEM(e, ne)
+  const int c0 = lane * 2;
+  const float* f = frame + e * FRAME;
+  const long jd = edst[e];
+  float gx[9], gy[9], lx[9], ly[9], mx[9], my[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const float2 t = *reinterpret_cast<const float2*>(gnode + jd * ROW + r * C + c0);
+    gx[r] = t.x; gy[r] = t.y;
+    if (r < NROWS) { const float2 m = *reinterpret_cast<const float2*>(msg + e * (NROWS * C) + r * C + c0); mx[r] = m.x; my[r] = m.y; }
+    else { mx[r] = 0.f; my[r] = 0.f; }
+  }
+  rot_fwd(f, gx, lx); rot_fwd(f, gy, ly);
+  const float sc = f[34] * scale;
+  float s = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    s += lx[r] * mx[r] + ly[r] * my[r];
+    lx[r] *= sc; ly[r] *= sc;
+  }
+  torque_acc(lx, mx, -1.0f, tx, ty, tz);
+  torque_acc(ly, my, -1.0f, tx, ty, tz);
+#pragma unroll
+  for (int r = 0; r < NROWS; ++r) *reinterpret_cast<float2*>(gmsg + e * (NROWS * C) + r * C + c0) = make_float2(lx[r], ly[r]);
+  s = wave_sum(s); tx = wave_sum(tx); ty = wave_sum(ty); tz = wave_sum(tz);
+  if (lane == 0) {
+    dedd[e] += f[35] * scale * s;
+    tau[e * 4 + 0] += tx; tau[e * 4 + 1] += ty; tau[e * 4 + 2] += tz;
+  }
+}
+
+// backward of the radial modulation: gy1 (9x256, in/out -> gxrot), xrot, rad -> grad (1536); tau += <gxrot, L xrot>
+__global__ __launch_bounds__(256) void k_modulate_bwd(float* __restrict__ gy1, const float* __restrict__ xrot,
+                                                      const float* __restrict__ rad, float* __restrict__ grad,
+                                                      float* __restrict__ tau, long ne) {
+  UMX_WAVE_ITEM(e, ne)
+  const int c0 = lane * 4;
+  float* g = gy1 + e * XROT + c0;
+  const float* x = xrot + e * XROT + c0;
+  const float* rd = rad + e * RAD + c0;
+  float* gr = grad + e * RAD + c0;
+  float4 gv[9], xv[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    gv[r] = *reinterpret_cast<const float4*>(g + r * 2 * C);
+    xv[r] = *reinterpret_cast<const float4*>(x + r * 2 * C);
+  }
+  // radial row of each m-primary row: m0 rows 0,1,2 -> 0,1,2 ; m1 rows (3,4 | 5,6) -> 3,4 ; m2 rows (7 | 8) -> 5
+  float4 rv[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) rv[k] = *reinterpret_cast<const float4*>(rd + k * 2 * C);
+  const int ridx[9] = {0, 1, 2, 3, 4, 3, 4, 5, 5};
+  float4 gacc[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) gacc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const int k = ridx[r];
+    gacc[k].x += gv[r].x * xv[r].x; gacc[k].y += gv[r].y * xv[r].y; gacc[k].z += gv[r].z * xv[r].z; gacc[k].w += gv[r].w * xv[r].w;
+    gv[r].x *= rv[k].x; gv[r].y *= rv[k].y; gv[r].z *= rv[k].z; gv[r].w *= rv[k].w;
+    *reinterpret_cast<float4*>(g + r * 2 * C) = gv[r];
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) *reinterpret_cast<float4*>(gr + k * 2 * C) = gacc[k];
+  float tx = 0.f, ty = 0.f, tz = 0.f;
+  float ga[9], xa[9];
+#pragma unroll
+  for (int comp = 0; comp < 4; ++comp) {
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      ga[r] = comp == 0 ? gv[r].x : comp == 1 ? gv[r].y : comp == 2 ? gv[r].z : gv[r].w;
+      xa[r] = comp == 0 ? xv[r].x : comp == 1 ? xv[r].y : comp == 2 ? xv[r].z : xv[r].w;
+    }
+    torque_acc(ga, xa, 1.0f, tx, ty, tz);
+  }
+  tx = wave_sum(tx); ty = wave_sum(ty); tz = wave_sum(tz);
+  if (lane == 0) { tau[e * 4 + 0] += tx; tau[e * 4 + 1] += ty; tau[e * 4 + 2] += tz; }
+}
+
+// backward of K7a (gather+rotate): g_xn[n] = sum_{e in in(n)} W_e^T gxrot[e][:, dst half] + W_rev^T gxrot[rev e][:, src half]
+__global__ __launch_bounds__(256) void k_gather_rotate_bwd(const float* __restrict__ gxrot, const float* __restrict__ frame,
+                                                           const int* __restrict__ row_ptr, const int* __restrict__ rev,
+                                                           float* __restrict__ gxn, long nt) {
+  UMX_WAVE_ITEM(node, nt)
+  const int c0 = lane * 2;
+  float ax[9], ay[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) { ax[r] = 0.f; ay[r] = 0.f; }
+  const int e0 = row_ptr[node], e1 = row_ptr[node + 1];
+  for (int e = e0; e < e1; ++e) {
+    const long re = rev[e];
+    float vx[9], vy[9];
+    const float* a = gxrot + (long)e * XROT + C + c0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) { const float2 t = *reinterpret_cast<const float2*>(a + r * 2 * C); vx[r] = t.x; vy[r] = t.y; }
+    const float* f = frame + (long)e * FRAME;
+    rot_bwd_acc(f, vx, 1.0f, ax); rot_bwd_acc(f, vy, 1.0f, ay);
+    const float* b = gxrot + re * XROT + c0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) { const float2 t = *reinterpret_cast<const float2*>(b + r * 2 * C); vx[r] = t.x; vy[r] = t.y; }
+    const float* f2 = frame + re * FRAME;
+    rot_bwd_acc(f2, vx, 1.0f, ax); rot_bwd_acc(f2, vy, 1.0f, ay);
+  }
+#pragma unroll
+  for (int r = 0; r < 9; ++r) *reinterpret_cast<float2*>(gxn + node * ROW + r * C + c0) = make_float2(ax[r], ay[r]);
+}
+
+// dE/dd through the gaussian basis: dedd[e] += sum_k ggauss[e][k] * d/dd exp(gcoef (d - mu_k)^2)
+__global__ __launch_bounds__(256) void k_radial_dd(const float* __restrict__ ggauss, const float* __restrict__ evec,
+                                                   float gcoef, float gdelta, float* __restrict__ dedd, long ne) {
+  UMX_WAVE_ITEM(e, ne)
+  const float d = evec[e * 4 + 3];
+  const float t = d - (float)lane * gdelta;
+  float v = ggauss[e * NG + lane] * __expf(gcoef * t * t) * 2.0f * gcoef * t;
+  v = wave_sum(v);
+  if (lane == 0) dedd[e] += v;
+}
+
+// dE/dvec per edge from dE/dd and the torque (frame detached at the +y pole, as the reference does)
+__global__ void k_force_edge(const float* __restrict__ dedd, const float* __restrict__ tau, const float* __restrict__ frame,
+                             const float* __restrict__ evec, float* __restrict__ gvec, long ne) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  const float4 v = *reinterpret_cast<const float4*>(evec + e * 4);
+  const float* f = frame + e * FRAME;
+  float lx = tau[e * 4 + 2], lz = -tau[e * 4 + 0];
+  if (fabsf(v.y - 1.0f) <= 1e-8f + 1e-5f) { lx = 0.f; lz = 0.f; }
+  const float inv = 1.0f / v.w, g = dedd[e];
+  // R^T (lx, 0, lz)
+  const float tx = f[0] * lx + f[6] * lz, ty = f[1] * lx + f[7] * lz, tz = f[2] * lx + f[8] * lz;
+  *reinterpret_cast<float4*>(gvec + e * 4) = make_float4(g * v.x + tx * inv, g * v.y + ty * inv, g * v.z + tz * inv, 0.f);
+}
+
+// F[n] = -rmsd * sum_{e in in(n)} (gvec[rev e] - gvec[e])   (vec = pos[src] - pos[dst])
+__global__ __launch_bounds__(256) void k_force_node(const float* __restrict__ gvec, const int* __restrict__ row_ptr,
+                                                    const int* __restrict__ rev, float rmsd, float* __restrict__ forces, long nt) {
+  UMX_WAVE_ITEM(node, nt)
+  const int e0 = row_ptr[node], e1 = row_ptr[node + 1];
+  float fx = 0.f, fy = 0.f, fz = 0.f;
+  for (int e = e0 + lane; e < e1; e += 64) {
+    const float4 a = *reinterpret_cast<const float4*>(gvec + (long)e * 4);
+    const float4 b = *reinterpret_cast<const float4*>(gvec + (long)rev[e] * 4);
+    fx += b.x - a.x; fy += b.y - a.y; fz += b.z - a.z;
+  }
+  fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
+  if (lane == 0) { forces[node * 3 + 0] = -rmsd * fx; forces[node * 3 + 1] = -rmsd * fy; forces[node * 3 + 2] = -rmsd * fz; }
+}
+
+}  // namespace umx

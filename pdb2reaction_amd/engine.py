@@ -1,0 +1,165 @@
+"""ctypes binding of ``libumx.so`` (C ABI in ``include/umx.h``).
+
+The library is the product: if it is missing or no gfx950 device is usable this module raises --
+there is no CPU fallback (the CPU restatement under ``oracle/`` is test infrastructure only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import weights as W
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libumx.so")
+
+_lib = None
+
+
+class UmxError(RuntimeError):
+    """A libumx call returned a non-zero status."""
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """dlopen libumx.so and declare every entry point of include/umx.h."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("UMX_LIBRARY", LIB_PATH)
+    if not os.path.exists(p):
+        raise ImportError(
+            f"{p} not found: the HIP engine is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `python -m pdb2reaction_amd.build`) in the repository root; there is no CPU fallback."
+        )
+    lib = C.CDLL(p)
+    vp, i32, i64p, dp, fp = C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_float)
+    sigs = {
+        "umx_abi_version": ([], i32),
+        "umx_create": ([C.POINTER(vp), i32], i32),
+        "umx_destroy": ([vp], i32),
+        "umx_last_error": ([vp], C.c_char_p),
+        "umx_load_weights": ([vp, vp, C.c_size_t], i32),
+        "umx_set_system": ([vp, i32, C.POINTER(C.c_int32), i32, i32, i32, C.c_float, i32], i32),
+        "umx_set_workspace_limit": ([vp, C.c_size_t], i32),
+        "umx_energy_forces": ([vp, i32, fp, dp, fp], i32),
+        "umx_energy_forces_dev": ([vp, i32, vp, vp, vp, vp], i32),
+        "umx_synchronize": ([vp], i32),
+        "umx_last_graph_stats": ([vp, i64p, C.POINTER(C.c_int32)], i32),
+        "umx_profile_enable": ([vp, i32], i32),
+        "umx_profile_read": ([vp, dp, i64p, dp, i32], i32),
+        "umx_debug_fetch": ([vp, C.c_char_p, vp, C.c_size_t, C.POINTER(C.c_size_t)], i32),
+        "umx_debug_keep": ([vp, i32], i32),
+    }
+    for name, (args, res) in sigs.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.argtypes, fn.restype = args, res
+    if path is None:
+        _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = (
+    "umx_abi_version", "umx_create", "umx_destroy", "umx_last_error", "umx_load_weights", "umx_set_system",
+    "umx_set_workspace_limit", "umx_energy_forces", "umx_energy_forces_dev", "umx_synchronize",
+    "umx_last_graph_stats", "umx_profile_enable", "umx_profile_read", "umx_debug_fetch", "umx_debug_keep",
+)
+
+
+class Engine:
+    """One UMA-S engine on one GPU (one per process/rank)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        self._h = C.c_void_p()
+        st = self.lib.umx_create(C.byref(self._h), int(device))
+        if st != 0:
+            raise UmxError(f"umx_create failed ({st}): {self.lib.umx_last_error(None).decode()}")
+        self.device = int(device)
+        self.natoms = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.umx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, st: int, what: str):
+        if st != 0:
+            raise UmxError(f"{what} failed ({st}): {self.lib.umx_last_error(self._h).decode()}")
+
+    # ---- setup -----------------------------------------------------------------------------------
+    def load_weights(self, weights: Union[bytes, Dict[str, np.ndarray]]):
+        blob = weights if isinstance(weights, (bytes, bytearray)) else W.pack_blob(weights)
+        buf = C.create_string_buffer(bytes(blob), len(blob))
+        self._chk(self.lib.umx_load_weights(self._h, C.cast(buf, C.c_void_p), len(blob)), "umx_load_weights")
+
+    def set_system(self, atomic_numbers: Sequence[int], charge: int = 0, spin: int = 1, task: str = "omol",
+                   radius: Optional[float] = None, max_neigh: Optional[int] = None):
+        z = np.ascontiguousarray(atomic_numbers, dtype=np.int32)
+        if task not in W.DATASET_LIST:
+            raise ValueError(f"task_name {task!r} not in {W.DATASET_LIST}")
+        self._chk(self.lib.umx_set_system(self._h, len(z), z.ctypes.data_as(C.POINTER(C.c_int32)), int(charge), int(spin),
+                                          W.DATASET_LIST.index(task), float(radius or 0.0), int(max_neigh or 0)),
+                  "umx_set_system")
+        self.natoms = len(z)
+
+    def set_workspace_limit(self, nbytes: int):
+        self._chk(self.lib.umx_set_workspace_limit(self._h, int(nbytes)), "umx_set_workspace_limit")
+
+    # ---- evaluation ------------------------------------------------------------------------------
+    def energy_forces(self, pos_ang: np.ndarray, forces: bool = True) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+        """pos_ang: (K,N,3) or (N,3) Angstrom -> (E [K] eV float64, F [K,N,3] eV/A float32 | None)."""
+        p = np.ascontiguousarray(pos_ang, dtype=np.float32)
+        if p.ndim == 2:
+            p = p[None]
+        if p.ndim != 3 or p.shape[1] != self.natoms or p.shape[2] != 3:
+            raise ValueError(f"positions must be (K,{self.natoms},3), got {p.shape}")
+        k = p.shape[0]
+        e = np.empty(k, dtype=np.float64)
+        f = np.empty_like(p) if forces else None
+        fp = C.POINTER(C.c_float)
+        self._chk(self.lib.umx_energy_forces(self._h, k, p.ctypes.data_as(fp), e.ctypes.data_as(C.POINTER(C.c_double)),
+                                             f.ctypes.data_as(fp) if forces else None), "umx_energy_forces")
+        return e, f
+
+    def energy_forces_dev(self, n_images: int, d_pos: int, d_energy: int, d_forces: Optional[int], stream: int = 0):
+        """Device-pointer form (integers from e.g. ``tensor.data_ptr()``); enqueues on ``stream``."""
+        self._chk(self.lib.umx_energy_forces_dev(self._h, int(n_images), C.c_void_p(d_pos), C.c_void_p(d_energy),
+                                                 C.c_void_p(d_forces) if d_forces else None,
+                                                 C.c_void_p(stream) if stream else None), "umx_energy_forces_dev")
+
+    def synchronize(self):
+        self._chk(self.lib.umx_synchronize(self._h), "umx_synchronize")
+
+    # ---- diagnostics -----------------------------------------------------------------------------
+    def graph_stats(self) -> Tuple[int, int]:
+        ne, md = C.c_int64(), C.c_int32()
+        self._chk(self.lib.umx_last_graph_stats(self._h, C.byref(ne), C.byref(md)), "umx_last_graph_stats")
+        return int(ne.value), int(md.value)
+
+    def profile_enable(self, on: bool = True):
+        self._chk(self.lib.umx_profile_enable(self._h, int(on)), "umx_profile_enable")
+
+    def profile_read(self, reset: bool = True):
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        self._chk(self.lib.umx_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(fl), int(reset)), "umx_profile_read")
+        return {"gemm_ms": ms.value, "gemm_launches": int(n.value), "gemm_flops": fl.value}
+
+    def debug_keep(self, on: bool = True):
+        self._chk(self.lib.umx_debug_keep(self._h, int(on)), "umx_debug_keep")
+
+    def debug_fetch(self, name: str, dtype=np.float32) -> np.ndarray:
+        nb = C.c_size_t()
+        self._chk(self.lib.umx_debug_fetch(self._h, name.encode(), None, 0, C.byref(nb)), "umx_debug_fetch")
+        out = np.empty(nb.value // np.dtype(dtype).itemsize, dtype=dtype)
+        self._chk(self.lib.umx_debug_fetch(self._h, name.encode(), out.ctypes.data_as(C.c_void_p), out.nbytes, None),
+                  "umx_debug_fetch")
+        return out

@@ -1,0 +1,357 @@
+"""UMA calculator for pysisyphus -- MI355X-native drop-in for ``pdb2reaction.uma_pysis``.
+
+Mirrors the reference interface (reference ``pdb2reaction/uma_pysis.py``):
+
+* ``CALC_KW`` / ``GEOM_KW_DEFAULT`` (``:132-165``), unit constants (``:127-129``);
+* ``UMAcore`` (``:170-419``): ``compute(coord_ang, forces=, hessian=)`` -> eV, eV/A;
+* ``uma_pysis(Calculator)`` (``:425-780``): ``get_energy / get_forces / get_hessian(elem, coords)``
+  with coordinates in Bohr, results in Hartree, Hartree/Bohr, Hartree/Bohr^2, frozen-atom force
+  zeroing (``:561-567``), finite-difference Hessian (``:595-686``), Hessian symmetrisation / unit
+  conversion / dtype (``:515-551``), mode dispatch (``:708-780``);
+* ``run_pysis`` (``:784-789``).
+
+What differs underneath: ``predict_unit.predict(batch)`` (fairchem, ``:373,385``) is replaced by the
+HIP engine (``libumx.so``), and two batched entry points are added so a string driver can evaluate
+all images at once: ``UMAcore.compute_batch`` and ``uma_pysis.get_forces_batch``.  The FD Hessian
+uses the batched path (the 2*3N_active displaced geometries are images of one batch) but keeps the
+reference's arithmetic: float32 forces, central difference with h = 1e-3 A, columns assembled in
+float64 when ``hessian_double``.
+
+There is no CPU fallback: importing works anywhere, evaluating requires a gfx950 GPU and the built
+library, and fails loudly otherwise.
+"""
+from __future__ import annotations
+
+import os
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from ._calculator_base import ANG2BOHR, AU2EV, BOHR2ANG, Calculator
+from . import synth
+from . import weights as W
+
+# ------------ unit conversion constants (reference uma_pysis.py:127-129) ----------------------
+EV2AU = 1.0 / AU2EV                       # eV -> Hartree
+F_EVAA_2_AU = EV2AU / ANG2BOHR            # eV/A -> Hartree/Bohr
+H_EVAA_2_AU = EV2AU / ANG2BOHR / ANG2BOHR  # eV/A^2 -> Hartree/Bohr^2
+
+# reference uma_pysis.py:132-135
+GEOM_KW_DEFAULT: Dict[str, Any] = {
+    "coord_type": "cart",
+    "freeze_atoms": [],
+}
+
+# reference uma_pysis.py:138-165
+CALC_KW: Dict[str, Any] = {
+    "charge": 0,
+    "spin": 1,
+    "model": "uma-s-1p1",
+    "task_name": "omol",
+    "device": "auto",
+    "workers": 1,
+    "workers_per_node": 1,
+    "max_neigh": None,
+    "radius": None,
+    "r_edges": False,
+    "out_hess_torch": True,
+    "freeze_atoms": None,
+    "hessian_calc_mode": "FiniteDifference",
+    "return_partial_hessian": False,
+    "hessian_double": True,
+}
+
+# number of displaced geometries evaluated per engine call while building an FD Hessian
+FD_BATCH = int(os.environ.get("UMX_FD_BATCH", "64"))
+
+
+def resolve_weights(model: str) -> Dict[str, np.ndarray]:
+    """Map the reference's ``model`` keyword to a merged UMA-S parameter set.
+
+    * a path to a ``.umxw`` blob -> loaded as is;
+    * a model name -> ``$UMX_WEIGHTS_DIR/<name>.umxw`` if present;
+    * otherwise the deterministic synthetic stand-in (``weights.make_synthetic_weights``), because the
+      real checkpoint is a gated download that does not exist in this environment.
+    """
+    if os.path.isfile(model):
+        return W.load_weights(model)
+    wdir = os.environ.get("UMX_WEIGHTS_DIR")
+    if wdir:
+        cand = os.path.join(wdir, f"{model}.umxw")
+        if os.path.isfile(cand):
+            return W.load_weights(cand)
+    return W.make_synthetic_weights(int(os.environ.get("UMX_SYNTHETIC_SEED", "0")))
+
+
+def _device_index(device: str) -> int:
+    """'auto' | 'cuda' | 'cuda:N' -> HIP ordinal; 'cpu' is refused (no CPU path exists)."""
+    d = str(device).lower()
+    if d == "cpu":
+        raise RuntimeError("device='cpu' requested, but this calculator has no CPU path; it requires an MI355X (gfx950) GPU.")
+    if d in ("auto", "cuda", "hip", "gpu"):
+        return int(os.environ.get("LOCAL_RANK", "0")) if d == "auto" and "LOCAL_RANK" in os.environ else 0
+    if ":" in d:
+        return int(d.split(":", 1)[1])
+    raise ValueError(f"unrecognised device {device!r}")
+
+
+# ===================================================================
+#                         UMA core wrapper
+# ===================================================================
+class UMAcore:
+    """Thin wrapper around the HIP engine (counterpart of reference ``UMAcore``, ``:170-419``)."""
+
+    def __init__(
+        self,
+        elem: Sequence[str],
+        *,
+        charge: int = 0,
+        spin: int = 1,
+        model: str = "uma-s-1p1",
+        task_name: str = "omol",
+        device: str = "auto",
+        workers: int = 1,
+        workers_per_node: int = 1,
+        max_neigh: Optional[int] = None,
+        radius: Optional[float] = None,
+        r_edges: bool = False,
+    ):
+        from .engine import Engine  # raises ImportError loudly when libumx.so is missing
+
+        self.device_str = device
+        self.workers = max(int(workers) if workers is not None else 1, 1)
+        self.workers_per_node = max(int(workers_per_node) if workers_per_node is not None else 1, 1)
+        # The reference's workers>1 is graph-parallel inference of ONE image (ParallelMLIPPredictUnit,
+        # :220-242).  Here images are the parallel unit (one engine per GPU, see parallel.py); inside
+        # a process `workers` only keeps the reference's side effect: no analytical Hessian.
+        self.parallel_predict = self.workers > 1
+        self.has_torch_model = False       # no nn.Module is exposed -> analytical Hessian unavailable
+        self.elem = [e.capitalize() for e in elem]
+        self.charge = charge
+        self.spin = spin
+        self.task_name = task_name
+        self._max_neigh_user = max_neigh
+        self._radius_user = radius
+        self._r_edges_user = r_edges
+
+        self.engine = Engine(_device_index(device))
+        self.engine.load_weights(resolve_weights(model))
+        self.z = synth.symbols_to_z(self.elem)
+        self.engine.set_system(self.z, charge=charge, spin=spin, task=task_name, radius=radius, max_neigh=max_neigh)
+
+    @property
+    def device(self):
+        import torch
+        return torch.device("cuda", self.engine.device)
+
+    # ----------------------------------------------------------------
+    def compute_batch(self, coords_ang: np.ndarray, *, forces: bool = True) -> Dict[str, Any]:
+        """Batched evaluation: (K,N,3) A -> {"energy": (K,) float64 eV, "forces": (K,N,3) float32 eV/A}."""
+        e, f = self.engine.energy_forces(np.asarray(coords_ang), forces=forces)
+        return {"energy": e, "forces": f}
+
+    def compute(self, coord_ang: np.ndarray, *, forces: bool = False, hessian: bool = False) -> Dict[str, Any]:
+        """Energy (eV) and optionally forces (eV/A) of one geometry; same contract as reference ``:330-419``."""
+        if hessian:
+            raise RuntimeError(
+                "Analytical Hessian is not available when predictor workers > 1 "
+                "or when predictor.model is not exposed. Use FiniteDifference Hessian."
+            )
+        e, f = self.engine.energy_forces(np.asarray(coord_ang, dtype=np.float64).reshape(1, -1, 3), forces=forces)
+        return {"energy": float(e[0]), "forces": (f[0] if forces else None), "hessian": None}
+
+
+# ===================================================================
+#                    PySisyphus calculator class
+# ===================================================================
+class uma_pysis(Calculator):
+    """PySisyphus-compatible UMA calculator (counterpart of reference ``:425-780``)."""
+
+    implemented_properties = ["energy", "forces", "hessian"]
+
+    def __init__(
+        self,
+        *,
+        charge: int = CALC_KW["charge"],
+        spin: int = CALC_KW["spin"],
+        model: str = CALC_KW["model"],
+        task_name: str = CALC_KW["task_name"],
+        device: str = CALC_KW["device"],
+        workers: int = CALC_KW["workers"],
+        workers_per_node: int = CALC_KW["workers_per_node"],
+        out_hess_torch: bool = CALC_KW["out_hess_torch"],
+        max_neigh: Optional[int] = CALC_KW["max_neigh"],
+        radius: Optional[float] = CALC_KW["radius"],
+        r_edges: bool = CALC_KW["r_edges"],
+        freeze_atoms: Optional[Sequence[int]] = CALC_KW["freeze_atoms"],
+        hessian_calc_mode: str = CALC_KW["hessian_calc_mode"],
+        return_partial_hessian: bool = CALC_KW["return_partial_hessian"],
+        hessian_double: bool = CALC_KW["hessian_double"],
+        **kwargs,
+    ):
+        super().__init__(charge=charge, mult=spin, **kwargs)
+        self._core: Optional[UMAcore] = None
+        self._core_kw = dict(
+            charge=charge, spin=spin, model=model, task_name=task_name, device=device, workers=workers,
+            workers_per_node=workers_per_node, max_neigh=max_neigh, radius=radius, r_edges=r_edges,
+        )
+        self.out_hess_torch = out_hess_torch
+        self.hessian_calc_mode = hessian_calc_mode
+        self.freeze_atoms: List[int] = sorted(set(int(i) for i in (freeze_atoms or [])))
+        self.return_partial_hessian = bool(return_partial_hessian)
+        self.hessian_double = bool(hessian_double)
+
+    # ---------- helpers ---------------------------------------------
+    def _ensure_core(self, elem: Sequence[str]):
+        # first `elem` binds the instance for its lifetime, as in the reference (:502-504)
+        if self._core is None:
+            self._core = UMAcore(elem, **self._core_kw)
+
+    @staticmethod
+    def _au_energy(E: float) -> float:
+        return E * EV2AU
+
+    @staticmethod
+    def _au_forces(F: np.ndarray) -> np.ndarray:
+        F64 = np.asarray(F, dtype=np.float64)
+        return (F64 * F_EVAA_2_AU).reshape(-1)
+
+    def _au_hessian(self, H):
+        """(N,3,N,3) eV/A^2 -> symmetrised (3N,3N) Hartree/Bohr^2; dtype/format as reference ``:515-551``."""
+        import torch
+
+        n = H.size(0)
+        H = H.view(n * 3, n * 3)
+        H = 0.5 * (H + H.T)
+        H = H * H_EVAA_2_AU
+        if self.hessian_double:
+            H = H.to(dtype=torch.float64)
+        if self.out_hess_torch:
+            return H.detach()
+        return H.detach().cpu().numpy()
+
+    def _active_and_frozen_dof_idx(self, n_atoms: int):
+        frozen_set = set(self.freeze_atoms)
+        active_atoms = [i for i in range(n_atoms) if i not in frozen_set]
+        active_dof_idx = [3 * i + j for i in active_atoms for j in range(3)]
+        frozen_dof_idx = [3 * i + j for i in self.freeze_atoms for j in range(3)]
+        return active_atoms, active_dof_idx, frozen_dof_idx
+
+    def _zero_frozen_forces_ev(self, F: np.ndarray) -> np.ndarray:
+        """Zero forces (eV/A) on frozen atoms; works on (N,3) and on batched (K,N,3) arrays."""
+        if (F is None) or (len(self.freeze_atoms) == 0):
+            return F
+        Fz = F.copy()
+        Fz[..., np.asarray(self.freeze_atoms, dtype=int), :] = 0.0
+        return Fz
+
+    # ---------- Finite-Difference Hessian (device assembly, batched displacements) -------------
+    def _build_fd_hessian_gpu(self, elem: Sequence[str], coord_ang: np.ndarray, *, eps_ang: float = 1.0e-3) -> Dict[str, Any]:
+        """H[:, k] = -(F(x + h e_k) - F(x - h e_k)) / (2h) over active DOF (reference ``:595-686``).
+
+        The reference issues 2 serial force calls per active DOF; here the displaced geometries are
+        evaluated ``FD_BATCH`` at a time as images of one batch.  Arithmetic per column is unchanged.
+        """
+        import torch
+
+        self._ensure_core(elem)
+        core = self._core
+        dev = core.device
+        n_atoms = len(elem)
+        dof = n_atoms * 3
+        active_atoms, active_dof_idx, _ = self._active_and_frozen_dof_idx(n_atoms)
+
+        res0 = core.compute(coord_ang, forces=True, hessian=False)
+        energy0_eV = res0["energy"]
+        F0 = res0["forces"]
+        force_dtype = torch.from_numpy(F0).dtype
+        hessian_dtype = torch.float64 if self.hessian_double else force_dtype
+        H = torch.zeros((dof, dof), device=dev, dtype=hessian_dtype)
+
+        half = max(FD_BATCH // 2, 1)
+        for s in range(0, len(active_dof_idx), half):
+            ks = active_dof_idx[s: s + half]
+            batch = np.repeat(np.asarray(coord_ang, dtype=np.float64)[None], 2 * len(ks), axis=0)
+            for m, k in enumerate(ks):
+                a, c = divmod(k, 3)
+                batch[2 * m, a, c] = coord_ang[a, c] + eps_ang
+                batch[2 * m + 1, a, c] = coord_ang[a, c] - eps_ang
+            F = core.compute_batch(batch, forces=True)["forces"].reshape(2 * len(ks), dof)
+            Ft = torch.from_numpy(F).to(dev, dtype=hessian_dtype)
+            cols = -(Ft[0::2] - Ft[1::2]) / (2.0 * eps_ang)          # (len(ks), 3N)
+            H[:, torch.as_tensor(ks, device=dev, dtype=torch.long)] = cols.T
+
+        if self.return_partial_hessian:
+            idx = torch.tensor(active_dof_idx, device=dev, dtype=torch.long)
+            H = H.index_select(0, idx).index_select(1, idx)
+            H = H.view(len(active_atoms), 3, len(active_atoms), 3)
+        else:
+            H = H.view(n_atoms, 3, n_atoms, 3)
+        return {"energy": energy0_eV, "forces": F0, "hessian": H}
+
+    # ---------- PySisyphus API --------------------------------------
+    def get_energy(self, elem, coords):
+        self._ensure_core(elem)
+        coord_ang = np.asarray(coords, dtype=np.float64).reshape(-1, 3) * BOHR2ANG
+        res = self._core.compute(coord_ang, forces=False, hessian=False)
+        return {"energy": self._au_energy(res["energy"])}
+
+    def get_forces(self, elem, coords):
+        self._ensure_core(elem)
+        coord_ang = np.asarray(coords, dtype=np.float64).reshape(-1, 3) * BOHR2ANG
+        res = self._core.compute(coord_ang, forces=True, hessian=False)
+        F_ev = self._zero_frozen_forces_ev(res["forces"])
+        return {"energy": self._au_energy(res["energy"]), "forces": self._au_forces(F_ev)}
+
+    def get_forces_batch(self, elem, coords_batch):
+        """All images of a string in ONE engine call.
+
+        ``coords_batch``: (K, 3N) or (K, N, 3) Bohr.  Returns ``{"energy": (K,) Hartree,
+        "forces": (K, 3N) Hartree/Bohr float64}`` -- per image exactly what ``get_forces`` returns.
+        """
+        self._ensure_core(elem)
+        c = np.asarray(coords_batch, dtype=np.float64)
+        k = c.shape[0]
+        coord_ang = c.reshape(k, -1, 3) * BOHR2ANG
+        res = self._core.compute_batch(coord_ang, forces=True)
+        F_ev = self._zero_frozen_forces_ev(res["forces"])
+        return {
+            "energy": np.asarray(res["energy"], dtype=np.float64) * EV2AU,
+            "forces": (np.asarray(F_ev, dtype=np.float64) * F_EVAA_2_AU).reshape(k, -1),
+        }
+
+    def get_energy_batch(self, elem, coords_batch):
+        self._ensure_core(elem)
+        c = np.asarray(coords_batch, dtype=np.float64)
+        k = c.shape[0]
+        res = self._core.compute_batch(c.reshape(k, -1, 3) * BOHR2ANG, forces=False)
+        return {"energy": np.asarray(res["energy"], dtype=np.float64) * EV2AU}
+
+    def get_hessian(self, elem, coords):
+        """Hessian per ``hessian_calc_mode``; the engine exposes no differentiable torch model, so --
+        exactly like the reference with ``workers > 1`` (``:736-737``) -- FiniteDifference is always used."""
+        self._ensure_core(elem)
+        coord_ang = np.asarray(coords, dtype=np.float64).reshape(-1, 3) * BOHR2ANG
+        core = self._core
+        force_fd = core.parallel_predict or (not core.has_torch_model)
+        mode = (self.hessian_calc_mode or "FiniteDifference").strip().lower()
+        if (not force_fd) and (mode in ("analytical", "analytic")):   # unreachable here; kept for parity of control flow
+            core.compute(coord_ang, forces=True, hessian=True)
+        res = self._build_fd_hessian_gpu(elem, coord_ang)
+        res_forces_ev = self._zero_frozen_forces_ev(res["forces"])
+        return {
+            "energy": self._au_energy(res["energy"]),
+            "forces": self._au_forces(res_forces_ev),
+            "hessian": self._au_hessian(res["hessian"]),
+        }
+
+
+# ---------- CLI ----------------------------------------
+def run_pysis():
+    """Enable ``uma_pysis input.yaml`` (reference ``:784-789``); needs pysisyphus installed."""
+    try:
+        from pysisyphus import run
+    except ImportError as exc:  # pragma: no cover
+        raise ImportError("run_pysis() needs pysisyphus, which is not installed in this environment") from exc
+    run.CALC_DICT["uma_pysis"] = uma_pysis
+    run.run()

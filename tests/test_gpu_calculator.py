@@ -1,0 +1,89 @@
+"""GPU tests of the drop-in calculator (reference pdb2reaction/uma_pysis.py API) on the real engine."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from pdb2reaction_amd import synth
+
+U = importlib.import_module("pdb2reaction_amd.uma_pysis")
+pytestmark = pytest.mark.gpu
+
+SYMS = {1: "H", 6: "C", 7: "N", 8: "O", 16: "S"}
+
+
+@pytest.fixture(scope="module")
+def setup(oracle):
+    z, imgs, _ = synth.make_images(14, 4, seed=21)
+    elem = [SYMS[int(v)].lower() for v in z]           # any case, like the reference (:266)
+    return z, elem, imgs
+
+
+def test_get_forces_matches_oracle_in_atomic_units(oracle, setup):
+    z, elem, imgs = setup
+    calc = U.uma_pysis(freeze_atoms=[0, 5])
+    x_bohr = (imgs[0] * U.ANG2BOHR).reshape(-1)
+    r = calc.get_forces(elem, x_bohr)
+    p32 = (x_bohr.reshape(-1, 3) * U.BOHR2ANG).astype(np.float32)
+    e_ref, f_ref = oracle.energy_forces(z, p32.astype(np.float64))
+    assert abs(r["energy"] - e_ref * U.EV2AU) <= 1e-4 * U.EV2AU
+    f_ref[[0, 5]] = 0.0
+    assert r["forces"].dtype == np.float64 and r["forces"].shape == (42,)
+    assert np.abs(r["forces"] - (f_ref * U.F_EVAA_2_AU).reshape(-1)).max() <= 1e-3 * U.F_EVAA_2_AU
+    assert np.all(r["forces"].reshape(-1, 3)[[0, 5]] == 0.0)
+    assert calc.get_energy(elem, x_bohr)["energy"] == pytest.approx(r["energy"], abs=1e-9)
+
+
+def test_batch_equals_serial_calls(setup):
+    z, elem, imgs = setup
+    calc = U.uma_pysis()
+    xb = imgs.reshape(4, -1) * U.ANG2BOHR
+    rb = calc.get_forces_batch(elem, xb)
+    for k in range(4):
+        r = calc.get_forces(elem, xb[k])
+        assert r["energy"] == rb["energy"][k] and np.array_equal(r["forces"], rb["forces"][k])
+
+
+def test_fd_hessian_against_oracle_fd(oracle, setup):
+    z, elem, imgs = setup
+    calc = U.uma_pysis(freeze_atoms=[3], out_hess_torch=True)
+    x_bohr = (imgs[1] * U.ANG2BOHR).reshape(-1)
+    r = calc.get_hessian(elem, x_bohr)
+    h = r["hessian"]
+    assert isinstance(h, torch.Tensor) and h.dtype == torch.float64 and h.shape == (42, 42) and h.is_cuda
+    h = h.cpu().numpy()
+    assert np.allclose(h, h.T)
+    # oracle central differences with the same step on a few active columns
+    p = (x_bohr.reshape(-1, 3) * U.BOHR2ANG).astype(np.float32).astype(np.float64)
+    full = np.zeros((42, 42))
+    cols = [0, 7, 20, 41]
+    for k in cols:
+        a, c = divmod(k, 3)
+        pp, pm = p.copy(), p.copy()
+        pp[a, c] += 1e-3
+        pm[a, c] -= 1e-3
+        fp = oracle.energy_forces(z, pp)[1].reshape(-1)
+        fm = oracle.energy_forces(z, pm)[1].reshape(-1)
+        full[:, k] = -(fp - fm) / 2e-3
+    # compare un-symmetrised information: H_sym[i,k] = (H[i,k]+H[k,i])/2, check the diagonal block of those columns
+    sub = np.ix_(cols, cols)
+    ref = 0.5 * (full[sub] + full[sub].T) * U.H_EVAA_2_AU
+    assert np.abs(h[sub] - ref).max() <= 5e-3 * U.H_EVAA_2_AU          # fp32 forces / 2e-3 A ~ 1e-3 eV/A^2 noise floor
+    calc2 = U.uma_pysis(freeze_atoms=[3], return_partial_hessian=True, out_hess_torch=False, hessian_double=False)
+    h2 = calc2.get_hessian(elem, x_bohr)["hessian"]
+    assert h2.shape == (39, 39) and h2.dtype == np.float32
+
+
+def test_error_behaviour(setup):
+    z, elem, imgs = setup
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        U.uma_pysis(device="cpu").get_energy(elem, imgs[0].reshape(-1))
+    with pytest.raises(ValueError):
+        U.uma_pysis().get_energy(["Xx"] * 14, imgs[0].reshape(-1))
+    c = U.uma_pysis()
+    c.get_energy(elem, imgs[0].reshape(-1))
+    with pytest.raises(RuntimeError, match="Analytical Hessian is not available"):
+        c._core.compute(imgs[0], forces=True, hessian=True)
+    with pytest.raises(ValueError):
+        c.get_energy(elem, np.zeros(9))                 # wrong atom count for the bound system

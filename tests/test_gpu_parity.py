@@ -1,0 +1,214 @@
+"""GPU parity tests (through the C ABI): HIP engine vs the float64 CPU oracle, the committed golden
+fixtures, and size-independent invariants at the full BASELINE sizes.
+
+Tolerances are the north-star's: |dE| <= 1e-4 eV, max|dF| <= 1e-3 eV/A (BASELINE.json)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from pdb2reaction_amd import synth, weights as W
+
+pytestmark = pytest.mark.gpu
+
+TOL_E = 1e-4   # eV
+TOL_F = 1e-3   # eV/Angstrom
+
+
+def check(engine, oracle, z, imgs, **sys_kw):
+    p32 = np.asarray(imgs, dtype=np.float32)
+    engine.set_system(z, **sys_kw)
+    e, f = engine.energy_forces(p32)
+    for k in range(len(p32)):
+        e_ref, f_ref = oracle.energy_forces(z, p32[k].astype(np.float64), **sys_kw)
+        assert abs(e[k] - e_ref) <= TOL_E, (k, e[k], e_ref)
+        assert np.abs(f[k] - f_ref).max() <= TOL_F
+    return e, f
+
+
+@pytest.mark.parametrize("n,k,seed", [(2, 1, 1), (9, 2, 2), (33, 3, 3), (64, 2, 4), (130, 1, 5)])
+def test_engine_matches_oracle(engine, oracle, n, k, seed):
+    z, imgs, _ = synth.make_images(n, k, seed=seed)
+    check(engine, oracle, z, imgs)
+
+
+@pytest.mark.parametrize("kw", [dict(charge=-1, spin=2, task="omat"), dict(charge=2, spin=3, task="oc20"), dict(charge=0, spin=1, task="omc")])
+def test_charge_spin_task(engine, oracle, kw):
+    z, imgs, _ = synth.make_images(24, 1, seed=11)
+    check(engine, oracle, z, imgs, **kw)
+
+
+def test_heavier_elements(engine, oracle):
+    z, imgs, _ = synth.make_images(28, 1, seed=12)
+    z = z.copy()
+    z[::3] = [26, 17, 15, 30, 35, 12, 29, 34, 11, 9][: len(z[::3])]
+    check(engine, oracle, z, imgs)
+
+
+@pytest.mark.parametrize("name", ["small_n20_k3", "small_n20_charged", "c1_n50_k8", "c2_n500_k2"])
+def test_golden_fixtures(engine, name):
+    g = load_golden(name)
+    engine.set_system(g["z"], charge=int(g["charge"]), spin=int(g["spin"]), task=str(g["task"]))
+    e, f = engine.energy_forces(g["pos"])
+    assert np.abs(e - g["energy"]).max() <= TOL_E
+    assert np.abs(f - g["forces"]).max() <= TOL_F
+
+
+def test_no_edges_and_isolated_atoms(engine, oracle):
+    """Empty / ragged graphs: a lone atom, two atoms beyond the cutoff, one isolated atom next to a cluster."""
+    z = np.array([8], dtype=np.int32)
+    engine.set_system(z)
+    e, f = engine.energy_forces(np.zeros((1, 1, 3), np.float32))
+    e_ref, _ = oracle.energy_forces(z, np.zeros((1, 3)))
+    assert engine.graph_stats() == (0, 0) and abs(e[0] - e_ref) <= TOL_E and np.all(f == 0)
+    z = np.array([1, 6], dtype=np.int32)
+    far = np.array([[[0, 0, 0], [0, 0, 7.5]]], np.float32)
+    engine.set_system(z)
+    e, f = engine.energy_forces(far)
+    assert engine.graph_stats()[0] == 0 and np.all(f == 0)
+    assert abs(e[0] - oracle.energy_forces(z, far[0].astype(np.float64))[0]) <= TOL_E
+    zc, pc = synth.make_cluster(12, seed=9)
+    z = np.concatenate([zc, [7]]).astype(np.int32)
+    p = np.concatenate([pc, [[40.0, 0, 0]]])[None]
+    check(engine, oracle, z, p)
+
+
+def test_pole_aligned_edges(engine, oracle):
+    """Edges exactly along +y / -y exercise the detached-pole branch and the flipped frame."""
+    z = np.array([6, 8, 1, 7], dtype=np.int32)
+    p = np.array([[[0, 0, 0], [0, 1.4, 0], [0, -1.1, 0], [1.2, 0.3, -0.4]]], np.float64)
+    check(engine, oracle, z, p)
+
+
+def test_max_neigh_is_enforced_loudly(engine):
+    from pdb2reaction_amd.engine import UmxError
+
+    z, imgs, _ = synth.make_images(40, 1, seed=3)
+    engine.set_system(z, max_neigh=5)
+    with pytest.raises(UmxError, match="max_neigh"):
+        engine.energy_forces(imgs)
+    engine.set_system(z, radius=3.0)
+    e, _ = engine.energy_forces(imgs)
+    assert np.isfinite(e).all()
+
+
+def test_batched_equals_single_and_chunked(engine):
+    """Images are independent units: batched, one-by-one and chunked evaluation agree bit for bit."""
+    z, imgs, _ = synth.make_images(70, 5, seed=6)
+    engine.set_system(z)
+    e, f = engine.energy_forces(imgs)
+    for k in range(5):
+        e1, f1 = engine.energy_forces(imgs[k])
+        assert e1[0] == e[k] and np.array_equal(f1[0], f[k])
+    os.environ["UMX_MAX_CHUNK_IMAGES"] = "2"
+    try:
+        e2, f2 = engine.energy_forces(imgs)
+    finally:
+        del os.environ["UMX_MAX_CHUNK_IMAGES"]
+    assert np.array_equal(e2, e) and np.array_equal(f2, f)
+    e3, _ = engine.energy_forces(imgs, forces=False)
+    assert np.array_equal(e3, e)
+
+
+def test_deterministic(engine):
+    z, imgs, _ = synth.make_images(90, 2, seed=8)
+    engine.set_system(z)
+    a = engine.energy_forces(imgs)
+    b = engine.energy_forces(imgs)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])     # segmented sums, no float atomics
+
+
+def test_device_pointer_entry(engine):
+    z, imgs, _ = synth.make_images(30, 3, seed=2)
+    engine.set_system(z)
+    e, f = engine.energy_forces(imgs)
+    dev = torch.device("cuda", 0)
+    pos = torch.as_tensor(imgs, dtype=torch.float32, device=dev).contiguous()
+    ed = torch.zeros(3, dtype=torch.float64, device=dev)
+    fd = torch.zeros(3, 30, 3, dtype=torch.float32, device=dev)
+    engine.energy_forces_dev(3, pos.data_ptr(), ed.data_ptr(), fd.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(ed.cpu().numpy(), e) and np.array_equal(fd.cpu().numpy(), f)
+
+
+def test_stage_by_stage_against_staged_oracle(engine, weights):
+    """Every intermediate of the forward AND of the analytic reverse pass vs oracle/staged.py."""
+    from oracle.staged import Staged
+
+    z, pos = synth.make_cluster(26, seed=4)
+    p32 = pos.astype(np.float32)
+    st = Staged(weights)
+    st.forward(z, p32.astype(np.float64))
+    st.backward()
+    t = {k: v.numpy() for k, v in st.t.items() if torch.is_tensor(v)}
+    ne = len(t["src"])
+    engine.set_system(z)
+    engine.debug_keep(True)
+    try:
+        engine.energy_forces(p32)
+        assert np.array_equal(engine.debug_fetch("src", np.int32), t["src"])
+        assert np.array_equal(engine.debug_fetch("dst", np.int32), t["dst"])
+        rev = engine.debug_fetch("rev", np.int32)
+        assert np.array_equal(t["src"][rev], t["dst"]) and np.array_equal(t["dst"][rev], t["src"])
+        names = ["x0", "rad.deg", "e_node", "g_xfinal", "dedd"]
+        for i in range(W.NUM_LAYERS):
+            names += [f"{s}.{i}" for s in ("xn", "xrot", "rad", "hid", "msg", "xmid", "xn2", "gspre", "ffh", "x", "g_xmid", "g_msg",
+                                            "g_hid", "g_xrot", "g_rad", "g_xn", "g_xin")]
+        for nm in names:
+            a = engine.debug_fetch(nm)
+            r = t[nm].reshape(-1)
+            assert a.size == r.size, nm
+            assert np.abs(a - r).max() <= 2e-5 * max(np.abs(r).max(), 1.0), nm
+        tau = engine.debug_fetch("tau").reshape(ne, 4)[:, :3]
+        assert np.abs(tau - t["tau"]).max() <= 2e-5 and np.abs(tau[:, 1]).max() <= 1e-5   # gauge: no torque about the edge
+    finally:
+        engine.debug_keep(False)
+
+
+# ---- BASELINE sizes: size-independent properties (the oracle is too slow there) -----------------
+@pytest.fixture(scope="module")
+def c3(engine):
+    z, imgs, frozen = synth.make_images(2000, 2)
+    engine.set_system(z)
+    e, f = engine.energy_forces(imgs)
+    return z, imgs, e, f
+
+
+def test_c3_newton_third_law(c3):
+    _, _, e, f = c3
+    assert np.isfinite(e).all() and np.isfinite(f).all()
+    assert np.abs(f.astype(np.float64).sum(axis=1)).max() <= 5e-4        # sum of 2000 float32 forces
+
+
+def test_c3_rotation_translation_invariance(engine, c3):
+    from scipy.spatial.transform import Rotation
+
+    z, imgs, e, f = c3
+    rm = Rotation.random(random_state=3).as_matrix()
+    e2, f2 = engine.energy_forces(imgs @ rm.T + np.array([1.0, -2.0, 0.5]))
+    assert np.abs(e2 - e).max() <= 2e-3                                   # fp32 round-off of rotated float32 inputs
+    assert np.abs(f2 - f @ rm.T.astype(np.float32)).max() <= TOL_F
+
+
+def test_c3_permutation_invariance(engine, c3):
+    z, imgs, e, f = c3
+    perm = np.random.default_rng(0).permutation(len(z))
+    engine.set_system(z[perm])
+    e2, f2 = engine.energy_forces(imgs[:, perm])
+    engine.set_system(z)
+    assert np.abs(e2 - e).max() <= 1e-3
+    assert np.abs(f2 - f[:, perm]).max() <= TOL_F
+
+
+def test_c3_forces_are_energy_gradient(engine, c3):
+    z, imgs, e, f = c3
+    h = 2e-2
+    rng = np.random.default_rng(1)
+    d = rng.standard_normal(imgs[0].shape)
+    d /= np.linalg.norm(d)
+    ep, _ = engine.energy_forces(imgs[0] + h * d, forces=False)
+    em, _ = engine.energy_forces(imgs[0] - h * d, forces=False)
+    fd = -(ep[0] - em[0]) / (2 * h)
+    assert abs(fd - float((f[0].astype(np.float64) * d).sum())) <= 2e-2 * max(1.0, abs(fd))

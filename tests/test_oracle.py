@@ -1,0 +1,138 @@
+"""CPU tests of the oracle itself: physical invariants (the only pin available -- the reference has
+no tests or golden vectors), the hand-derived reverse pass, golden fixtures."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from pdb2reaction_amd import synth, weights as W
+
+
+@pytest.fixture(scope="module")
+def system():
+    z, pos = synth.make_cluster(16, seed=3)
+    return z, pos
+
+
+def test_param_inventory():
+    shapes = W.param_shapes()
+    n = sum(int(np.prod(s)) for s in shapes.values())
+    assert n == 6_349_926                                   # ~6.6 M "active" parameters of UMA-S
+    assert shapes["blocks.0.edge_wise.so2_conv_1.fc_m0.weight"] == (640, 768)
+    assert shapes["blocks.3.edge_wise.so2_conv_1.rad_func.fc3.weight"] == (1536, 128)
+
+
+def test_blob_roundtrip(weights):
+    blob = W.pack_blob(weights)
+    back = W.unpack_blob(blob)
+    assert list(back) == list(weights)
+    assert all(np.array_equal(back[k], weights[k]) for k in weights)
+    with pytest.raises(ValueError):
+        W.unpack_blob(b"garbage!" + blob[8:])
+
+
+def test_rotation_translation_invariance(oracle, system):
+    from scipy.spatial.transform import Rotation
+
+    z, pos = system
+    e, f = oracle.energy_forces(z, pos)
+    rm = Rotation.random(random_state=5).as_matrix()
+    e2, f2 = oracle.energy_forces(z, pos @ rm.T + np.array([0.3, -2.0, 1.1]))
+    assert abs(e2 - e) < 1e-9
+    assert np.abs(f2 - f @ rm.T).max() < 1e-10
+
+
+def test_permutation_invariance(oracle, system):
+    z, pos = system
+    e, f = oracle.energy_forces(z, pos)
+    perm = np.random.default_rng(1).permutation(len(z))
+    e2, f2 = oracle.energy_forces(z[perm], pos[perm])
+    assert abs(e2 - e) < 1e-9
+    assert np.abs(f2 - f[perm]).max() < 1e-10
+
+
+def test_gauge_roll_invariance(oracle, system):
+    """mmax == lmax: E and F do not depend on the roll angle of the per-edge frame."""
+    from oracle.escn_md_oracle import radius_graph
+
+    z, pos = system
+    e, f = oracle.energy_forces(z, pos)
+    src, _ = radius_graph(torch.as_tensor(pos), W.CUTOFF)
+    roll = torch.rand(len(src), dtype=torch.float64, generator=torch.Generator().manual_seed(0)) * 6.28
+    e2, f2 = oracle.energy_forces(z, pos, roll=roll)
+    assert abs(e2 - e) < 1e-9
+    assert np.abs(f2 - f).max() < 1e-10
+
+
+def test_forces_are_minus_gradient(oracle, system):
+    z, pos = system
+    _, f = oracle.energy_forces(z, pos)
+    assert np.abs(f.sum(0)).max() < 1e-10                   # Newton's third law
+    h = 1e-4
+    for a, c in [(0, 0), (7, 1), (15, 2)]:
+        pp, pm = pos.copy(), pos.copy()
+        pp[a, c] += h
+        pm[a, c] -= h
+        ep, _ = oracle.energy_forces(z, pp, forces=False)
+        em, _ = oracle.energy_forces(z, pm, forces=False)
+        assert abs(-(ep - em) / (2 * h) - f[a, c]) < 1e-6
+
+
+def test_charge_spin_task_change_the_result(oracle, system):
+    z, pos = system
+    e0, _ = oracle.energy_forces(z, pos, forces=False)
+    assert abs(oracle.energy_forces(z, pos, charge=1, forces=False)[0] - e0) > 1e-6
+    assert abs(oracle.energy_forces(z, pos, spin=3, forces=False)[0] - e0) > 1e-6
+    assert abs(oracle.energy_forces(z, pos, task="omat", forces=False)[0] - e0) > 1e-6
+
+
+def test_hand_derived_backward_matches_autograd(weights, oracle, system):
+    """The kernel-level reverse pass (torque formulation, oracle/staged.py) equals autograd."""
+    from oracle.staged import Staged
+
+    z, pos = system
+    st = Staged(weights)
+    em = st.forward(z, pos)
+    g = st.backward()
+    e, f = oracle.energy_forces(z, pos)
+    rmsd = float(weights["normalizer.rmsd"][0])
+    e_st = float(em) * rmsd + float(np.asarray(weights["element_refs"], np.float64)[z].sum())
+    assert abs(e_st - e) < 1e-9
+    assert np.abs(-g.numpy() * rmsd - f).max() < 1e-11
+    assert st.t["tau"][:, 1].abs().max() < 1e-12          # no torque about the edge axis (gauge)
+
+
+def test_edge_frames_are_rotations():
+    from oracle.escn_md_oracle import edge_rotation, wigner_m_primary
+
+    g = torch.Generator().manual_seed(2)
+    n = torch.randn(200, 3, dtype=torch.float64, generator=g)
+    n[0] = torch.tensor([0.0, -1.0, 0.0])                  # south pole: flipped branch
+    n[1] = torch.tensor([0.0, 1.0, 0.0])
+    n[2] = torch.tensor([1e-9, -1.0, 1e-9])
+    n = n / n.norm(dim=1, keepdim=True)
+    r = edge_rotation(n)
+    assert torch.allclose(r @ r.transpose(1, 2), torch.eye(3, dtype=torch.float64).expand(200, 3, 3), atol=1e-12)
+    assert torch.allclose(torch.linalg.det(r), torch.ones(200, dtype=torch.float64), atol=1e-12)
+    y = torch.tensor([0.0, 1.0, 0.0], dtype=torch.float64)
+    assert torch.allclose(torch.einsum("eij,ej->ei", r, n), y.expand(200, 3), atol=1e-12)
+    w = wigner_m_primary(r)
+    assert torch.allclose(w @ w.transpose(1, 2), torch.eye(9, dtype=torch.float64).expand(200, 9, 9), atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["small_n20_k3", "small_n20_charged"])
+def test_oracle_reproduces_golden(oracle, name):
+    """Committed fixtures are regenerated bit-for-bit-close by the oracle (weights RNG, model code unchanged)."""
+    g = load_golden(name)
+    for k in range(len(g["pos"])):
+        e, f = oracle.energy_forces(g["z"], g["pos"][k].astype(np.float64), charge=int(g["charge"]), spin=int(g["spin"]),
+                                    task=str(g["task"]))
+        assert abs(e - g["energy"][k]) < 1e-9
+        assert np.abs(f - g["forces"][k]).max() < 1e-10
+
+
+def test_oracle_c1_golden_first_image(oracle):
+    g = load_golden("c1_n50_k8")
+    e, f = oracle.energy_forces(g["z"], g["pos"][0].astype(np.float64))
+    assert abs(e - g["energy"][0]) < 1e-9
+    assert np.abs(f - g["forces"][0]).max() < 1e-10

@@ -1,0 +1,75 @@
+"""world_size-2 gloo test of the image-sharded evaluator (the N>1 path of bench.py), CPU only."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pdb2reaction_amd.parallel import ShardedImageEvaluator, shard_bounds
+
+
+def toy(c):
+    k = c.shape[0]
+    x = c.reshape(k, -1)
+    return 0.5 * (x ** 2).sum(1) + x[:, 0], -(x + torch.nn.functional.one_hot(torch.zeros(k, dtype=torch.long), x.shape[1])).reshape(c.shape)
+
+
+def test_shard_bounds_cover_everything():
+    for k in (1, 5, 8, 16, 24):
+        for w in (1, 2, 3, 8):
+            cuts = [shard_bounds(k, w, r) for r in range(w)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == k
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in cuts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, k, n, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(0)
+        coords = torch.randn(k, n, 3, dtype=torch.float64, generator=g)
+        calls = []
+
+        def local(c):
+            calls.append(c.shape[0])
+            return toy(c)
+
+        ev = ShardedImageEvaluator(local, k, n, torch.device("cpu"))
+        e, f = ev(coords)
+        e2, f2 = ev(coords + 1.0)
+        out[rank] = (e.numpy(), f.numpy(), e2.numpy(), calls)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k", [5, 16])
+def test_sharded_equals_single_process(k):
+    n, world = 7, 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, k, n, out), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(0)
+    coords = torch.randn(k, n, 3, dtype=torch.float64, generator=g)
+    e_ref, f_ref = toy(coords)
+    for r in range(world):
+        e, f, e2, calls = out[r]
+        assert np.array_equal(e, e_ref.numpy()) and np.array_equal(f, f_ref.numpy())       # bit-for-bit per image
+        assert np.array_equal(e2, toy(coords + 1.0)[0].numpy())
+        lo, hi = shard_bounds(k, world, r)
+        assert calls == [hi - lo, hi - lo]                                               # each rank evaluated only its shard
+
+
+def test_single_process_path():
+    ev = ShardedImageEvaluator(toy, 3, 4, torch.device("cpu"))
+    c = torch.arange(36, dtype=torch.float64).reshape(3, 4, 3)
+    e, f = ev(c)
+    assert torch.equal(e, toy(c)[0]) and torch.equal(f, toy(c)[1])

@@ -39,12 +39,24 @@ FLOP_PER_EDGE = 30.98e6          # algorithmic E+F work per directed edge (SURVE
 PEAK_FP32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense f32 matrix peak
 
 
+def usable_cores() -> int:
+    """Host cores this process may actually use (affinity and cgroup quota, not the machine total)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("UMX_CPU_BASELINE_THREADS", "16"))))
+
+
 def cpu_baseline(n_atoms_sample: int, edges_per_iter: float):
     """Time the CPU oracle (float32, all host threads) on ONE image of `n_atoms_sample` atoms and scale
     by directed edges to the benchmark's string iteration."""
     from oracle.escn_md_oracle import Oracle, radius_graph
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     w = W.make_synthetic_weights(0)
     orc = Oracle(w, dtype=torch.float32)
@@ -69,7 +81,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--atoms", type=int, default=2000)
     ap.add_argument("--images", type=int, default=16)
-    ap.add_argument("--cpu-sample-atoms", type=int, default=300)
+    ap.add_argument("--cpu-sample-atoms", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -170,7 +182,7 @@ def main():
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_sample_atoms, edges_iter)
             except Exception as exc:  # the baseline is informative; never lose the GPU numbers to it
-                out["cpu_baseline"] = {"value": None, "unit": "iterations/s", "cores": os.cpu_count(), "kind": "port",
+                out["cpu_baseline"] = {"value": None, "unit": "iterations/s", "cores": usable_cores(), "kind": "port",
                                        "sample": f"failed: {type(exc).__name__}: {exc}"}
         print(json.dumps(out), flush=True)
     if world > 1:

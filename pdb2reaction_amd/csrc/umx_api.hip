@@ -77,7 +77,7 @@ struct umx_engine {
   int* d_deg_all = nullptr; long deg_all_cap = 0;
   int* d_img_edges = nullptr; long img_edges_cap = 0;
   // host io staging for the host-pointer entry point
-  float* d_io_pos = nullptr; double* d_io_e = nullptr; float* d_io_f = nullptr; long io_cap = 0;
+  float* d_io_pos = nullptr; double* d_io_e = nullptr; float* d_io_f = nullptr; long io_cap = 0, io_img_cap = 0;
   // stats / profiling / debug
   int64_t last_edges = 0; int32_t last_maxdeg = 0;
   bool prof_on = false;
@@ -785,12 +785,19 @@ int umx_energy_forces(umx_engine* eng, int n_images, const float* pos, double* e
   const long nt = (long)n_images * eng->natoms;
   if (eng->io_cap < nt) {
     HIPCHK(eng, hipStreamSynchronize(eng->stream));
-    for (void* p : {(void*)eng->d_io_pos, (void*)eng->d_io_e, (void*)eng->d_io_f}) if (p) HIPCHK(eng, hipFree(p));
-    eng->d_io_pos = nullptr; eng->d_io_e = nullptr; eng->d_io_f = nullptr;
+    if (eng->d_io_pos) HIPCHK(eng, hipFree(eng->d_io_pos));
+    if (eng->d_io_f) HIPCHK(eng, hipFree(eng->d_io_f));
+    eng->d_io_pos = nullptr; eng->d_io_f = nullptr; eng->io_cap = 0;
     HIPCHK(eng, hipMalloc(&eng->d_io_pos, nt * 3 * sizeof(float)));
     HIPCHK(eng, hipMalloc(&eng->d_io_f, nt * 3 * sizeof(float)));
-    HIPCHK(eng, hipMalloc(&eng->d_io_e, (size_t)n_images * sizeof(double)));
     eng->io_cap = nt;
+  }
+  if (eng->io_img_cap < n_images) {
+    HIPCHK(eng, hipStreamSynchronize(eng->stream));
+    if (eng->d_io_e) HIPCHK(eng, hipFree(eng->d_io_e));
+    eng->d_io_e = nullptr; eng->io_img_cap = 0;
+    HIPCHK(eng, hipMalloc(&eng->d_io_e, (size_t)n_images * sizeof(double)));
+    eng->io_img_cap = n_images;
   }
   HIPCHK(eng, hipMemcpyAsync(eng->d_io_pos, pos, nt * 3 * sizeof(float), hipMemcpyHostToDevice, eng->stream));
   CHK(umx_energy_forces_dev(eng, n_images, eng->d_io_pos, eng->d_io_e, forces ? eng->d_io_f : nullptr, nullptr));

@@ -176,6 +176,21 @@ def c3(engine):
     return z, imgs, e, f
 
 
+def pole_atoms(pos, cutoff=W.CUTOFF, tol=2e-5):
+    """Atoms on an edge whose direction is within the reference's isclose(nhat_y, 1) pole mask (rtol 1e-5):
+    fairchem detaches the frame gradient there, so forces on those atoms are not rotation covariant."""
+    p = np.asarray(pos, dtype=np.float64)
+    bad = np.zeros(len(p), dtype=bool)
+    for s0 in range(0, len(p), 500):
+        d = p[None, :, :] - p[s0:s0 + 500, None, :]
+        r = np.linalg.norm(d, axis=-1)
+        m = (r > 0) & (r <= cutoff + 1e-3) & (np.abs(d[..., 1] / np.maximum(r, 1e-30) - 1.0) <= tol)
+        i, j = np.nonzero(m)
+        bad[i + s0] = True
+        bad[j] = True
+    return bad
+
+
 def test_c3_newton_third_law(c3):
     _, _, e, f = c3
     assert np.isfinite(e).all() and np.isfinite(f).all()
@@ -187,9 +202,14 @@ def test_c3_rotation_translation_invariance(engine, c3):
 
     z, imgs, e, f = c3
     rm = Rotation.random(random_state=3).as_matrix()
-    e2, f2 = engine.energy_forces(imgs @ rm.T + np.array([1.0, -2.0, 0.5]))
+    rot = imgs @ rm.T + np.array([1.0, -2.0, 0.5])
+    e2, f2 = engine.energy_forces(rot)
     assert np.abs(e2 - e).max() <= 2e-3                                   # fp32 round-off of rotated float32 inputs
-    assert np.abs(f2 - f @ rm.T.astype(np.float32)).max() <= TOL_F
+    diff = np.abs(f2 - f @ rm.T.astype(np.float32)).max(axis=2)
+    for k in range(len(imgs)):
+        ok = ~(pole_atoms(imgs[k]) | pole_atoms(rot[k]))
+        assert ok.sum() >= len(z) - 40
+        assert diff[k][ok].max() <= TOL_F
 
 
 def test_c3_permutation_invariance(engine, c3):
@@ -199,7 +219,7 @@ def test_c3_permutation_invariance(engine, c3):
     e2, f2 = engine.energy_forces(imgs[:, perm])
     engine.set_system(z)
     assert np.abs(e2 - e).max() <= 1e-3
-    assert np.abs(f2 - f[:, perm]).max() <= TOL_F
+    assert np.abs(f2 - f[:, perm]).max() <= TOL_F                          # same frames, different summation order
 
 
 def test_c3_forces_are_energy_gradient(engine, c3):

@@ -19,6 +19,7 @@
 #include "../../include/umx.h"
 #include "umx_common.h"
 #include "umx_gemm.h"
+#include "umx_gemm_bf16.h"
 #include "umx_kernels.h"
 
 using namespace umx;
@@ -53,6 +54,9 @@ struct umx_engine {
   bool have_weights = false;
   float* d_w = nullptr;          // raw blob data section
   float* d_dw = nullptr;         // derived weights
+  unsigned short* d_bw = nullptr; // bf16 planes of the large SO(2)/radial weights (3 planes each)
+  std::map<const float*, std::pair<const unsigned short*, long>> planes;   // fp32 weight ptr -> (planes, plane stride)
+  int prec_fwd = 0, prec_bwd = 0, cur_prec = 0;   // 0 = fp32 MFMA, 3 = bf16x6, 2 = bf16x3 (UMX_PRECISION)
   std::map<std::string, Tensor> wt;
   std::vector<float> h_w;        // host copy of the data section (needed to build derived weights)
   RadialW rdeg{};
@@ -68,6 +72,8 @@ struct umx_engine {
   int max_neigh = 300;
   int* d_z = nullptr;
   float* d_sysemb = nullptr;
+  float* d_gmu = nullptr;        // gaussian centres mu_k = k * cutoff/63, each rounded from double
+  float gcoef = 0.f;
   double refsum = 0.0;
   // workspace
   size_t ws_limit = 0;
@@ -123,6 +129,26 @@ int launch_gemm(umx_engine* eng, const GemmP& p, int amode, int cplx, int epi, i
     pr->flops = cplx ? 8.0 * p.M * (double)p.N * p.K : 2.0 * p.M * (double)p.N * p.K * gz;
     HIPCHK(eng, hipEventRecord(pr->a, eng->stream));
   }
+  GemmP q = p;
+  int prec = 0;
+  if (eng->cur_prec > 0 && epi == E_BIAS && gz == 1 && (amode == A_PLAIN || amode == A_MODUL)) {
+    auto it = eng->planes.find(p.B);
+    if (it != eng->planes.end()) { prec = eng->cur_prec; q.Bpl = it->second.first; q.bplane = it->second.second; }
+  }
+  if (prec > 0) {
+    const int key = amode * 100 + cplx * 10 + prec;
+    switch (key) {
+      case A_PLAIN * 100 + 0 + 3: hipLaunchKernelGGL((umx_gemm_bf16_kernel<A_PLAIN, 0, 3>), grid, block, 0, eng->stream, q); break;
+      case A_PLAIN * 100 + 10 + 3: hipLaunchKernelGGL((umx_gemm_bf16_kernel<A_PLAIN, 1, 3>), grid, block, 0, eng->stream, q); break;
+      case A_MODUL * 100 + 0 + 3: hipLaunchKernelGGL((umx_gemm_bf16_kernel<A_MODUL, 0, 3>), grid, block, 0, eng->stream, q); break;
+      case A_MODUL * 100 + 10 + 3: hipLaunchKernelGGL((umx_gemm_bf16_kernel<A_MODUL, 1, 3>), grid, block, 0, eng->stream, q); break;
+      case A_PLAIN * 100 + 0 + 2: hipLaunchKernelGGL((umx_gemm_bf16_kernel<A_PLAIN, 0, 2>), grid, block, 0, eng->stream, q); break;
+      case A_PLAIN * 100 + 10 + 2: hipLaunchKernelGGL((umx_gemm_bf16_kernel<A_PLAIN, 1, 2>), grid, block, 0, eng->stream, q); break;
+      case A_MODUL * 100 + 0 + 2: hipLaunchKernelGGL((umx_gemm_bf16_kernel<A_MODUL, 0, 2>), grid, block, 0, eng->stream, q); break;
+      case A_MODUL * 100 + 10 + 2: hipLaunchKernelGGL((umx_gemm_bf16_kernel<A_MODUL, 1, 2>), grid, block, 0, eng->stream, q); break;
+      default: return fail(eng, UMX_ERR_ARG, "gemm: split-bf16 variant not instantiated");
+    }
+  } else {
   const int key = amode * 100 + cplx * 10 + epi;
   switch (key) {
     case A_PLAIN * 100 + 0 + E_BIAS: hipLaunchKernelGGL((umx_gemm_kernel<A_PLAIN, 0, E_BIAS>), grid, block, 0, eng->stream, p); break;
@@ -132,6 +158,7 @@ int launch_gemm(umx_engine* eng, const GemmP& p, int amode, int cplx, int epi, i
     case A_GAUSS * 100 + 0 + E_TABLES: hipLaunchKernelGGL((umx_gemm_kernel<A_GAUSS, 0, E_TABLES>), grid, block, 0, eng->stream, p); break;
     case A_SILU * 100 + 0 + E_BIAS: hipLaunchKernelGGL((umx_gemm_kernel<A_SILU, 0, E_BIAS>), grid, block, 0, eng->stream, p); break;
     default: return fail(eng, UMX_ERR_ARG, "gemm: variant not instantiated");
+  }
   }
   HIPCHK(eng, hipGetLastError());
   if (pr) HIPCHK(eng, hipEventRecord(pr->b, eng->stream));
@@ -231,10 +258,8 @@ int dbg_capture(umx_engine* eng, const std::string& name, const void* dptr, size
 // ---- radial MLP forward / backward -------------------------------------------------------------
 int radial_fwd(umx_engine* eng, const WS& w, const RadialW& r, int slot, long ne, float* rad_out) {
   hipStream_t s = eng->stream;
-  const float gdelta = eng->cutoff / (NG - 1);
-  const float gcoef = -0.5f / ((2.0f * gdelta) * (2.0f * gdelta));
   GemmP p = gp_zero();
-  p.evec = w.evec; p.gcoef = gcoef; p.gdelta = gdelta; p.B = r.w1g; p.ldb = NG; p.Cp = w.h1pre[slot]; p.ldc = RH;
+  p.evec = w.evec; p.gcoef = eng->gcoef; p.gmu = eng->d_gmu; p.B = r.w1g; p.ldb = NG; p.Cp = w.h1pre[slot]; p.ldc = RH;
   p.TS = r.ts; p.TT = r.tt; p.esrc = w.esrc; p.edst = w.edst; p.znode = eng->d_z; p.natoms = eng->natoms;
   p.M = (int)ne; p.N = RH; p.K = NG;
   CHK(launch_gemm(eng, p, A_GAUSS, 0, E_TABLES));
@@ -248,14 +273,12 @@ int radial_fwd(umx_engine* eng, const WS& w, const RadialW& r, int slot, long ne
 
 int radial_bwd(umx_engine* eng, const WS& w, const RadialW& r, int slot, long ne, const float* grad) {
   hipStream_t s = eng->stream;
-  const float gdelta = eng->cutoff / (NG - 1);
-  const float gcoef = -0.5f / ((2.0f * gdelta) * (2.0f * gdelta));
   CHK(gemm_plain(eng, grad, r.out, 0, r.w3T, r.out, nullptr, w.e128a, RH, 0, ne, RH, r.out));
   hipLaunchKernelGGL(k_ln_silu_bwd, dim3(nblk(ne, 4)), dim3(256), 0, s, w.e128a, w.h2pre[slot], r.ln2w, r.ln2b, w.e128b, ne);
   CHK(gemm_plain(eng, w.e128b, RH, 0, r.w2T, RH, nullptr, w.e128a, RH, 0, ne, RH, RH));
   hipLaunchKernelGGL(k_ln_silu_bwd, dim3(nblk(ne, 4)), dim3(256), 0, s, w.e128a, w.h1pre[slot], r.ln1w, r.ln1b, w.e128b, ne);
   CHK(gemm_plain(eng, w.e128b, RH, 0, r.w1gT, RH, nullptr, w.ggauss, NG, 0, ne, NG, RH));
-  hipLaunchKernelGGL(k_radial_dd, dim3(nblk(ne, 4)), dim3(256), 0, s, w.ggauss, w.evec, gcoef, gdelta, w.dedd, ne);
+  hipLaunchKernelGGL(k_radial_dd, dim3(nblk(ne, 4)), dim3(256), 0, s, w.ggauss, w.evec, eng->gcoef, eng->d_gmu, w.dedd, ne);
   HIPCHK(eng, hipGetLastError());
   return UMX_OK;
 }
@@ -275,6 +298,7 @@ int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, long
   const long nn = nimg * N;
   const float rc2 = eng->cutoff * eng->cutoff;
   const dim3 B256(256);
+  eng->cur_prec = eng->prec_fwd;
   // K1 graph
   hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, d_deg, nn, w.row_ptr, w.stats);
   hipLaunchKernelGGL(k_graph_fill, dim3(nblk(nn, 4)), B256, 0, s, d_pos, N, nn, rc2, w.row_ptr, w.esrc, w.edst, w.evec);
@@ -342,6 +366,7 @@ int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, long
   if (!d_forces) return UMX_OK;
 
   // ---------------- K10: analytic reverse pass ----------------
+  eng->cur_prec = eng->prec_bwd;
   if (ne > 0) {
     HIPCHK(eng, hipMemsetAsync(w.dedd, 0, ne * sizeof(float), s));
     HIPCHK(eng, hipMemsetAsync(w.tau, 0, ne * 4 * sizeof(float), s));
@@ -463,7 +488,7 @@ int umx_destroy(umx_engine* eng) {
   (void)hipSetDevice(eng->dev);
   (void)hipStreamSynchronize(eng->stream);
   for (auto& r : eng->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-  void* ptrs[] = {eng->d_w, eng->d_dw, eng->d_z, eng->d_sysemb, eng->arena, eng->d_deg_all, eng->d_img_edges, eng->d_io_pos, eng->d_io_e, eng->d_io_f};
+  void* ptrs[] = {eng->d_w, eng->d_dw, eng->d_bw, eng->d_gmu, eng->d_z, eng->d_sysemb, eng->arena, eng->d_deg_all, eng->d_img_edges, eng->d_io_pos, eng->d_io_e, eng->d_io_f};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   (void)hipStreamDestroy(eng->stream);
   delete eng;
@@ -615,6 +640,52 @@ int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes) {
   HIPCHK(eng, hipMemcpy(eng->d_dw, dw.data(), dw.size() * sizeof(float), hipMemcpyHostToDevice));
   auto W = [&](const std::string& nm) -> const float* { return eng->d_w + eng->wt[nm].off; };
   auto D = [&](size_t o) -> const float* { return eng->d_dw + o; };
+  // ---- bf16 planes (x = x0 + x1 + x2, round-to-nearest-even, exact residuals) of the large weights ----
+  std::vector<unsigned short> bw;
+  struct PlaneReq { const float* host; const float* dev; size_t count; size_t off; };
+  std::vector<PlaneReq> preq;
+  auto want_planes = [&](const float* host, const float* dev, size_t count) {
+    PlaneReq r{host, dev, count, (bw.size() + 63) & ~size_t(63)};
+    bw.resize(r.off + 3 * count);
+    for (size_t i = 0; i < count; ++i) {
+      float x = host[i];
+      for (int q = 0; q < 3; ++q) {
+        uint32_t u; std::memcpy(&u, &x, 4);
+        const uint32_t rr = u + 0x7FFFu + ((u >> 16) & 1u);
+        const unsigned short hb = (unsigned short)(rr >> 16);
+        bw[r.off + q * count + i] = hb;
+        const uint32_t back = (uint32_t)hb << 16; float fb; std::memcpy(&fb, &back, 4);
+        x -= fb;
+      }
+    }
+    preq.push_back(r);
+  };
+  const float* hd = dw.data();
+  for (int i = 0; i < NL; ++i) {
+    const std::string bpre = "blocks." + std::to_string(i);
+    const std::string c1 = bpre + ".edge_wise.so2_conv_1", c2 = bpre + ".edge_wise.so2_conv_2";
+    auto WH = [&](const std::string& nm, size_t cnt) { want_planes(hw + eng->wt[nm].off, W(nm), cnt); };
+    WH(c1 + ".fc_m0.weight", 640 * 768); WH(c1 + ".so2_m_conv.0.fc.weight", 512 * 512); WH(c1 + ".so2_m_conv.1.fc.weight", 256 * 256);
+    WH(c2 + ".fc_m0.weight", 384 * 384); WH(c2 + ".so2_m_conv.0.fc.weight", 512 * 256); WH(c2 + ".so2_m_conv.1.fc.weight", 256 * 128);
+    WH(c1 + ".rad_func.fc3.weight", (size_t)RAD * RH);
+    want_planes(hd + loff[i].c1m0T, D(loff[i].c1m0T), 768 * 640); want_planes(hd + loff[i].c1m1T, D(loff[i].c1m1T), 512 * 512);
+    want_planes(hd + loff[i].c1m2T, D(loff[i].c1m2T), 256 * 256); want_planes(hd + loff[i].c2m0T, D(loff[i].c2m0T), 384 * 384);
+    want_planes(hd + loff[i].c2m1T, D(loff[i].c2m1T), 512 * 256); want_planes(hd + loff[i].c2m2T, D(loff[i].c2m2T), 256 * 128);
+    want_planes(hd + roff[c1 + ".rad_func"].w3T, D(roff[c1 + ".rad_func"].w3T), (size_t)RH * RAD);
+  }
+  if (eng->d_bw) { HIPCHK(eng, hipFree(eng->d_bw)); eng->d_bw = nullptr; }
+  HIPCHK(eng, hipMalloc(&eng->d_bw, bw.size() * sizeof(unsigned short)));
+  HIPCHK(eng, hipMemcpy(eng->d_bw, bw.data(), bw.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  eng->planes.clear();
+  for (const auto& r : preq) eng->planes[r.dev] = {eng->d_bw + r.off, (long)r.count};
+  {
+    const char* pv = std::getenv("UMX_PRECISION");
+    const std::string mode = pv ? pv : "split";
+    if (mode == "fp32") { eng->prec_fwd = 0; eng->prec_bwd = 0; }
+    else if (mode == "bf16x6") { eng->prec_fwd = 3; eng->prec_bwd = 3; }
+    else if (mode == "split") { eng->prec_fwd = 3; eng->prec_bwd = 2; }
+    else return fail(eng, UMX_ERR_ARG, "UMX_PRECISION must be fp32, bf16x6 or split");
+  }
   auto fill_rad = [&](RadialW& r, const std::string& pre, int out) {
     const RadOff& o = roff[pre];
     r.w1g = D(o.w1g); r.w1gT = D(o.w1gT); r.ts = D(o.ts); r.tt = D(o.tt); r.w2T = D(o.w2T); r.w3T = D(o.w3T);
@@ -671,15 +742,37 @@ int umx_set_system(umx_engine* eng, int n_atoms, const int32_t* z, int charge, i
   HIPCHK(eng, hipMalloc(&eng->d_z, n_atoms * sizeof(int)));
   HIPCHK(eng, hipMemcpy(eng->d_z, z, n_atoms * sizeof(int), hipMemcpyHostToDevice));
   if (!eng->d_sysemb) HIPCHK(eng, hipMalloc(&eng->d_sysemb, C * sizeof(float)));
-  auto W = [&](const std::string& nm) -> const float* { return eng->d_w + eng->wt[nm].off; };
-  hipLaunchKernelGGL(k_sys_emb, dim3(1), dim3(C), 0, eng->stream, W("charge_embedding.weight") + (long)(charge + 100) * C,
-                     W("spin_embedding.weight") + (long)spin * C, W("dataset_embedding.weight") + (long)task_index * C,
-                     W("mix_csd.weight"), W("mix_csd.bias"), eng->d_sysemb);
-  HIPCHK(eng, hipGetLastError());
-  HIPCHK(eng, hipStreamSynchronize(eng->stream));
+  {
+    // system embedding silu(mix_csd [chg | spin | dataset]) in double on the host (setup, once per system): it is
+    // added to EVERY atom in every layer, so any error in it is a same-sign energy bias that grows with N.
+    const float* hw = eng->h_w.data();
+    auto HW = [&](const std::string& nm) -> const float* { return hw + eng->wt[nm].off; };
+    const float* chg = HW("charge_embedding.weight") + (size_t)(charge + 100) * C;
+    const float* spn = HW("spin_embedding.weight") + (size_t)spin * C;
+    const float* dst = HW("dataset_embedding.weight") + (size_t)task_index * C;
+    const float* mw = HW("mix_csd.weight");
+    const float* mb = HW("mix_csd.bias");
+    float se[C];
+    for (int o = 0; o < C; ++o) {
+      double acc = mb[o];
+      for (int k = 0; k < C; ++k)
+        acc += (double)mw[(size_t)o * 3 * C + k] * chg[k] + (double)mw[(size_t)o * 3 * C + C + k] * spn[k] +
+               (double)mw[(size_t)o * 3 * C + 2 * C + k] * dst[k];
+      se[o] = (float)(acc / (1.0 + std::exp(-acc)));
+    }
+    HIPCHK(eng, hipMemcpy(eng->d_sysemb, se, sizeof(se), hipMemcpyHostToDevice));
+  }
   eng->natoms = n_atoms;
   eng->refsum = rs;
   eng->cutoff = radius > 0.f ? radius : 6.0f;
+  {
+    const double delta = (double)eng->cutoff / (NG - 1);
+    float mu[NG];
+    for (int k = 0; k < NG; ++k) mu[k] = (float)(k * delta);
+    eng->gcoef = (float)(-0.5 / ((2.0 * delta) * (2.0 * delta)));
+    if (!eng->d_gmu) HIPCHK(eng, hipMalloc(&eng->d_gmu, NG * sizeof(float)));
+    HIPCHK(eng, hipMemcpy(eng->d_gmu, mu, sizeof(mu), hipMemcpyHostToDevice));
+  }
   eng->max_neigh = max_neigh > 0 ? max_neigh : 300;
   eng->have_system = true;
   return UMX_OK;

@@ -23,10 +23,16 @@ constexpr float LN_EPS = 1e-5f;
 constexpr float DEG_RESCALE = 5.0f;
 constexpr float SQRT3 = 1.7320508075688772f;
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// Accurate (<= 1 ulp, unbiased) transcendentals on purpose: every atom shares the same weights, so the
+// deterministic error of the fast v_exp/v_rsq approximations does not average out over atoms -- it showed up
+// as a same-sign per-atom energy bias of ~1e-7 eV that grows linearly with N.  These ops live in HBM-bound
+// kernels (and in GEMM prologues with ample VALU slack), so the extra instructions are free.
+__device__ __forceinline__ float exp_f(float x) { return expf(x); }
+__device__ __forceinline__ float rsqrt_f(float x) { return 1.0f / sqrtf(x); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float silu_grad_f(float x) {
-  const float s = 1.0f / (1.0f + __expf(-x));
+  const float s = 1.0f / (1.0f + expf(-x));
   return s * (1.0f + x * (1.0f - s));
 }
 

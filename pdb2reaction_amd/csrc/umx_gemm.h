@@ -32,9 +32,10 @@ struct GemmP {
   // A operand: row r at A + r*lda + offA{0,1} (+ blockIdx.z * zA); offA1 = imaginary rows (CPLX)
   const float* A; long lda; int offA0, offA1;
   const float* R; long ldr; int offR;            // A_MODUL: A .* R
-  const float* evec; float gcoef, gdelta;        // A_GAUSS: exp(gcoef (d - k*gdelta)^2), d = evec[4r+3]
+  const float* evec; float gcoef; const float* gmu;   // A_GAUSS: exp(gcoef (d - mu_k)^2), d = evec[4r+3], mu = 64-entry table
   // B operand: weights [rows][ldb]; CPLX row of kind ab: ab*bHalf + n
   const float* B; long ldb; int bHalf;
+  const unsigned short* Bpl; long bplane;        // split-bf16 kernels: plane q of the weights at Bpl + q*bplane (same [row][ldb] layout)
   // C: row r at C + r*ldc + offC (+ blockIdx.z * zC); offCi = imaginary output (CPLX)
   float* Cp; long ldc; int offC, offCi;
   const float* bias;                             // [N] or null
@@ -50,6 +51,50 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int G_BK = 32;
 constexpr int G_LDK = 36;   // padded LDS row (floats)
+
+// C/D map of 32x32 MFMA tiles (dtype independent on gfx950): col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+template <int CPLX, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[2][2], int mt, int nt, int wm, int wn, int l31, int h) {
+  if (CPLX) {
+    const int chan = nt * 64 + wn * 32 + l31;
+    if (chan < p.N) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long e = (long)mt * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (e < p.M) {
+          const float yr = acc[0][0][r] - p.conj * acc[1][1][r];
+          const float yi = acc[1][0][r] + p.conj * acc[0][1][r];
+          float* c = p.Cp + e * p.ldc + chan;
+          c[p.offC] = yr;
+          c[p.offCi] = yi;
+        }
+      }
+    }
+  } else {
+    const long zoffC = (long)blockIdx.z * p.zC, zoffR = (long)blockIdx.z * p.zRes;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = nt * 128 + wn * 64 + j * 32 + l31;
+        if (col >= p.N) continue;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long row = (long)mt * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < p.M) {
+            float v = acc[i][j][r] + bv;
+            if (EPI == E_TABLES) {
+              const int zs = p.znode[p.esrc[row] % p.natoms], zd = p.znode[p.edst[row] % p.natoms];
+              v += p.TS[zs * RH + col] + p.TT[zd * RH + col];
+            }
+            if (p.resid) v += p.resid[row * p.ldres + p.offRes + zoffR + col];
+            p.Cp[row * p.ldc + p.offC + zoffC + col] = v;
+          }
+        }
+      }
+  }
+}
 
 template <int AMODE, int CPLX, int EPI>
 __global__ __launch_bounds__(256, 2) void umx_gemm_kernel(const GemmP p) {
@@ -84,11 +129,12 @@ __global__ __launch_bounds__(256, 2) void umx_gemm_kernel(const GemmP p) {
       if (grow < p.M) {
         if (AMODE == A_GAUSS) {
           const float d = p.evec[grow * 4 + 3];
+          const float4 mu = *reinterpret_cast<const float4*>(p.gmu + k0);
           float t;
-          t = d - (float)(k0 + 0) * p.gdelta; v.x = __expf(p.gcoef * t * t);
-          t = d - (float)(k0 + 1) * p.gdelta; v.y = __expf(p.gcoef * t * t);
-          t = d - (float)(k0 + 2) * p.gdelta; v.z = __expf(p.gcoef * t * t);
-          t = d - (float)(k0 + 3) * p.gdelta; v.w = __expf(p.gcoef * t * t);
+          t = d - mu.x; v.x = exp_f(p.gcoef * t * t);
+          t = d - mu.y; v.y = exp_f(p.gcoef * t * t);
+          t = d - mu.z; v.z = exp_f(p.gcoef * t * t);
+          t = d - mu.w; v.w = exp_f(p.gcoef * t * t);
         } else {
           v = *reinterpret_cast<const float4*>(p.A + grow * p.lda + offA + zoffA + k0);
           if (AMODE == A_MODUL) {
@@ -158,46 +204,7 @@ __global__ __launch_bounds__(256, 2) void umx_gemm_kernel(const GemmP p) {
     __syncthreads();
   }
 
-  // ---- epilogue: C/D map of 32x32 tiles: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  if (CPLX) {
-    const int chan = nt * 64 + wn * 32 + l31;
-    if (chan < p.N) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long e = (long)mt * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (e < p.M) {
-          const float yr = acc[0][0][r] - p.conj * acc[1][1][r];
-          const float yi = acc[1][0][r] + p.conj * acc[0][1][r];
-          float* c = p.Cp + e * p.ldc + chan;
-          c[p.offC] = yr;
-          c[p.offCi] = yi;
-        }
-      }
-    }
-  } else {
-    const long zoffC = (long)blockIdx.z * p.zC, zoffR = (long)blockIdx.z * p.zRes;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int col = nt * 128 + wn * 64 + j * 32 + l31;
-        if (col >= p.N) continue;
-        const float bv = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const long row = (long)mt * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (row < p.M) {
-            float v = acc[i][j][r] + bv;
-            if (EPI == E_TABLES) {
-              const int zs = p.znode[p.esrc[row] % p.natoms], zd = p.znode[p.edst[row] % p.natoms];
-              v += p.TS[zs * RH + col] + p.TT[zd * RH + col];
-            }
-            if (p.resid) v += p.resid[row * p.ldres + p.offRes + zoffR + col];
-            p.Cp[row * p.ldc + p.offC + zoffC + col] = v;
-          }
-        }
-      }
-  }
+  gemm_epilogue<CPLX, EPI>(p, acc, mt, nt, wm, wn, l31, h);
 }
 
 }  // namespace umx

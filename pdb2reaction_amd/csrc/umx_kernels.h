@@ -158,17 +158,6 @@ __global__ void k_edge_geom(const float* __restrict__ evec, long ne, float cutof
 // ------------------------------------------------------------------------------------------------
 // node-level kernels
 // ------------------------------------------------------------------------------------------------
-// system embedding: silu(mix_csd [chg | spin | dataset])
-__global__ void k_sys_emb(const float* __restrict__ chg, const float* __restrict__ spin, const float* __restrict__ ds,
-                          const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out) {
-  const int o = threadIdx.x;   // 128 threads
-  float acc = b[o];
-  for (int k = 0; k < C; ++k) acc += w[o * 3 * C + k] * chg[k];
-  for (int k = 0; k < C; ++k) acc += w[o * 3 * C + C + k] * spin[k];
-  for (int k = 0; k < C; ++k) acc += w[o * 3 * C + 2 * C + k] * ds[k];
-  out[o] = silu_f(acc);
-}
-
 __global__ void k_node_init(const int* __restrict__ znode, int natoms, long nt, const float* __restrict__ emb,
                             const float* __restrict__ sysemb, float* __restrict__ x) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -195,7 +184,7 @@ __global__ __launch_bounds__(256) void k_norm_fwd(const float* __restrict__ x, c
 #pragma unroll
   for (int r = 4; r < 9; ++r) q += (v[r].x * v[r].x + v[r].y * v[r].y) * (1.0f / 15.0f);
   q = wave_sum(q) * (1.0f / C);
-  const float s = rsqrtf(q + NORM_EPS);
+  const float s = rsqrt_f(q + NORM_EPS);
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
     const int l = (r == 0) ? 0 : (r < 4 ? 1 : 2);
@@ -236,7 +225,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd(const float* __restrict__ gy, 
   }
   q = wave_sum(q) * (1.0f / C);
   dot = wave_sum(dot);
-  const float s = rsqrtf(q + NORM_EPS);
+  const float s = rsqrt_f(q + NORM_EPS);
   const float k = s * s * s * dot * (1.0f / C);
   float2 o[9];
 #pragma unroll
@@ -267,7 +256,7 @@ __global__ __launch_bounds__(256) void k_ln_silu_fwd(const float* __restrict__ x
   const float mu = wave_sum(v.x + v.y) * (1.0f / RH);
   v.x -= mu; v.y -= mu;
   const float var = wave_sum(v.x * v.x + v.y * v.y) * (1.0f / RH);
-  const float rstd = rsqrtf(var + LN_EPS);
+  const float rstd = rsqrt_f(var + LN_EPS);
   const float2 ww = *reinterpret_cast<const float2*>(w + c0), bb = *reinterpret_cast<const float2*>(b + c0);
   *reinterpret_cast<float2*>(y + row * RH + c0) =
       make_float2(silu_f(v.x * rstd * ww.x + bb.x), silu_f(v.y * rstd * ww.y + bb.y));
@@ -283,7 +272,7 @@ __global__ __launch_bounds__(256) void k_ln_silu_bwd(const float* __restrict__ g
   const float mu = wave_sum(v.x + v.y) * (1.0f / RH);
   v.x -= mu; v.y -= mu;
   const float var = wave_sum(v.x * v.x + v.y * v.y) * (1.0f / RH);
-  const float rstd = rsqrtf(var + LN_EPS);
+  const float rstd = rsqrt_f(var + LN_EPS);
   const float2 ww = *reinterpret_cast<const float2*>(w + c0), bb = *reinterpret_cast<const float2*>(b + c0);
   const float xh0 = v.x * rstd, xh1 = v.y * rstd;
   const float gw0 = go.x * silu_grad_f(xh0 * ww.x + bb.x) * ww.x;
@@ -587,11 +576,11 @@ __global__ __launch_bounds__(256) void k_gather_rotate_bwd(const float* __restri
 
 // dE/dd through the gaussian basis: dedd[e] += sum_k ggauss[e][k] * d/dd exp(gcoef (d - mu_k)^2)
 __global__ __launch_bounds__(256) void k_radial_dd(const float* __restrict__ ggauss, const float* __restrict__ evec,
-                                                   float gcoef, float gdelta, float* __restrict__ dedd, long ne) {
+                                                   float gcoef, const float* __restrict__ gmu, float* __restrict__ dedd, long ne) {
   UMX_WAVE_ITEM(e, ne)
   const float d = evec[e * 4 + 3];
-  const float t = d - (float)lane * gdelta;
-  float v = ggauss[e * NG + lane] * __expf(gcoef * t * t) * 2.0f * gcoef * t;
+  const float t = d - gmu[lane];
+  float v = ggauss[e * NG + lane] * exp_f(gcoef * t * t) * 2.0f * gcoef * t;
   v = wave_sum(v);
   if (lane == 0) dedd[e] += v;
 }

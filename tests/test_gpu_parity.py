@@ -56,6 +56,32 @@ def test_golden_fixtures(engine, name):
     assert np.abs(f - g["forces"]).max() <= TOL_F
 
 
+def test_c3_energy_golden(engine):
+    """2000-atom images (BASELINE c3 size) against float64 oracle energies (tools/make_golden_c3.py).
+    Guards the systematic part of the error: anything shared by all atoms (e.g. the system embedding)
+    must be exact, or the bias grows linearly with N (it was -2e-4 eV before sys_emb moved to float64)."""
+    g = load_golden("c3_n2000_energy")
+    engine.set_system(g["z"])
+    e, _ = engine.energy_forces(g["pos"], forces=False)
+    assert np.abs(e - g["energy"]).max() <= TOL_E
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16x6", "split"])
+def test_precision_modes(weights, oracle, mode, monkeypatch):
+    """UMX_PRECISION: fp32-MFMA everywhere, or split-bf16 (6-term forward / 3-term reverse) on the large SO(2)/radial
+    GEMMs -- every mode must hold the north-star tolerances."""
+    from pdb2reaction_amd.engine import Engine
+
+    monkeypatch.setenv("UMX_PRECISION", mode)
+    eng = Engine(0)
+    try:
+        eng.load_weights(weights)
+        z, imgs, _ = synth.make_images(150, 2, seed=13)
+        check(eng, oracle, z, imgs)
+    finally:
+        eng.close()
+
+
 def test_no_edges_and_isolated_atoms(engine, oracle):
     """Empty / ragged graphs: a lone atom, two atoms beyond the cutoff, one isolated atom next to a cluster."""
     z = np.array([8], dtype=np.int32)

@@ -42,7 +42,7 @@ struct LayerW {
   RadialW rad;
 };
 
-struct ProfRec { hipEvent_t a, b; double flops; };
+struct ProfRec { hipEvent_t a, b; double flops; int M, N, K, amode, cplx, prec, gz; };
 
 }  // namespace
 
@@ -127,6 +127,7 @@ int launch_gemm(umx_engine* eng, const GemmP& p, int amode, int cplx, int epi, i
     }
     pr = &eng->prof[eng->prof_used++];
     pr->flops = cplx ? 8.0 * p.M * (double)p.N * p.K : 2.0 * p.M * (double)p.N * p.K * gz;
+    pr->M = p.M; pr->N = p.N; pr->K = p.K; pr->amode = amode; pr->cplx = cplx; pr->gz = gz; pr->prec = 0;
     HIPCHK(eng, hipEventRecord(pr->a, eng->stream));
   }
   GemmP q = p;
@@ -135,6 +136,7 @@ int launch_gemm(umx_engine* eng, const GemmP& p, int amode, int cplx, int epi, i
     auto it = eng->planes.find(p.B);
     if (it != eng->planes.end()) { prec = eng->cur_prec; q.Bpl = it->second.first; q.bplane = it->second.second; }
   }
+  if (pr) pr->prec = prec;
   if (prec > 0) {
     const int key = amode * 100 + cplx * 10 + prec;
     switch (key) {
@@ -918,11 +920,16 @@ int umx_profile_read(umx_engine* eng, double* gemm_ms, int64_t* gemm_launches, d
   HIPCHK(eng, hipSetDevice(eng->dev));
   HIPCHK(eng, hipStreamSynchronize(eng->stream));
   double ms = 0.0, fl = 0.0;
+  FILE* dump = nullptr;
+  if (const char* dp = std::getenv("UMX_PROFILE_DUMP")) dump = std::fopen(dp, "a");
   for (size_t i = 0; i < eng->prof_used; ++i) {
     float t = 0.f;
     HIPCHK(eng, hipEventElapsedTime(&t, eng->prof[i].a, eng->prof[i].b));
     ms += t; fl += eng->prof[i].flops;
+    const ProfRec& r = eng->prof[i];
+    if (dump) std::fprintf(dump, "%d,%d,%d,%d,%d,%d,%d,%.6f,%.6e\n", r.M, r.N, r.K, r.amode, r.cplx, r.prec, r.gz, t, r.flops);
   }
+  if (dump) std::fclose(dump);
   if (gemm_ms) *gemm_ms = ms;
   if (gemm_launches) *gemm_launches = (int64_t)eng->prof_used;
   if (gemm_flops) *gemm_flops = fl;

@@ -52,44 +52,67 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int G_BK = 32;
 constexpr int G_LDK = 36;   // padded LDS row (floats)
 
-// C/D map of 32x32 MFMA tiles (dtype independent on gfx950): col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+// C/D map of 32x32 MFMA tiles (dtype independent on gfx950): col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// Stores are issued as straight-line code on a block-uniform fast path (tile fully inside M x N): a guarded store per
+// element puts every store in its own basic block behind a compiler-inserted s_waitcnt vmcnt(0), and vmcnt counts
+// stores too, so the 64+ stores of a thread would each wait for the previous one's round trip.
 template <int CPLX, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[2][2], int mt, int nt, int wm, int wn, int l31, int h) {
   if (CPLX) {
     const int chan = nt * 64 + wn * 32 + l31;
-    if (chan < p.N) {
+    const long e0 = (long)mt * 64 + wm * 32 + 4 * h;
+    const bool full = ((long)mt * 64 + 64 <= p.M) && (nt * 64 + 64 <= p.N);
+    float* c = p.Cp + e0 * p.ldc + chan;
+    if (full) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const long e = (long)mt * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (e < p.M) {
-          const float yr = acc[0][0][r] - p.conj * acc[1][1][r];
-          const float yi = acc[1][0][r] + p.conj * acc[0][1][r];
-          float* c = p.Cp + e * p.ldc + chan;
-          c[p.offC] = yr;
-          c[p.offCi] = yi;
+        float* cr = c + (long)((r & 3) + 8 * (r >> 2)) * p.ldc;
+        cr[p.offC] = acc[0][0][r] - p.conj * acc[1][1][r];
+        cr[p.offCi] = acc[1][0][r] + p.conj * acc[0][1][r];
+      }
+    } else if (chan < p.N) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        if (e0 + dr < p.M) {
+          float* cr = c + (long)dr * p.ldc;
+          cr[p.offC] = acc[0][0][r] - p.conj * acc[1][1][r];
+          cr[p.offCi] = acc[1][0][r] + p.conj * acc[0][1][r];
         }
       }
     }
   } else {
     const long zoffC = (long)blockIdx.z * p.zC, zoffR = (long)blockIdx.z * p.zRes;
+    const bool full = ((long)mt * 128 + 128 <= p.M) && (nt * 128 + 128 <= p.N);
+    float bv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = nt * 128 + wn * 64 + j * 32 + l31;
+      bv[j] = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int col = nt * 128 + wn * 64 + j * 32 + l31;
-        if (col >= p.N) continue;
-        const float bv = p.bias ? p.bias[col] : 0.f;
+        const long row0 = (long)mt * 128 + wm * 64 + i * 32 + 4 * h;
+        float* c = p.Cp + row0 * p.ldc + p.offC + zoffC + col;
+        if (full && EPI == E_BIAS && !p.resid) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const long row = (long)mt * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (row < p.M) {
-            float v = acc[i][j][r] + bv;
-            if (EPI == E_TABLES) {
-              const int zs = p.znode[p.esrc[row] % p.natoms], zd = p.znode[p.edst[row] % p.natoms];
-              v += p.TS[zs * RH + col] + p.TT[zd * RH + col];
+          for (int r = 0; r < 16; ++r) c[(long)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[i][j][r] + bv[j];
+        } else if (col < p.N) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const long row = row0 + (r & 3) + 8 * (r >> 2);
+            if (row < p.M) {
+              float v = acc[i][j][r] + bv[j];
+              if (EPI == E_TABLES) {
+                const int zs = p.znode[p.esrc[row] % p.natoms], zd = p.znode[p.edst[row] % p.natoms];
+                v += p.TS[zs * RH + col] + p.TT[zd * RH + col];
+              }
+              if (p.resid) v += p.resid[row * p.ldres + p.offRes + zoffR + col];
+              p.Cp[row * p.ldc + p.offC + zoffC + col] = v;
             }
-            if (p.resid) v += p.resid[row * p.ldres + p.offRes + zoffR + col];
-            p.Cp[row * p.ldc + p.offC + zoffC + col] = v;
           }
         }
       }

@@ -38,7 +38,8 @@ __device__ __forceinline__ void split_store(float4 v, __bf16* dst, int plane_str
   }
 }
 
-template <int AMODE, int CPLX, int P>
+// ABL (dev only, tools/gemm_bench.hip): 1 = no fp32->bf16 split (raw truncation), 2 = no global A/R loads, 4 = no MFMA, 8 = no B loads
+template <int AMODE, int CPLX, int P, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void umx_gemm_bf16_kernel(const GemmP p) {
   __shared__ __attribute__((aligned(16))) __bf16 lds[2][P][128][GB_LDK];   // [A|B][plane][row][k]
   constexpr int BMR = CPLX ? 64 : 128;
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void umx_gemm_bf16_kernel(const GemmP p) {
       if (CPLX) { grow = (long)mt * 64 + (trow & 63); offA = (trow >> 6) ? p.offA1 : p.offA0; }
       else      { grow = (long)mt * 128 + trow;       offA = p.offA0; }
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (grow < p.M) {
+      if (grow < p.M && !(ABL & 2)) {
         v = *reinterpret_cast<const float4*>(p.A + grow * p.lda + offA + k0 + k4);
         if (AMODE == A_MODUL) {
           const float4 m = *reinterpret_cast<const float4*>(p.R + grow * p.ldr + p.offR + k0 + k4);
@@ -85,12 +86,17 @@ __global__ __launch_bounds__(256, 2) void umx_gemm_bf16_kernel(const GemmP p) {
       else      { brow = nt * 128 + trow; ok = brow < p.N; }
 #pragma unroll
       for (int q = 0; q < P; ++q)
-        rb[q][r] = ok ? *reinterpret_cast<const uint4*>(p.Bpl + q * p.bplane + (long)brow * p.ldb + k0 + k8) : make_uint4(0u, 0u, 0u, 0u);
+        rb[q][r] = (ok && !(ABL & 8)) ? *reinterpret_cast<const uint4*>(p.Bpl + q * p.bplane + (long)brow * p.ldb + k0 + k8) : make_uint4(0u, 0u, 0u, 0u);
     }
   };
   auto lstore = [&]() {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) split_store<P>(ra[r], &lds[0][0][trow0 + 32 * r][k4], PLANE);
+    for (int r = 0; r < 4; ++r) {
+      if (ABL & 1) {
+#pragma unroll
+        for (int q = 0; q < P; ++q) *reinterpret_cast<uint2*>(&lds[0][q][trow0 + 32 * r][k4]) = make_uint2(__float_as_uint(ra[r].x) + q, __float_as_uint(ra[r].z));
+      } else split_store<P>(ra[r], &lds[0][0][trow0 + 32 * r][k4], PLANE);
+    }
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -138,7 +144,8 @@ __global__ __launch_bounds__(256, 2) void umx_gemm_bf16_kernel(const GemmP p) {
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][qa], b[j][qb], acc[i][j], 0, 0, 0);
+              if (ABL & 4) { acc[i][j][0] += (float)a[i][qa][0] * (float)b[j][qb][0]; }
+              else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][qa], b[j][qb], acc[i][j], 0, 0, 0);
         }
     }
     __syncthreads();

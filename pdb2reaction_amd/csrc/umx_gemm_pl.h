@@ -1,0 +1,241 @@
+// umx_gemm_pl.h -- multi-plane bf16 MFMA GEMM with an asynchronous LDS-DMA ring (gfx950).
+//
+//   C[M x N] (fp32) = sum_{i+j<P} A_i[M x K] . B_j[N x K]^T ,   A_i, B_j bf16 planes in HBM
+//
+// Both operands arrive already split into P bf16 planes (x = x0 + x1 (+ x2), exact): weights once at
+// load time, activations by the HBM-bound producer kernel that writes them (one conversion per element
+// instead of one per N tile).  P = 3 -> 6 MFMAs per product (fp32-equivalent, forward pass),
+// P = 2 -> 3 MFMAs (reverse pass).
+//
+// PLANE-INTERLEAVED ROW LAYOUT ("PL" layout).  A matrix X[rows][K] is stored as rows of K*P bf16:
+//   element (r, k, plane q)  ->  r * (K*P) + (k / 32) * (32*P) + q * 32 + (k % 32)
+// so the P planes of one 32-column block of a row are contiguous (128 B for P=2, 192 B for P=3): one
+// global_load_lds wave-instruction then fetches whole 128-B lines.  (With separate planes and a 16-wide
+// k-step every line was requested four separate times and the fill, not the MFMA, set the pace.)
+//
+// Structure (cdna_hip_programming.md section 5; measured steps in DESIGN.md section 5):
+//  * 256 x (64*WNT) block tile, BK = 32, 4 waves (2x2), ONE block per CU, each wave owns a
+//    128 x (32*WNT) C tile = 4 x WNT v_mfma_f32_32x32x16_bf16 tiles (up to 256 accumulator registers;
+//    the wave has the whole 512-entry register file).
+//  * Operand tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR staging, no VALU): a ring of S
+//    stages, tile kt+S-1 is requested while tile kt is consumed; the only waits are a counted
+//    s_waitcnt vmcnt((S-2)*G) and ONE raw s_barrier per k-step (never __syncthreads(), which would drain
+//    the DMA queue).  All LDS lives in one __shared__ array.
+//  * LDS image = the DMA's flat chunk order (row-major, 4P 16-B slots per row, no padding possible);
+//    bank conflicts are removed by permuting the SOURCE chunk with a per-row XOR and applying the same
+//    involution to fragment reads (conflict-free ds_read_b128).
+//  * Rows past M / N are clamped on the source side (their results are masked in the epilogue).
+//  * CPLX: rows are (re/im, edge), weight rows (A/B half, channel); every wave holds both re/im row
+//    groups and both A/B column groups of its edges x channels and combines them in the accumulators.
+#pragma once
+#include "umx_gemm.h"
+
+namespace umx {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+struct GemmPL {
+  const unsigned short* Apl; long lda; int offA0, offA1;   // PL layout: lda = row pitch in bf16 (= K_total*P); offsets in COLUMNS (multiples of 32)
+  const unsigned short* Bpl; long ldb; int bHalf;          // weights, PL layout (ldb = K*P)
+  float* Cp; long ldc; int offC, offCi;
+  const float* bias;
+  float conj;
+  int M, N, K;       // CPLX: M = edges, N = channels per half
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// per-row slot permutation (an involution): LDS slot s of row r holds source chunk pl_perm(s, r)
+template <int P> __device__ __forceinline__ int pl_perm(int s, int r) {
+  return P == 2 ? (s ^ ((r >> 1) & 7)) : ((s & ~3) | ((s & 3) ^ ((r >> 2) & 3)));
+}
+
+// request one k-tile (32 columns, all planes) of A and B into the ring stage at `sbase`.
+// (A plain __device__ function: a lambda calling the LDS-DMA builtin silently drops the host-side kernel stub, and
+//  hipcc 7.2 rejects a second kernel re-using one specialization of such a function -- hence the TAG parameter.)
+template <int JA, int JB, int TA_B, int TAG>
+__device__ __forceinline__ void pl_issue(const GemmPL& p, unsigned char* sbase, const long (&a_off)[JA], const long (&b_off)[JB], long kofs, int piece) {
+#pragma unroll
+  for (int j = 0; j < JA; ++j)
+    __builtin_amdgcn_global_load_lds(p.Apl + a_off[j] + kofs, (__attribute__((address_space(3))) void*)(sbase + piece + j * 4096), 16, 0, 0);
+#pragma unroll
+  for (int j = 0; j < JB; ++j)
+    __builtin_amdgcn_global_load_lds(p.Bpl + b_off[j] + kofs, (__attribute__((address_space(3))) void*)(sbase + TA_B + piece + j * 4096), 16, 0, 0);
+}
+
+// WNT = MFMA tiles per wave along N (4 -> 256-wide block tile, 2 -> 128-wide).
+// ABL (dev only): 1 = no DMA in the main loop, 2 = no MFMA, 4 = no C stores, 8 = no LDS fragment reads
+template <int CPLX, int P, int S, int WNT, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void umx_gemm_pl_kernel(const GemmPL p) {
+  constexpr int BN = 64 * WNT;                 // block tile columns (B rows)
+  constexpr int SEG = 4 * P;                   // 16-B chunks per row per k-tile
+  constexpr int ROWB = SEG * 16;               // bytes per row per k-tile (128 or 192)
+  constexpr int TA_B = 256 * ROWB;
+  constexpr int TB_B = BN * ROWB;
+  constexpr int STAGE_B = TA_B + TB_B;
+  static_assert(S * STAGE_B <= 160 * 1024, "ring does not fit the 160 KiB LDS");
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[S * STAGE_B];
+  constexpr int BMR = CPLX ? 128 : 256;        // logical rows (edges) per block
+  constexpr int BNC = CPLX ? BN / 2 : BN;      // logical cols (channels) per block
+  constexpr int JA = SEG;                      // A chunks per lane per k-tile (256 rows * SEG / 256 lanes)
+  constexpr int JB = BN * SEG / 256;
+  constexpr int G = JA + JB;                   // global_load_lds instructions per wave per k-tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const int nN = (p.N + BNC - 1) / BNC;
+  const int nM = (p.M + BMR - 1) / BMR;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int mt = (slot / nN) * 8 + xcd, nt = slot % nN;
+  if (mt >= nM) return;
+
+  // ---- per-lane source offsets (bf16 elements): flat chunk id c = tid + 256 j -> row = c / SEG, LDS slot = c % SEG
+  long a_off[JA], b_off[JB];
+#pragma unroll
+  for (int j = 0; j < JA; ++j) {
+    const int c = tid + 256 * j, trow = c / SEG, s = c % SEG;
+    long grow; int offA;
+    if (CPLX) { grow = (long)mt * 128 + (trow & 127); offA = (trow >> 7) ? p.offA1 : p.offA0; }
+    else      { grow = (long)mt * 256 + trow;         offA = p.offA0; }
+    if (grow >= p.M) grow = p.M - 1;
+    a_off[j] = grow * p.lda + (long)offA * P + pl_perm<P>(s, trow) * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < JB; ++j) {
+    const int c = tid + 256 * j, trow = c / SEG, s = c % SEG;
+    int brow;
+    if (CPLX) { int cc = nt * BNC + (trow % BNC); if (cc >= p.N) cc = p.N - 1; brow = (trow / BNC) * p.bHalf + cc; }
+    else      { brow = nt * BN + trow; if (brow >= p.N) brow = p.N - 1; }
+    b_off[j] = (long)brow * p.ldb + pl_perm<P>(s, trow) * 8;
+  }
+  const int piece = __builtin_amdgcn_readfirstlane(wave * 1024);   // this wave's 1-KiB piece inside a 4-KiB group
+
+  f32x16 acc[4][WNT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment rows inside the tile
+  int a_row[4], b_row[WNT];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) a_row[t] = CPLX ? ((t >> 1) * 128 + wm * 64 + (t & 1) * 32 + l31) : (wm * 128 + t * 32 + l31);
+#pragma unroll
+  for (int t = 0; t < WNT; ++t)
+    b_row[t] = CPLX ? ((t / (WNT / 2)) * BNC + wn * (BNC / 2) + (t % (WNT / 2)) * 32 + l31) : (wn * (BN / 2) + t * 32 + l31);
+
+  const int nk = p.K / 32;
+  constexpr int TAG = ABL * 10000 + CPLX * 1000 + P * 100 + S * 10 + WNT;
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s)
+    if (s < nk) pl_issue<JA, JB, TA_B, TAG>(p, ring + s * STAGE_B, a_off, b_off, (long)s * 32 * P, piece);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + S - 2 < nk) wait_vmcnt<(S - 2) * G>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // everyone's tile kt landed; everyone finished reading tile kt-1
+    if (kt + S - 1 < nk && !(ABL & 1))
+      pl_issue<JA, JB, TA_B, TAG>(p, ring + ((kt + S - 1) % S) * STAGE_B, a_off, b_off, (long)(kt + S - 1) * 32 * P, piece);
+    const unsigned char* sbase = ring + (kt % S) * STAGE_B;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t a[4][P], b[WNT][P];
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        const int u = q * 4 + ks * 2 + h;      // source chunk wanted: plane q, k-chunk 2 ks + h
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (ABL & 8) { for (int z = 0; z < 8; ++z) a[t][q][z] = (__bf16)(float)(kt + t); }
+          else a[t][q] = *reinterpret_cast<const bf16x8_t*>(sbase + a_row[t] * ROWB + pl_perm<P>(u, a_row[t]) * 16);
+        }
+#pragma unroll
+        for (int t = 0; t < WNT; ++t) {
+          if (ABL & 8) { for (int z = 0; z < 8; ++z) b[t][q][z] = (__bf16)(float)(kt - t); }
+          else b[t][q] = *reinterpret_cast<const bf16x8_t*>(sbase + TA_B + b_row[t] * ROWB + pl_perm<P>(u, b_row[t]) * 16);
+        }
+      }
+#pragma unroll
+      for (int ord = P - 1; ord >= 0; --ord)     // smallest terms first
+#pragma unroll
+        for (int qa = 0; qa <= ord; ++qa) {
+          const int qb = ord - qa;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < WNT; ++j) {
+              if (ABL & 2) acc[i][j][0] += (float)a[i][qa][0] * (float)b[j][qb][1];
+              else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][qa], b[j][qb], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+  }
+
+  // ---- epilogue (C/D map of 32x32 tiles: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)); straight-line
+  //      stores on the block-uniform fast path, see gemm_epilogue in umx_gemm.h
+  const bool full = ((long)mt * BMR + BMR <= p.M) && (nt * BNC + BNC <= p.N);
+  if (ABL & 4) {
+    float sum = 0.f;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < WNT; ++j) for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+    if (sum == 1.2345f) p.Cp[0] = sum;
+    return;
+  }
+  if (CPLX) {
+#pragma unroll
+    for (int eg = 0; eg < 2; ++eg)
+#pragma unroll
+      for (int cg = 0; cg < WNT / 2; ++cg) {
+        const int chan = nt * BNC + wn * (BNC / 2) + cg * 32 + l31;
+        const long e0 = (long)mt * 128 + wm * 64 + eg * 32 + 4 * h;
+        float* c = p.Cp + e0 * p.ldc + chan;
+        if (full) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float* cr = c + (long)((r & 3) + 8 * (r >> 2)) * p.ldc;
+            cr[p.offC] = acc[eg][cg][r] - p.conj * acc[2 + eg][WNT / 2 + cg][r];
+            cr[p.offCi] = acc[2 + eg][cg][r] + p.conj * acc[eg][WNT / 2 + cg][r];
+          }
+        } else if (chan < p.N) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            if (e0 + dr < p.M) {
+              float* cr = c + (long)dr * p.ldc;
+              cr[p.offC] = acc[eg][cg][r] - p.conj * acc[2 + eg][WNT / 2 + cg][r];
+              cr[p.offCi] = acc[2 + eg][cg][r] + p.conj * acc[eg][WNT / 2 + cg][r];
+            }
+          }
+        }
+      }
+  } else {
+    float bv[WNT];
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+      const int col = nt * BN + wn * (BN / 2) + j * 32 + l31;
+      bv[j] = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) {
+        const int col = nt * BN + wn * (BN / 2) + j * 32 + l31;
+        const long row0 = (long)mt * 256 + wm * 128 + i * 32 + 4 * h;
+        float* c = p.Cp + row0 * p.ldc + p.offC + col;
+        if (full) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) c[(long)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[i][j][r] + bv[j];
+        } else if (col < p.N) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            if (row0 + dr < p.M) c[(long)dr * p.ldc] = acc[i][j][r] + bv[j];
+          }
+        }
+      }
+  }
+}
+
+}  // namespace umx

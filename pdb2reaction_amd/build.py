@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libumx.so")
 SOURCES = ["umx_api.hip"]
-HEADERS = ["umx_common.h", "umx_gemm.h", "umx_gemm_bf16.h", "umx_kernels.h", os.path.join("..", "..", "include", "umx.h")]
+HEADERS = ["umx_common.h", "umx_gemm.h", "umx_gemm_pl.h", "umx_kernels.h", "umx_kernels_pl.h", os.path.join("..", "..", "include", "umx.h")]
 
 
 def find_hipcc() -> str:

@@ -7,7 +7,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
-#include "umx_gemm_bf16.h"
 #include "umx_gemm_pl.h"
 using namespace umx;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
@@ -64,7 +63,6 @@ int main(int argc, char** argv) {
     if (getenv("DBG")) { for (int r : {0, 1, 33, 130}) { printf("     row %d ref:", r); for (int c : {0, 1, 31, 32, 64, 100}) printf(" %9.4f", c1[(size_t)r * N + c]); printf("\n     row %d got:", r); for (int c : {0, 1, 31, 32, 64, 100}) printf(" %9.4f", c2[(size_t)r * N + c]); printf("\n"); } }
   };
   rep("fp32 PLAIN", timeit([&] { hipLaunchKernelGGL((umx_gemm_kernel<A_PLAIN, 0, E_BIAS>), grid, block, 0, 0, p); }));
-  { GemmP p3 = p; p3.Cp = C2; rep("bf16 P=3 PLAIN (reg-staged, split in GEMM; garbage B planes)", timeit([&] { hipLaunchKernelGGL((umx_gemm_bf16_kernel<A_PLAIN, 0, 3, 0>), grid, block, 0, 0, p3); })); }
   auto launch_pl = [&](void (*k)(const GemmPL), dim3 g, const GemmPL& a) { hipLaunchKernelGGL(k, g, block, 0, 0, a); };
   auto gridpl = [&](int bn) { const long nm = (M + 255) / 256, nn = (N + bn - 1) / bn; return dim3((unsigned)(((nm + 7) / 8) * 8 * nn)); };
   CK(hipMemset(C2, 0, M * (long)N * 4));
@@ -82,6 +80,5 @@ int main(int argc, char** argv) {
   rep("PL 256x256 P=2 S=2 noStores(4)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 2, 4, 4>, gridpl(256), q2); }));
   rep("PL 256x128 P=3 S=2 noMFMA(2)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 3, 2, 2, 2>, gridpl(128), q); }));
   rep("PL 256x128 P=3 S=2 noDMA(1)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 3, 2, 2, 1>, gridpl(128), q); }));
-  { GemmP p3 = p; p3.Cp = C2; rep("bf16 P=2 PLAIN (reg-staged 128x128)", timeit([&] { hipLaunchKernelGGL((umx_gemm_bf16_kernel<A_PLAIN, 0, 2, 0>), grid, block, 0, 0, p3); })); }
   return 0;
 }

@@ -19,7 +19,8 @@
 #include "../../include/umx.h"
 #include "umx_common.h"
 #include "umx_gemm.h"
-#include "umx_gemm_bf16.h"
+#include "umx_gemm_pl.h"
+#include "umx_kernels_pl.h"
 #include "umx_kernels.h"
 
 using namespace umx;
@@ -54,9 +55,9 @@ struct umx_engine {
   bool have_weights = false;
   float* d_w = nullptr;          // raw blob data section
   float* d_dw = nullptr;         // derived weights
-  unsigned short* d_bw = nullptr; // bf16 planes of the large SO(2)/radial weights (3 planes each)
-  std::map<const float*, std::pair<const unsigned short*, long>> planes;   // fp32 weight ptr -> (planes, plane stride)
-  int prec_fwd = 0, prec_bwd = 0, cur_prec = 0;   // 0 = fp32 MFMA, 3 = bf16x6, 2 = bf16x3 (UMX_PRECISION)
+  unsigned short* d_bw = nullptr; // plane-interleaved (PL) bf16 copies of the large SO(2)/radial weights
+  std::map<const float*, const unsigned short*> planes;   // fp32 weight ptr -> PL planes (P=3 forward weights, P=2 transposed)
+  bool pl = true;                 // UMX_PRECISION=split (default): split-bf16 PL GEMMs; fp32: fp32-MFMA everywhere
   std::map<std::string, Tensor> wt;
   std::vector<float> h_w;        // host copy of the data section (needed to build derived weights)
   RadialW rdeg{};
@@ -130,27 +131,6 @@ int launch_gemm(umx_engine* eng, const GemmP& p, int amode, int cplx, int epi, i
     pr->M = p.M; pr->N = p.N; pr->K = p.K; pr->amode = amode; pr->cplx = cplx; pr->gz = gz; pr->prec = 0;
     HIPCHK(eng, hipEventRecord(pr->a, eng->stream));
   }
-  GemmP q = p;
-  int prec = 0;
-  if (eng->cur_prec > 0 && epi == E_BIAS && gz == 1 && (amode == A_PLAIN || amode == A_MODUL)) {
-    auto it = eng->planes.find(p.B);
-    if (it != eng->planes.end()) { prec = eng->cur_prec; q.Bpl = it->second.first; q.bplane = it->second.second; }
-  }
-  if (pr) pr->prec = prec;
-  if (prec > 0) {
-    const int key = amode * 100 + cplx * 10 + prec;
-    switch (key) {
-      case A_PLAIN * 100 + 0 + 3: hipLaunchKernelGGL((umx_gemm_bf16_kernel<A_PLAIN, 0, 3>), grid, block, 0, eng->stream, q); break;
-      case A_PLAIN * 100 + 10 + 3: hipLaunchKernelGGL((umx_gemm_bf16_kernel<A_PLAIN, 1, 3>), grid, block, 0, eng->stream, q); break;
-      case A_MODUL * 100 + 0 + 3: hipLaunchKernelGGL((umx_gemm_bf16_kernel<A_MODUL, 0, 3>), grid, block, 0, eng->stream, q); break;
-      case A_MODUL * 100 + 10 + 3: hipLaunchKernelGGL((umx_gemm_bf16_kernel<A_MODUL, 1, 3>), grid, block, 0, eng->stream, q); break;
-      case A_PLAIN * 100 + 0 + 2: hipLaunchKernelGGL((umx_gemm_bf16_kernel<A_PLAIN, 0, 2>), grid, block, 0, eng->stream, q); break;
-      case A_PLAIN * 100 + 10 + 2: hipLaunchKernelGGL((umx_gemm_bf16_kernel<A_PLAIN, 1, 2>), grid, block, 0, eng->stream, q); break;
-      case A_MODUL * 100 + 0 + 2: hipLaunchKernelGGL((umx_gemm_bf16_kernel<A_MODUL, 0, 2>), grid, block, 0, eng->stream, q); break;
-      case A_MODUL * 100 + 10 + 2: hipLaunchKernelGGL((umx_gemm_bf16_kernel<A_MODUL, 1, 2>), grid, block, 0, eng->stream, q); break;
-      default: return fail(eng, UMX_ERR_ARG, "gemm: split-bf16 variant not instantiated");
-    }
-  } else {
   const int key = amode * 100 + cplx * 10 + epi;
   switch (key) {
     case A_PLAIN * 100 + 0 + E_BIAS: hipLaunchKernelGGL((umx_gemm_kernel<A_PLAIN, 0, E_BIAS>), grid, block, 0, eng->stream, p); break;
@@ -160,7 +140,6 @@ int launch_gemm(umx_engine* eng, const GemmP& p, int amode, int cplx, int epi, i
     case A_GAUSS * 100 + 0 + E_TABLES: hipLaunchKernelGGL((umx_gemm_kernel<A_GAUSS, 0, E_TABLES>), grid, block, 0, eng->stream, p); break;
     case A_SILU * 100 + 0 + E_BIAS: hipLaunchKernelGGL((umx_gemm_kernel<A_SILU, 0, E_BIAS>), grid, block, 0, eng->stream, p); break;
     default: return fail(eng, UMX_ERR_ARG, "gemm: variant not instantiated");
-  }
   }
   HIPCHK(eng, hipGetLastError());
   if (pr) HIPCHK(eng, hipEventRecord(pr->b, eng->stream));
@@ -186,6 +165,43 @@ int gemm_cplx(umx_engine* eng, const float* A, long lda, int offRe, int offIm, c
   return launch_gemm(eng, p, R ? A_MODUL : A_PLAIN, 1, E_BIAS);
 }
 
+// split-bf16 GEMM on plane-interleaved operands (umx_gemm_pl.h).  Wkey = fp32 device pointer of the weight (its PL copy is
+// looked up); a_cols = total columns of the A matrix (row pitch = a_cols * P); offsets in columns.
+int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_cols, int offA0, int offA1, const float* Wkey, int bHalf,
+            const float* bias, float* Cp, long ldc, int offC, int offCi, long M, int N, int K, float conj) {
+  if (M <= 0) return UMX_OK;
+  auto it = eng->planes.find(Wkey);
+  if (it == eng->planes.end()) return fail(eng, UMX_ERR_ARG, "gemm_pl: weight has no PL copy");
+  if (K % 32 != 0) return fail(eng, UMX_ERR_ARG, "gemm_pl: K not a multiple of 32");
+  GemmPL q;
+  std::memset(&q, 0, sizeof(q));
+  q.Apl = Apl; q.lda = (long)a_cols * P; q.offA0 = offA0; q.offA1 = offA1; q.Bpl = it->second; q.ldb = (long)K * P; q.bHalf = bHalf;
+  q.Cp = Cp; q.ldc = ldc; q.offC = offC; q.offCi = offCi; q.bias = bias; q.conj = conj; q.M = (int)M; q.N = N; q.K = K;
+  const int bmr = cplx ? 128 : 256, bnc = cplx ? 64 : 128;
+  const long nM = (M + bmr - 1) / bmr, nN = (N + bnc - 1) / bnc;
+  dim3 grid((unsigned)(((nM + 7) / 8) * 8 * nN)), block(256);
+  ProfRec* pr = nullptr;
+  if (eng->prof_on) {
+    if (eng->prof_used == eng->prof.size()) {
+      ProfRec r; HIPCHK(eng, hipEventCreate(&r.a)); HIPCHK(eng, hipEventCreate(&r.b)); r.flops = 0; eng->prof.push_back(r);
+    }
+    pr = &eng->prof[eng->prof_used++];
+    pr->flops = cplx ? 8.0 * M * (double)N * K : 2.0 * M * (double)N * K;
+    pr->M = (int)M; pr->N = N; pr->K = K; pr->amode = 9; pr->cplx = cplx; pr->gz = 1; pr->prec = P;
+    HIPCHK(eng, hipEventRecord(pr->a, eng->stream));
+  }
+  if (P == 3) {
+    if (cplx) hipLaunchKernelGGL((umx_gemm_pl_kernel<1, 3, 2, 2>), grid, block, 0, eng->stream, q);
+    else hipLaunchKernelGGL((umx_gemm_pl_kernel<0, 3, 2, 2>), grid, block, 0, eng->stream, q);
+  } else {
+    if (cplx) hipLaunchKernelGGL((umx_gemm_pl_kernel<1, 2, 2, 2>), grid, block, 0, eng->stream, q);
+    else hipLaunchKernelGGL((umx_gemm_pl_kernel<0, 2, 2, 2>), grid, block, 0, eng->stream, q);
+  }
+  HIPCHK(eng, hipGetLastError());
+  if (pr) HIPCHK(eng, hipEventRecord(pr->b, eng->stream));
+  return UMX_OK;
+}
+
 // ---- workspace ---------------------------------------------------------------------------------
 struct WS {
   // node level
@@ -206,6 +222,7 @@ struct WS {
   float* hg[NL];
   float* msg[NL];
   float *xrot, *hid, *gmsg, *ghg, *gy1, *grad, *e128a, *e128b, *ggauss;
+  unsigned short *y1pl, *hidpl, *a2pl, *gmsgpl, *ghgpl, *gradpl;   // split-bf16 path: PL operands
 };
 
 struct Bump {
@@ -218,7 +235,7 @@ struct Bump {
   }
 };
 
-size_t carve(char* base, long nn, long ne, WS* w) {
+size_t carve(char* base, long nn, long ne, WS* w, bool pl) {
   Bump b{base};
   WS t;
   t.deg = nullptr;  // deg comes from the per-call array
@@ -240,9 +257,19 @@ size_t carve(char* base, long nn, long ne, WS* w) {
   for (auto& x : t.rad) x = b.take<float>(ne * RAD);
   for (auto& x : t.hg) x = b.take<float>(ne * HG);
   for (auto& x : t.msg) x = b.take<float>(ne * ROW);
-  t.xrot = b.take<float>(ne * XROT); t.hid = b.take<float>(ne * ROW); t.gmsg = b.take<float>(ne * ROW);
-  t.ghg = b.take<float>(ne * HG); t.gy1 = b.take<float>(ne * XROT); t.grad = b.take<float>(ne * RAD);
+  t.hid = b.take<float>(ne * ROW); t.gy1 = b.take<float>(ne * XROT);
   t.e128a = b.take<float>(ne * RH); t.e128b = b.take<float>(ne * RH); t.ggauss = b.take<float>(ne * NG);
+  t.xrot = t.ghg = t.grad = nullptr;
+  t.y1pl = t.hidpl = t.a2pl = t.gmsgpl = t.ghgpl = t.gradpl = nullptr;
+  if (pl) {
+    t.gmsg = b.take<float>(ne * 3 * C);                      // only the edge-degree backward uses fp32 g_msg (E x 384)
+    t.y1pl = b.take<unsigned short>(ne * XROT * 3); t.hidpl = b.take<unsigned short>(ne * ROW * 3);
+    t.a2pl = b.take<unsigned short>(ne * RH * 3); t.gmsgpl = b.take<unsigned short>(ne * ROW * 2);
+    t.ghgpl = b.take<unsigned short>(ne * HG * 2); t.gradpl = b.take<unsigned short>(ne * RAD * 2);
+  } else {
+    t.xrot = b.take<float>(ne * XROT); t.gmsg = b.take<float>(ne * ROW);
+    t.ghg = b.take<float>(ne * HG); t.grad = b.take<float>(ne * RAD);
+  }
   if (w) *w = t;
   return (b.off + 255) & ~size_t(255);
 }
@@ -267,15 +294,21 @@ int radial_fwd(umx_engine* eng, const WS& w, const RadialW& r, int slot, long ne
   CHK(launch_gemm(eng, p, A_GAUSS, 0, E_TABLES));
   hipLaunchKernelGGL(k_ln_silu_fwd, dim3(nblk(ne, 4)), dim3(256), 0, s, w.h1pre[slot], r.ln1w, r.ln1b, w.ra, ne);
   CHK(gemm_plain(eng, w.ra, RH, 0, r.w2, RH, r.b2, w.h2pre[slot], RH, 0, ne, RH, RH));
-  hipLaunchKernelGGL(k_ln_silu_fwd, dim3(nblk(ne, 4)), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.ra, ne);
-  CHK(gemm_plain(eng, w.ra, RH, 0, r.w3, RH, r.b3, rad_out, r.out, 0, ne, r.out, RH));
+  if (eng->pl && eng->planes.count(r.w3)) {
+    hipLaunchKernelGGL(k_ln_silu_fwd_pl<3>, dim3(nblk(ne, 4)), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne);
+    CHK(gemm_pl(eng, 0, 3, w.a2pl, RH, 0, 0, r.w3, 0, r.b3, rad_out, r.out, 0, 0, ne, r.out, RH, 1.0f));
+  } else {
+    hipLaunchKernelGGL(k_ln_silu_fwd, dim3(nblk(ne, 4)), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.ra, ne);
+    CHK(gemm_plain(eng, w.ra, RH, 0, r.w3, RH, r.b3, rad_out, r.out, 0, ne, r.out, RH));
+  }
   HIPCHK(eng, hipGetLastError());
   return UMX_OK;
 }
 
-int radial_bwd(umx_engine* eng, const WS& w, const RadialW& r, int slot, long ne, const float* grad) {
+int radial_bwd(umx_engine* eng, const WS& w, const RadialW& r, int slot, long ne, const float* grad, const unsigned short* gradpl = nullptr) {
   hipStream_t s = eng->stream;
-  CHK(gemm_plain(eng, grad, r.out, 0, r.w3T, r.out, nullptr, w.e128a, RH, 0, ne, RH, r.out));
+  if (gradpl) CHK(gemm_pl(eng, 0, 2, gradpl, r.out, 0, 0, r.w3T, 0, nullptr, w.e128a, RH, 0, 0, ne, RH, r.out, 1.0f));
+  else CHK(gemm_plain(eng, grad, r.out, 0, r.w3T, r.out, nullptr, w.e128a, RH, 0, ne, RH, r.out));
   hipLaunchKernelGGL(k_ln_silu_bwd, dim3(nblk(ne, 4)), dim3(256), 0, s, w.e128a, w.h2pre[slot], r.ln2w, r.ln2b, w.e128b, ne);
   CHK(gemm_plain(eng, w.e128b, RH, 0, r.w2T, RH, nullptr, w.e128a, RH, 0, ne, RH, RH));
   hipLaunchKernelGGL(k_ln_silu_bwd, dim3(nblk(ne, 4)), dim3(256), 0, s, w.e128a, w.h1pre[slot], r.ln1w, r.ln1b, w.e128b, ne);
@@ -300,7 +333,6 @@ int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, long
   const long nn = nimg * N;
   const float rc2 = eng->cutoff * eng->cutoff;
   const dim3 B256(256);
-  eng->cur_prec = eng->prec_fwd;
   // K1 graph
   hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, d_deg, nn, w.row_ptr, w.stats);
   hipLaunchKernelGGL(k_graph_fill, dim3(nblk(nn, 4)), B256, 0, s, d_pos, N, nn, rc2, w.row_ptr, w.esrc, w.edst, w.evec);
@@ -326,7 +358,18 @@ int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, long
     float* xmid = w.xs[2 * i + 1];
     float* xout = w.xs[2 * i + 2];
     hipLaunchKernelGGL(k_norm_fwd, dim3(nblk(nn, 4)), B256, 0, s, xin, L.n1w, L.n1b, eng->d_sysemb, w.xn[i], nn);
-    if (ne > 0) {
+    if (ne > 0 && eng->pl) {
+      CHK(radial_fwd(eng, w, L.rad, i, ne, w.rad[i]));
+      hipLaunchKernelGGL(k_gather_rotate_mod_pl<3>, dim3(nblk(ne, 4)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne);
+      // SO(2) conv 1 on the pre-modulated planes -> hg = [gate | hpre]
+      CHK(gemm_pl(eng, 0, 3, w.y1pl, XROT, 0, 0, L.c1m0, 0, L.c1m0b, w.hg[i], HG, 0, 0, ne, 640, 768, 1.0f));
+      CHK(gemm_pl(eng, 1, 3, w.y1pl, XROT, 768, 1280, L.c1m1, 256, nullptr, w.hg[i], HG, 640, 896, ne, 256, 512, 1.0f));
+      CHK(gemm_pl(eng, 1, 3, w.y1pl, XROT, 1792, 2048, L.c1m2, 128, nullptr, w.hg[i], HG, 1152, 1280, ne, 128, 256, 1.0f));
+      hipLaunchKernelGGL(k_gate_edge_fwd_pl<3>, dim3(nblk(ne * (H / 4), 256)), B256, 0, s, w.hg[i], w.hidpl, ne);
+      CHK(gemm_pl(eng, 0, 3, w.hidpl, ROW, 0, 0, L.c2m0, 0, L.c2m0b, w.msg[i], ROW, 0, 0, ne, 384, 384, 1.0f));
+      CHK(gemm_pl(eng, 1, 3, w.hidpl, ROW, 384, 640, L.c2m1, 256, nullptr, w.msg[i], ROW, 384, 640, ne, 256, 256, 1.0f));
+      CHK(gemm_pl(eng, 1, 3, w.hidpl, ROW, 896, 1024, L.c2m2, 128, nullptr, w.msg[i], ROW, 896, 1024, ne, 128, 128, 1.0f));
+    } else if (ne > 0) {
       hipLaunchKernelGGL(k_gather_rotate, dim3(nblk(ne, 4)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.xrot, ne);
       CHK(radial_fwd(eng, w, L.rad, i, ne, w.rad[i]));
       // SO(2) conv 1 (radially modulated) -> hg = [gate | hpre]
@@ -346,8 +389,9 @@ int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, long
     }
     hipLaunchKernelGGL(k_rotate_back_reduce<9>, dim3(nblk(nn, 4)), B256, 0, s, w.msg[i], w.frame, w.row_ptr, xin, xmid, nn, 1.0f);
     HIPCHK(eng, hipGetLastError());
-    DBG("xn" + t, w.xn[i], nn * ROW); DBG("xrot" + t, w.xrot, ne * XROT); DBG("rad" + t, w.rad[i], ne * RAD);
-    DBG("hg" + t, w.hg[i], ne * HG); DBG("hid" + t, w.hid, ne * ROW); DBG("msg" + t, w.msg[i], ne * ROW); DBG("xmid" + t, xmid, nn * ROW);
+    DBG("xn" + t, w.xn[i], nn * ROW); DBG("rad" + t, w.rad[i], ne * RAD);
+    if (!eng->pl) { DBG("xrot" + t, w.xrot, ne * XROT); DBG("hid" + t, w.hid, ne * ROW); }
+    DBG("hg" + t, w.hg[i], ne * HG); DBG("msg" + t, w.msg[i], ne * ROW); DBG("xmid" + t, xmid, nn * ROW);
     // K8 atom-wise
     hipLaunchKernelGGL(k_norm_fwd, dim3(nblk(nn, 4)), B256, 0, s, xmid, L.n2w, L.n2b, (const float*)nullptr, w.xn2, nn);
     CHK(gemm_plain(eng, w.xn2, ROW, 0, L.smlp, C, L.smlpb, w.gspre[i], 2 * H, 0, nn, 2 * H, C));
@@ -368,7 +412,6 @@ int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, long
   if (!d_forces) return UMX_OK;
 
   // ---------------- K10: analytic reverse pass ----------------
-  eng->cur_prec = eng->prec_bwd;
   if (ne > 0) {
     HIPCHK(eng, hipMemsetAsync(w.dedd, 0, ne * sizeof(float), s));
     HIPCHK(eng, hipMemsetAsync(w.tau, 0, ne * 4 * sizeof(float), s));
@@ -394,7 +437,20 @@ int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, long
     hipLaunchKernelGGL(k_norm_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.G1, xmid, L.n2w, w.G0, w.G2, nn);   // G2 = g_xmid
     HIPCHK(eng, hipGetLastError());
     DBG("g_xmid" + t, w.G2, nn * ROW);
-    if (ne > 0) {
+    if (ne > 0 && eng->pl) {
+      hipLaunchKernelGGL(k_rotate_back_bwd_pl<2>, dim3(nblk(ne, 4)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne);
+      CHK(gemm_pl(eng, 0, 2, w.gmsgpl, ROW, 0, 0, L.c2m0T, 0, nullptr, w.hid, ROW, 0, 0, ne, 384, 384, 1.0f));
+      CHK(gemm_pl(eng, 1, 2, w.gmsgpl, ROW, 384, 640, L.c2m1T, 256, nullptr, w.hid, ROW, 384, 640, ne, 256, 256, -1.0f));
+      CHK(gemm_pl(eng, 1, 2, w.gmsgpl, ROW, 896, 1024, L.c2m2T, 128, nullptr, w.hid, ROW, 896, 1024, ne, 128, 128, -1.0f));
+      DBG("g_hid" + t, w.hid, ne * ROW);
+      hipLaunchKernelGGL(k_gate_edge_bwd_pl<2>, dim3(nblk(ne * (H / 4), 256)), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne);
+      CHK(gemm_pl(eng, 0, 2, w.ghgpl, HG, 0, 0, L.c1m0T, 0, nullptr, w.gy1, XROT, 0, 0, ne, 768, 640, 1.0f));
+      CHK(gemm_pl(eng, 1, 2, w.ghgpl, HG, 640, 896, L.c1m1T, 512, nullptr, w.gy1, XROT, 768, 1280, ne, 512, 256, -1.0f));
+      CHK(gemm_pl(eng, 1, 2, w.ghgpl, HG, 1152, 1280, L.c1m2T, 256, nullptr, w.gy1, XROT, 1792, 2048, ne, 256, 128, -1.0f));
+      hipLaunchKernelGGL(k_modulate_bwd_pl<2>, dim3(nblk(ne, 4)), B256, 0, s, w.gy1, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.gradpl, w.tau, ne);
+      DBG("g_xrot" + t, w.gy1, ne * XROT);
+      CHK(radial_bwd(eng, w, L.rad, i, ne, nullptr, w.gradpl));
+    } else if (ne > 0) {
       hipLaunchKernelGGL(k_rotate_back_bwd<9>, dim3(nblk(ne, 4)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsg, w.dedd, w.tau, ne, 1.0f);
       CHK(gemm_plain(eng, w.gmsg, ROW, 0, L.c2m0T, 3 * C, nullptr, w.hid, ROW, 0, ne, 3 * H, 3 * C));
       CHK(gemm_cplx(eng, w.gmsg, ROW, 384, 640, nullptr, 0, 0, L.c2m1T, 256, 256, w.hid, ROW, 384, 640, ne, 256, 256, -1.0f));
@@ -642,51 +698,54 @@ int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes) {
   HIPCHK(eng, hipMemcpy(eng->d_dw, dw.data(), dw.size() * sizeof(float), hipMemcpyHostToDevice));
   auto W = [&](const std::string& nm) -> const float* { return eng->d_w + eng->wt[nm].off; };
   auto D = [&](size_t o) -> const float* { return eng->d_dw + o; };
-  // ---- bf16 planes (x = x0 + x1 + x2, round-to-nearest-even, exact residuals) of the large weights ----
+  // ---- plane-interleaved bf16 copies (umx_gemm_pl.h "PL" layout) of the large weights: P=3 for the forward
+  //      orientation, P=2 for the transposed (reverse-pass) orientation; RNE split with exact residuals ----
   std::vector<unsigned short> bw;
-  struct PlaneReq { const float* host; const float* dev; size_t count; size_t off; };
+  struct PlaneReq { const float* dev; size_t off; };
   std::vector<PlaneReq> preq;
-  auto want_planes = [&](const float* host, const float* dev, size_t count) {
-    PlaneReq r{host, dev, count, (bw.size() + 63) & ~size_t(63)};
-    bw.resize(r.off + 3 * count);
-    for (size_t i = 0; i < count; ++i) {
-      float x = host[i];
-      for (int q = 0; q < 3; ++q) {
-        uint32_t u; std::memcpy(&u, &x, 4);
-        const uint32_t rr = u + 0x7FFFu + ((u >> 16) & 1u);
-        const unsigned short hb = (unsigned short)(rr >> 16);
-        bw[r.off + q * count + i] = hb;
-        const uint32_t back = (uint32_t)hb << 16; float fb; std::memcpy(&fb, &back, 4);
-        x -= fb;
+  auto want_planes = [&](const float* host, const float* dev, int rows, int K, int P) {
+    PlaneReq r{dev, (bw.size() + 63) & ~size_t(63)};
+    bw.resize(r.off + (size_t)rows * K * P);
+    for (int rr = 0; rr < rows; ++rr)
+      for (int k = 0; k < K; ++k) {
+        float x = host[(size_t)rr * K + k];
+        for (int q = 0; q < P; ++q) {
+          uint32_t u; std::memcpy(&u, &x, 4);
+          const uint32_t rnd = u + 0x7FFFu + ((u >> 16) & 1u);
+          const unsigned short hb = (unsigned short)(rnd >> 16);
+          bw[r.off + (size_t)rr * K * P + (size_t)(k / 32) * 32 * P + (size_t)q * 32 + (k % 32)] = hb;
+          const uint32_t back = (uint32_t)hb << 16; float fb; std::memcpy(&fb, &back, 4);
+          x -= fb;
+        }
       }
-    }
     preq.push_back(r);
   };
   const float* hd = dw.data();
   for (int i = 0; i < NL; ++i) {
     const std::string bpre = "blocks." + std::to_string(i);
     const std::string c1 = bpre + ".edge_wise.so2_conv_1", c2 = bpre + ".edge_wise.so2_conv_2";
-    auto WH = [&](const std::string& nm, size_t cnt) { want_planes(hw + eng->wt[nm].off, W(nm), cnt); };
-    WH(c1 + ".fc_m0.weight", 640 * 768); WH(c1 + ".so2_m_conv.0.fc.weight", 512 * 512); WH(c1 + ".so2_m_conv.1.fc.weight", 256 * 256);
-    WH(c2 + ".fc_m0.weight", 384 * 384); WH(c2 + ".so2_m_conv.0.fc.weight", 512 * 256); WH(c2 + ".so2_m_conv.1.fc.weight", 256 * 128);
-    WH(c1 + ".rad_func.fc3.weight", (size_t)RAD * RH);
-    want_planes(hd + loff[i].c1m0T, D(loff[i].c1m0T), 768 * 640); want_planes(hd + loff[i].c1m1T, D(loff[i].c1m1T), 512 * 512);
-    want_planes(hd + loff[i].c1m2T, D(loff[i].c1m2T), 256 * 256); want_planes(hd + loff[i].c2m0T, D(loff[i].c2m0T), 384 * 384);
-    want_planes(hd + loff[i].c2m1T, D(loff[i].c2m1T), 512 * 256); want_planes(hd + loff[i].c2m2T, D(loff[i].c2m2T), 256 * 128);
-    want_planes(hd + roff[c1 + ".rad_func"].w3T, D(roff[c1 + ".rad_func"].w3T), (size_t)RH * RAD);
+    auto WH = [&](const std::string& nm, int rows, int K) { want_planes(hw + eng->wt[nm].off, W(nm), rows, K, 3); };
+    WH(c1 + ".fc_m0.weight", 640, 768); WH(c1 + ".so2_m_conv.0.fc.weight", 512, 512); WH(c1 + ".so2_m_conv.1.fc.weight", 256, 256);
+    WH(c2 + ".fc_m0.weight", 384, 384); WH(c2 + ".so2_m_conv.0.fc.weight", 512, 256); WH(c2 + ".so2_m_conv.1.fc.weight", 256, 128);
+    WH(c1 + ".rad_func.fc3.weight", RAD, RH);
+    want_planes(hd + loff[i].c1m0T, D(loff[i].c1m0T), 768, 640, 2); want_planes(hd + loff[i].c1m1T, D(loff[i].c1m1T), 2 * 512, 256, 2);
+    want_planes(hd + loff[i].c1m2T, D(loff[i].c1m2T), 2 * 256, 128, 2); want_planes(hd + loff[i].c2m0T, D(loff[i].c2m0T), 384, 384, 2);
+    want_planes(hd + loff[i].c2m1T, D(loff[i].c2m1T), 2 * 256, 256, 2); want_planes(hd + loff[i].c2m2T, D(loff[i].c2m2T), 2 * 128, 128, 2);
+    want_planes(hd + roff[c1 + ".rad_func"].w3T, D(roff[c1 + ".rad_func"].w3T), RH, RAD, 2);
   }
   if (eng->d_bw) { HIPCHK(eng, hipFree(eng->d_bw)); eng->d_bw = nullptr; }
   HIPCHK(eng, hipMalloc(&eng->d_bw, bw.size() * sizeof(unsigned short)));
   HIPCHK(eng, hipMemcpy(eng->d_bw, bw.data(), bw.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
   eng->planes.clear();
-  for (const auto& r : preq) eng->planes[r.dev] = {eng->d_bw + r.off, (long)r.count};
+  for (const auto& r : preq) eng->planes[r.dev] = eng->d_bw + r.off;
   {
     const char* pv = std::getenv("UMX_PRECISION");
     const std::string mode = pv ? pv : "split";
-    if (mode == "fp32") { eng->prec_fwd = 0; eng->prec_bwd = 0; }
-    else if (mode == "bf16x6") { eng->prec_fwd = 3; eng->prec_bwd = 3; }
-    else if (mode == "split") { eng->prec_fwd = 3; eng->prec_bwd = 2; }
-    else return fail(eng, UMX_ERR_ARG, "UMX_PRECISION must be fp32, bf16x6 or split");
+    if (mode == "fp32") eng->pl = false;
+    else if (mode == "split") eng->pl = true;
+    else return fail(eng, UMX_ERR_ARG, "UMX_PRECISION must be fp32 or split");
+    // a precision change alters the workspace carve-up: force a re-carve on the next call
+    eng->cap_nodes = 0; eng->cap_edges = 0;
   }
   auto fill_rad = [&](RadialW& r, const std::string& pre, int out) {
     const RadOff& o = roff[pre];
@@ -839,11 +898,11 @@ int umx_energy_forces_dev(umx_engine* eng, int n_images, const float* d_pos, dou
     long k1 = k0, e = 0;
     while (k1 < K && (k1 - k0) < max_chunk) {
       const long e2 = e + img_edges[k1];
-      if (k1 > k0 && carve(nullptr, (k1 - k0 + 1) * N, e2, nullptr) > budget) break;
+      if (k1 > k0 && carve(nullptr, (k1 - k0 + 1) * N, e2, nullptr, eng->pl) > budget) break;
       e = e2; ++k1;
     }
-    if (carve(nullptr, (k1 - k0) * N, e, nullptr) > budget)
-      return fail(eng, UMX_ERR_CAPACITY, "one image needs " + std::to_string(carve(nullptr, N, e, nullptr) >> 20) + " MiB of workspace, budget is " +
+    if (carve(nullptr, (k1 - k0) * N, e, nullptr, eng->pl) > budget)
+      return fail(eng, UMX_ERR_CAPACITY, "one image needs " + std::to_string(carve(nullptr, N, e, nullptr, eng->pl) >> 20) + " MiB of workspace, budget is " +
                                              std::to_string(budget >> 20) + " MiB");
     chunks.push_back({k0, k1});
     need_nodes = std::max(need_nodes, (k1 - k0) * N);
@@ -854,14 +913,14 @@ int umx_energy_forces_dev(umx_engine* eng, int n_images, const float* d_pos, dou
     HIPCHK(eng, hipStreamSynchronize(s));
     if (eng->arena) { HIPCHK(eng, hipFree(eng->arena)); eng->arena = nullptr; eng->arena_bytes = 0; }
     const long cn = std::max(need_nodes, eng->cap_nodes), ce = std::max(need_edges + need_edges / 50 + 1024, eng->cap_edges);
-    size_t bytes = carve(nullptr, cn, ce, nullptr);
+    size_t bytes = carve(nullptr, cn, ce, nullptr, eng->pl);
     long ce2 = ce;
-    if (bytes > budget) { ce2 = std::max(need_edges, 1L); bytes = carve(nullptr, cn, ce2, nullptr); }
+    if (bytes > budget) { ce2 = std::max(need_edges, 1L); bytes = carve(nullptr, cn, ce2, nullptr, eng->pl); }
     HIPCHK(eng, hipMalloc(&eng->arena, bytes));
     eng->arena_bytes = bytes; eng->cap_nodes = cn; eng->cap_edges = ce2;
   }
   WS w;
-  carve(eng->arena, eng->cap_nodes, eng->cap_edges, &w);
+  carve(eng->arena, eng->cap_nodes, eng->cap_edges, &w, eng->pl);
   if (eng->dbg_on) eng->dbg.clear();
   for (auto& ch : chunks) {
     const long k0 = ch.first, k1 = ch.second;

@@ -1,0 +1,253 @@
+// umx_kernels_pl.h -- producer kernels of the split-bf16 path: every A operand of the large SO(2)/radial GEMMs is
+// written ONCE, already split into bf16 planes, in the plane-interleaved row layout of umx_gemm_pl.h:
+//   element (row, k, plane q) -> row * (K*P) + (k / 32) * (32*P) + q * 32 + (k % 32)
+// P = 3 for forward operands (exact 24-bit split), P = 2 for reverse-pass operands.
+// Fusions relative to the fp32 path: the radial modulation is applied by the gather/rotate producer (the conv-1 GEMM
+// no longer reads `rad`), and the reverse pass re-derives the rotated message inside the modulation-backward kernel
+// instead of round-tripping a 9 KB/edge buffer through HBM.
+#pragma once
+#include "umx_common.h"
+
+namespace umx {
+
+template <int P> __device__ __forceinline__ long pl_index(int k) { return (long)(k >> 5) * (32 * P) + (k & 31); }
+
+// split 2 adjacent values into P planes and store them (k even): 4-byte store per plane
+template <int P> __device__ __forceinline__ void pl_store2(unsigned short* row, int k, float x0, float x1) {
+  unsigned short* d = row + pl_index<P>(k);
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
+    const unsigned int pk = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
+    *reinterpret_cast<unsigned int*>(d + q * 32) = pk;
+    x0 -= (float)h0; x1 -= (float)h1;
+  }
+}
+// split 4 adjacent values (k multiple of 4): 8-byte store per plane
+template <int P> __device__ __forceinline__ void pl_store4(unsigned short* row, int k, float4 v) {
+  unsigned short* d = row + pl_index<P>(k);
+  float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    unsigned short hb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { const __bf16 h = (__bf16)x[c]; hb[c] = __builtin_bit_cast(unsigned short, h); x[c] -= (float)h; }
+    *reinterpret_cast<uint2*>(d + q * 32) = make_uint2((unsigned int)hb[0] | ((unsigned int)hb[1] << 16), (unsigned int)hb[2] | ((unsigned int)hb[3] << 16));
+  }
+}
+
+#define UMX_WAVE_ITEM_PL(idx, count)                                                  \
+  const int lane = threadIdx.x & 63;                                                  \
+  const long idx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))); \
+  if (idx >= (count)) return;
+
+// LayerNorm(128)+SiLU of the radial MLP, output as PL planes (A operand of the fc3 GEMM)
+template <int P>
+__global__ __launch_bounds__(256) void k_ln_silu_fwd_pl(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, unsigned short* __restrict__ y, long rows) {
+  UMX_WAVE_ITEM_PL(row, rows)
+  const int c0 = lane * 2;
+  float2 v = *reinterpret_cast<const float2*>(x + row * RH + c0);
+  const float mu = wave_sum(v.x + v.y) * (1.0f / RH);
+  v.x -= mu; v.y -= mu;
+  const float var = wave_sum(v.x * v.x + v.y * v.y) * (1.0f / RH);
+  const float rstd = rsqrt_f(var + LN_EPS);
+  const float2 ww = *reinterpret_cast<const float2*>(w + c0), bb = *reinterpret_cast<const float2*>(b + c0);
+  pl_store2<P>(y + row * (RH * P), c0, silu_f(v.x * rstd * ww.x + bb.x), silu_f(v.y * rstd * ww.y + bb.y));
+}
+
+// K7a fused: y1[e] = (W_e [xn[src] | xn[dst]]) .* rad[e]  as PL planes (9 m-primary rows x 256 columns)
+template <int P>
+__global__ __launch_bounds__(256) void k_gather_rotate_mod_pl(const float* __restrict__ xn, const int* __restrict__ esrc,
+                                                              const int* __restrict__ edst, const float* __restrict__ frame,
+                                                              const float* __restrict__ rad, unsigned short* __restrict__ y1, long ne) {
+  UMX_WAVE_ITEM_PL(e, ne)
+  const int c0 = lane * 2;
+  const float* f = frame + e * FRAME;
+  const long js = esrc[e], jd = edst[e];
+  float sx[9], sy[9], dx[9], dy[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const float2 a = *reinterpret_cast<const float2*>(xn + js * ROW + r * C + c0);
+    const float2 b = *reinterpret_cast<const float2*>(xn + jd * ROW + r * C + c0);
+    sx[r] = a.x; sy[r] = a.y; dx[r] = b.x; dy[r] = b.y;
+  }
+  const float* rd = rad + e * RAD;
+  unsigned short* out = y1 + e * (long)(XROT * P);
+  const int ridx[9] = {0, 1, 2, 3, 4, 3, 4, 5, 5};   // radial row of each m-primary row
+  float p[9], q[9];
+  rot_fwd(f, sx, p); rot_fwd(f, sy, q);
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const float2 m = *reinterpret_cast<const float2*>(rd + ridx[r] * 2 * C + c0);
+    pl_store2<P>(out, r * 2 * C + c0, p[r] * m.x, q[r] * m.y);
+  }
+  rot_fwd(f, dx, p); rot_fwd(f, dy, q);
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const float2 m = *reinterpret_cast<const float2*>(rd + ridx[r] * 2 * C + C + c0);
+    pl_store2<P>(out, r * 2 * C + C + c0, p[r] * m.x, q[r] * m.y);
+  }
+}
+
+// SO(2) gate: hg = [gate(256) | hpre(9x128)] (fp32) -> hid (9x128) as PL planes
+template <int P>
+__global__ void k_gate_edge_fwd_pl(const float* __restrict__ hg, unsigned short* __restrict__ hid, long ne) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ne * (H / 4)) return;
+  const long e = i / (H / 4);
+  const int c = (int)(i % (H / 4)) * 4;
+  const float* p = hg + e * HG;
+  const float4 g1 = *reinterpret_cast<const float4*>(p + c), g2 = *reinterpret_cast<const float4*>(p + H + c);
+  const float4 s1 = make_float4(sigmoid_f(g1.x), sigmoid_f(g1.y), sigmoid_f(g1.z), sigmoid_f(g1.w));
+  const float4 s2 = make_float4(sigmoid_f(g2.x), sigmoid_f(g2.y), sigmoid_f(g2.z), sigmoid_f(g2.w));
+  unsigned short* o = hid + e * (long)(ROW * P);
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const float4 v = *reinterpret_cast<const float4*>(p + 2 * H + r * H + c);
+    float4 w;
+    if (r == 0) w = make_float4(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w));
+    else {
+      const bool l1 = (r == 1 || r == 3 || r == 5);
+      const float4 s = l1 ? s1 : s2;
+      w = make_float4(v.x * s.x, v.y * s.y, v.z * s.z, v.w * s.w);
+    }
+    pl_store4<P>(o, r * H + c, w);
+  }
+}
+
+// backward of K7b for the SO(2) messages: g_msg[e] = env_e (W_e g[dst e]) as PL planes; dedd/tau as the fp32 kernel
+template <int P>
+__global__ __launch_bounds__(256) void k_rotate_back_bwd_pl(const float* __restrict__ gnode, const float* __restrict__ msg,
+                                                            const float* __restrict__ frame, const int* __restrict__ edst,
+                                                            unsigned short* __restrict__ gmsg, float* __restrict__ dedd,
+                                                            float* __restrict__ tau, long ne) {
+  UMX_WAVE_ITEM_PL(e, ne)
+  const int c0 = lane * 2;
+  const float* f = frame + e * FRAME;
+  const long jd = edst[e];
+  float gx[9], gy[9], lx[9], ly[9], mx[9], my[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const float2 t = *reinterpret_cast<const float2*>(gnode + jd * ROW + r * C + c0);
+    gx[r] = t.x; gy[r] = t.y;
+    const float2 m = *reinterpret_cast<const float2*>(msg + e * ROW + r * C + c0);
+    mx[r] = m.x; my[r] = m.y;
+  }
+  rot_fwd(f, gx, lx); rot_fwd(f, gy, ly);
+  const float sc = f[34];
+  float s = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    s += lx[r] * mx[r] + ly[r] * my[r];
+    lx[r] *= sc; ly[r] *= sc;
+  }
+  torque_acc(lx, mx, -1.0f, tx, ty, tz);
+  torque_acc(ly, my, -1.0f, tx, ty, tz);
+  unsigned short* o = gmsg + e * (long)(ROW * P);
+#pragma unroll
+  for (int r = 0; r < 9; ++r) pl_store2<P>(o, r * C + c0, lx[r], ly[r]);
+  s = wave_sum(s); tx = wave_sum(tx); ty = wave_sum(ty); tz = wave_sum(tz);
+  if (lane == 0) {
+    dedd[e] += f[35] * s;
+    tau[e * 4 + 0] += tx; tau[e * 4 + 1] += ty; tau[e * 4 + 2] += tz;
+  }
+}
+
+// backward of the edge gate: ghid (9x128 fp32), hg (forward, fp32) -> g_hg = [ggate | ghpre] as PL planes (1408 columns)
+template <int P>
+__global__ void k_gate_edge_bwd_pl(const float* __restrict__ ghid, const float* __restrict__ hg, unsigned short* __restrict__ ghg, long ne) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ne * (H / 4)) return;
+  const long e = i / (H / 4);
+  const int c = (int)(i % (H / 4)) * 4;
+  const float* p = hg + e * HG;
+  const float4 g1 = *reinterpret_cast<const float4*>(p + c), g2 = *reinterpret_cast<const float4*>(p + H + c);
+  const float s1[4] = {sigmoid_f(g1.x), sigmoid_f(g1.y), sigmoid_f(g1.z), sigmoid_f(g1.w)};
+  const float s2[4] = {sigmoid_f(g2.x), sigmoid_f(g2.y), sigmoid_f(g2.z), sigmoid_f(g2.w)};
+  unsigned short* o = ghg + e * (long)(HG * P);
+  float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const float4 gv4 = *reinterpret_cast<const float4*>(ghid + e * ROW + r * H + c);
+    const float4 hv4 = *reinterpret_cast<const float4*>(p + 2 * H + r * H + c);
+    const float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, hv[4] = {hv4.x, hv4.y, hv4.z, hv4.w};
+    float w[4];
+    const bool l1 = (r == 1 || r == 3 || r == 5);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (r == 0) w[k] = gv[k] * silu_grad_f(hv[k]);
+      else {
+        w[k] = gv[k] * (l1 ? s1[k] : s2[k]);
+        if (l1) a1[k] += gv[k] * hv[k]; else a2[k] += gv[k] * hv[k];
+      }
+    }
+    pl_store4<P>(o, 2 * H + r * H + c, make_float4(w[0], w[1], w[2], w[3]));
+  }
+  pl_store4<P>(o, c, make_float4(a1[0] * s1[0] * (1.0f - s1[0]), a1[1] * s1[1] * (1.0f - s1[1]), a1[2] * s1[2] * (1.0f - s1[2]), a1[3] * s1[3] * (1.0f - s1[3])));
+  pl_store4<P>(o, H + c, make_float4(a2[0] * s2[0] * (1.0f - s2[0]), a2[1] * s2[1] * (1.0f - s2[1]), a2[2] * s2[2] * (1.0f - s2[2]), a2[3] * s2[3] * (1.0f - s2[3])));
+}
+
+// backward of the radial modulation with the rotated message RE-DERIVED in place (gather + rotate, no HBM round trip):
+// gy1 (9x256 fp32, in/out -> gxrot = gy1 .* rad), g_rad (1536) as PL planes, tau += <gxrot, L xrot>
+template <int P>
+__global__ __launch_bounds__(256) void k_modulate_bwd_pl(float* __restrict__ gy1, const float* __restrict__ xn,
+                                                         const int* __restrict__ esrc, const int* __restrict__ edst,
+                                                         const float* __restrict__ frame, const float* __restrict__ rad,
+                                                         unsigned short* __restrict__ grad, float* __restrict__ tau, long ne) {
+  UMX_WAVE_ITEM_PL(e, ne)
+  const int c0 = lane * 4;                     // column of the 256-wide [src | dst] row; lanes 0-31 own the source half
+  const float* f = frame + e * FRAME;
+  const long node = (lane < 32) ? esrc[e] : edst[e];
+  const int cn = c0 & (C - 1);
+  float4 xv[9];
+  {
+    float4 raw[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) raw[r] = *reinterpret_cast<const float4*>(xn + node * ROW + r * C + cn);
+    float in[9], out[9];
+#pragma unroll
+    for (int comp = 0; comp < 4; ++comp) {
+#pragma unroll
+      for (int r = 0; r < 9; ++r) in[r] = comp == 0 ? raw[r].x : comp == 1 ? raw[r].y : comp == 2 ? raw[r].z : raw[r].w;
+      rot_fwd(f, in, out);
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        if (comp == 0) xv[r].x = out[r]; else if (comp == 1) xv[r].y = out[r]; else if (comp == 2) xv[r].z = out[r]; else xv[r].w = out[r];
+      }
+    }
+  }
+  float* g = gy1 + e * XROT + c0;
+  const float* rd = rad + e * RAD + c0;
+  float4 gv[9], rv[6], gacc[6];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) gv[r] = *reinterpret_cast<const float4*>(g + r * 2 * C);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { rv[k] = *reinterpret_cast<const float4*>(rd + k * 2 * C); gacc[k] = make_float4(0.f, 0.f, 0.f, 0.f); }
+  const int ridx[9] = {0, 1, 2, 3, 4, 3, 4, 5, 5};
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const int k = ridx[r];
+    gacc[k].x += gv[r].x * xv[r].x; gacc[k].y += gv[r].y * xv[r].y; gacc[k].z += gv[r].z * xv[r].z; gacc[k].w += gv[r].w * xv[r].w;
+    gv[r].x *= rv[k].x; gv[r].y *= rv[k].y; gv[r].z *= rv[k].z; gv[r].w *= rv[k].w;
+    *reinterpret_cast<float4*>(g + r * 2 * C) = gv[r];
+  }
+  unsigned short* gr = grad + e * (long)(RAD * P);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) pl_store4<P>(gr, k * 2 * C + c0, gacc[k]);
+  float tx = 0.f, ty = 0.f, tz = 0.f;
+  float ga[9], xa[9];
+#pragma unroll
+  for (int comp = 0; comp < 4; ++comp) {
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      ga[r] = comp == 0 ? gv[r].x : comp == 1 ? gv[r].y : comp == 2 ? gv[r].z : gv[r].w;
+      xa[r] = comp == 0 ? xv[r].x : comp == 1 ? xv[r].y : comp == 2 ? xv[r].z : xv[r].w;
+    }
+    torque_acc(ga, xa, 1.0f, tx, ty, tz);
+  }
+  tx = wave_sum(tx); ty = wave_sum(ty); tz = wave_sum(tz);
+  if (lane == 0) { tau[e * 4 + 0] += tx; tau[e * 4 + 1] += ty; tau[e * 4 + 2] += tz; }
+}
+
+}  // namespace umx

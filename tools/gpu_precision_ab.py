@@ -9,7 +9,7 @@ from oracle.escn_md_oracle import Oracle
 torch.set_num_threads(16)
 w = W.make_synthetic_weights(0)
 engs = {}
-for mode in ("fp32", "split", "bf16x6"):
+for mode in ("fp32", "split"):
     os.environ["UMX_PRECISION"] = mode
     e = Engine(0); e.load_weights(w); engs[mode] = e
 orc = Oracle(w)
@@ -36,5 +36,5 @@ for mode, eng in engs.items():
     dt = (time.time() - t) / 3
     eng.profile_enable(True); eng.profile_read(True); eng.energy_forces(p); pr = eng.profile_read(True); eng.profile_enable(False)
     print(f"N=2000 K=4 {mode:7s}: {dt*1e3:.1f} ms/call ({dt/4*1e3:.1f} ms/image)  gemm {pr['gemm_ms']:.1f} ms  {pr['gemm_flops']/pr['gemm_ms']/1e9:.1f} alg-TFLOP/s", flush=True)
-for mode in ("split", "bf16x6"):
+for mode in ("split",):
     print(f"N=2000 {mode} vs fp32: dE={np.abs(res[mode][0]-res['fp32'][0]).max():.3e} eV  max dF={np.abs(res[mode][1]-res['fp32'][1]).max():.3e} eV/A")

@@ -37,6 +37,7 @@ from pdb2reaction_amd.uma_pysis import EV2AU, F_EVAA_2_AU  # noqa: E402
 
 FLOP_PER_EDGE = 30.98e6          # algorithmic E+F work per directed edge
 PEAK_FP32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense f32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparse headline)
 
 
 def usable_cores() -> int:
@@ -159,24 +160,38 @@ def main():
     it_s = args.steps / dt
 
     if rank == 0:
-        per_launch_flops = prof["gemm_flops"] / max(prof["gemm_launches"], 1)
-        per_launch_ms = prof["gemm_ms"] / max(prof["gemm_launches"], 1)
-        ach = prof["gemm_flops"] / max(prof["gemm_ms"], 1e-9) / 1e9          # TFLOP/s inside the GEMM kernels
+        pl, f32 = prof["split_bf16"], prof["fp32"]
+        split = pl["launches"] > 0
+        dom = pl if split else f32
+        # dominant kernel family: in the default (split) mode the plane-interleaved bf16 LDS-DMA GEMM.  `achieved` counts the
+        # FLOPs the matrix cores executed (6 bf16 MFMA products per fp32-equivalent product in the forward pass, 3 in the
+        # reverse pass) against the dense bf16 peak; `achieved_algorithmic` is the fp32-equivalent rate (2*M*N*K per product).
+        ach = dom["mfma_flops"] / max(dom["ms"], 1e-9) / 1e9
+        peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
         out = {
             "metric": "path_opt_string_iterations_per_s", "value": it_s, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16x3-split (fp32-equivalent 24-bit products fwd, 16-bit reverse pass), fp32 accumulate" if split else "f32",
+            "data": "synthetic",
             "image_atom_steps_per_s": k * n * it_s,
             "algorithmic_tflops": FLOP_PER_EDGE * edges_iter * it_s / 1e12,
             "config": {"workload": f"c3: {n}-atom synthetic active-site cluster x {k} images, GSM-style string iteration "
                                    f"(batched UMA-S E+F of all images + string update), UMA-S shapes, synthetic weights",
                        "atoms": n, "images": k, "directed_edges_per_iteration": int(edges_iter), "max_degree": maxdeg,
                        "parallelism": f"images sharded {k}/{world} per GPU, 1 all-gather/iteration" if world > 1 else "single GPU, all images batched"},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "umx_gemm_kernel<*> (fp32-MFMA SO(2)/radial/atom-wise linears, rank 0)",
-                         "launches": prof["gemm_launches"], "avg_launch_ms": per_launch_ms,
-                         "flops_per_launch": per_launch_flops, "share_of_step": prof["gemm_ms"] / (ms * args.steps)},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                         "kernel": ("umx_gemm_pl_kernel<*> (split-bf16 LDS-DMA GEMM: SO(2)/radial linears + transposes, rank 0)" if split
+                                    else "umx_gemm_kernel<*> (fp32-MFMA GEMM, rank 0)"),
+                         "launches": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
+                         "flops_per_launch": dom["mfma_flops"] / max(dom["launches"], 1),
+                         "achieved_algorithmic": dom["alg_flops"] / max(dom["ms"], 1e-9) / 1e9,
+                         "algorithmic_flops_per_launch": dom["alg_flops"] / max(dom["launches"], 1),
+                         "share_of_step": dom["ms"] / (ms * args.steps),
+                         "other_gemm_family": {"kernel": "umx_gemm_kernel<*> (fp32 MFMA)" if split else None,
+                                               "ms_per_step": f32["ms"] / args.steps if split else 0.0,
+                                               "achieved": f32["alg_flops"] / max(f32["ms"], 1e-9) / 1e9 if split else 0.0,
+                                               "peak": PEAK_FP32_MFMA_TFLOPS}},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -83,12 +83,20 @@ int umx_synchronize(umx_engine* eng);
  * the maximum in-degree.  (Diagnostics for roofline accounting)         */
 int umx_last_graph_stats(const umx_engine* eng, int64_t* n_edges_total, int32_t* max_degree);
 
-/* Accumulated device time (ms, HIP events on the engine's launch stream) and launch count of
- * the dominant kernel family (the SO(2)/radial fp32-MFMA GEMM) since the last reset, plus the
- * FLOPs those launches performed.  bench.py uses this for the live roofline figure.            */
+/* Per-launch device time (HIP events on the launch stream) of the two GEMM kernel families since the last reset.
+ * Family 0 = split-bf16 LDS-DMA GEMM (umx_gemm_pl_kernel: SO(2) / radial-fc3 linears and their transposes),
+ * family 1 = fp32-MFMA GEMM (umx_gemm_kernel: small radial / atom-wise / readout linears; everything in fp32 mode).
+ * alg_flops = 2*M*N*K per product (what the model needs); mfma_flops = FLOPs the matrix cores executed
+ * (x6 for the 3-plane forward split, x3 for the 2-plane reverse split, x1 for fp32).  bench.py uses this for the
+ * live roofline figure.                                                                                      */
+typedef struct umx_profile_stats {
+  double ms[2];
+  int64_t launches[2];
+  double alg_flops[2];
+  double mfma_flops[2];
+} umx_profile_stats;
 int umx_profile_enable(umx_engine* eng, int on);
-int umx_profile_read(umx_engine* eng, double* gemm_ms, int64_t* gemm_launches, double* gemm_flops,
-                     int reset);
+int umx_profile_read(umx_engine* eng, umx_profile_stats* out, int reset);
 
 /* Test hook: copy a named intermediate buffer of the most recent evaluation's last chunk to the
  * host.  Returns the buffer size in bytes through *nbytes_out when host_buf == NULL.           */

@@ -75,6 +75,10 @@ int main(int argc, char** argv) {
   rep("PL 256x128 P=2 S=3", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 3, 2>, gridpl(128), q2); }));
   check("PL 256x128 P=2 S=3 vs fp32 (~1e-5 rel)");
   rep("PL 256x128 P=2 S=2", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 2, 2>, gridpl(128), q2); }));
+  rep("PL 256x128 P=3 S=2 A-nt(16)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 3, 2, 2, 16>, gridpl(128), q); }));
+  rep("PL 256x128 P=2 S=2 A-nt(16)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 2, 2, 16>, gridpl(128), q2); }));
+  rep("PL 256x128 P=2 S=2 noStores(4)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 2, 2, 4>, gridpl(128), q2); }));
+  rep("PL 256x128 P=3 S=2 noStores(4)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 3, 2, 2, 4>, gridpl(128), q); }));
   rep("PL 256x256 P=2 S=2 noMFMA(2)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 2, 4, 2>, gridpl(256), q2); }));
   rep("PL 256x256 P=2 S=2 noDMA(1)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 2, 4, 1>, gridpl(256), q2); }));
   rep("PL 256x256 P=2 S=2 noStores(4)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 2, 4, 4>, gridpl(256), q2); }));

@@ -50,6 +50,9 @@ struct ProfRec { hipEvent_t a, b; double flops; int M, N, K, amode, cplx, prec, 
 struct umx_engine {
   int dev = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // second lane: half-chunks alternate streams so HBM-bound producers overlap the other lane's GEMMs
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int n_lanes = 1;                 // UMX_STREAMS (1 or 2); 2 gives ~2.5 % on c3 but inflates event-bracketed kernel timings
   std::string err;
   // weights
   bool have_weights = false;
@@ -514,7 +517,7 @@ std::vector<float> transpose(const float* src, int rows, int cols) {
 // ================================================================================================
 extern "C" {
 
-int umx_abi_version(void) { return 1; }
+int umx_abi_version(void) { return 2; }
 
 const char* umx_last_error(const umx_engine* eng) { return eng ? eng->err.c_str() : g_create_err.c_str(); }
 
@@ -532,7 +535,10 @@ int umx_create(umx_engine** out, int device_ordinal) {
   }
   umx_engine* e = new umx_engine();
   e->dev = device_ordinal;
-  if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (const char* ev = std::getenv("UMX_STREAMS")) e->n_lanes = std::atoi(ev) >= 2 ? 2 : 1;
+  if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
     g_create_err = "umx_create: hipSetDevice/hipStreamCreate failed";
     delete e;
     return UMX_ERR_HIP;
@@ -548,6 +554,9 @@ int umx_destroy(umx_engine* eng) {
   for (auto& r : eng->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   void* ptrs[] = {eng->d_w, eng->d_dw, eng->d_bw, eng->d_gmu, eng->d_z, eng->d_sysemb, eng->arena, eng->d_deg_all, eng->d_img_edges, eng->d_io_pos, eng->d_io_e, eng->d_io_f};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  (void)hipStreamSynchronize(eng->stream2);
+  (void)hipEventDestroy(eng->ev_fork); (void)hipEventDestroy(eng->ev_join);
+  (void)hipStreamDestroy(eng->stream2);
   (void)hipStreamDestroy(eng->stream);
   delete eng;
   return UMX_OK;
@@ -890,7 +899,9 @@ int umx_energy_forces_dev(umx_engine* eng, int n_images, const float* d_pos, dou
     HIPCHK(eng, hipMemGetInfo(&fr, &tot));
     budget = (size_t)((fr + eng->arena_bytes) * 0.85);
   }
-  long max_chunk = K;
+  int lanes = (eng->n_lanes >= 2 && K >= 2) ? 2 : 1;
+  budget /= lanes;
+  long max_chunk = (K + lanes - 1) / lanes;          // at least `lanes` chunks so both streams have work
   if (const char* ev = std::getenv("UMX_MAX_CHUNK_IMAGES")) { long v = std::atol(ev); if (v > 0) max_chunk = std::min(max_chunk, v); }
   std::vector<std::pair<long, long>> chunks;   // [k0, k1)
   long need_nodes = 0, need_edges = 0;
@@ -911,23 +922,42 @@ int umx_energy_forces_dev(umx_engine* eng, int n_images, const float* d_pos, dou
   }
   if (need_nodes > eng->cap_nodes || need_edges > eng->cap_edges) {
     HIPCHK(eng, hipStreamSynchronize(s));
+    HIPCHK(eng, hipStreamSynchronize(eng->stream2));
     if (eng->arena) { HIPCHK(eng, hipFree(eng->arena)); eng->arena = nullptr; eng->arena_bytes = 0; }
     const long cn = std::max(need_nodes, eng->cap_nodes), ce = std::max(need_edges + need_edges / 50 + 1024, eng->cap_edges);
     size_t bytes = carve(nullptr, cn, ce, nullptr, eng->pl);
     long ce2 = ce;
     if (bytes > budget) { ce2 = std::max(need_edges, 1L); bytes = carve(nullptr, cn, ce2, nullptr, eng->pl); }
-    HIPCHK(eng, hipMalloc(&eng->arena, bytes));
-    eng->arena_bytes = bytes; eng->cap_nodes = cn; eng->cap_edges = ce2;
+    HIPCHK(eng, hipMalloc(&eng->arena, lanes * bytes));     // one workspace per lane
+    eng->arena_bytes = lanes * bytes; eng->cap_nodes = cn; eng->cap_edges = ce2;
   }
-  WS w;
-  carve(eng->arena, eng->cap_nodes, eng->cap_edges, &w, eng->pl);
+  WS wl[2];
+  if (lanes == 2 && eng->arena_bytes < 2 * carve(nullptr, eng->cap_nodes, eng->cap_edges, nullptr, eng->pl)) lanes = 1;   // arena was sized for one lane
+  const size_t lane_bytes = carve(eng->arena, eng->cap_nodes, eng->cap_edges, &wl[0], eng->pl);
+  if (eng->arena_bytes >= 2 * lane_bytes) carve(eng->arena + lane_bytes, eng->cap_nodes, eng->cap_edges, &wl[1], eng->pl);
   if (eng->dbg_on) eng->dbg.clear();
+  if (lanes == 2) {          // lane 1 starts after everything enqueued so far on the primary stream (degree pass, caller's work)
+    HIPCHK(eng, hipEventRecord(eng->ev_fork, s));
+    HIPCHK(eng, hipStreamWaitEvent(eng->stream2, eng->ev_fork, 0));
+  }
+  int st = UMX_OK;
+  size_t ci = 0;
   for (auto& ch : chunks) {
     const long k0 = ch.first, k1 = ch.second;
     long e = 0;
     for (long k = k0; k < k1; ++k) e += img_edges[k];
-    CHK(run_chunk(eng, w, d_pos + k0 * N * 3, eng->d_deg_all + k0 * N, k1 - k0, e, d_energy + k0, d_forces ? d_forces + k0 * N * 3 : nullptr));
+    const int lane = (lanes == 2) ? (int)(ci & 1) : 0;
+    eng->stream = lane ? eng->stream2 : s;
+    st = run_chunk(eng, wl[lane], d_pos + k0 * N * 3, eng->d_deg_all + k0 * N, k1 - k0, e, d_energy + k0, d_forces ? d_forces + k0 * N * 3 : nullptr);
+    eng->stream = s;
+    if (st != UMX_OK) break;
+    ++ci;
   }
+  if (lanes == 2) {          // join: the primary stream continues only after lane 1 has drained
+    HIPCHK(eng, hipEventRecord(eng->ev_join, eng->stream2));
+    HIPCHK(eng, hipStreamWaitEvent(s, eng->ev_join, 0));
+  }
+  if (st != UMX_OK) return st;
   return UMX_OK;
 }
 
@@ -974,8 +1004,9 @@ int umx_profile_enable(umx_engine* eng, int on) {
   return UMX_OK;
 }
 
-int umx_profile_read(umx_engine* eng, double* gemm_ms, int64_t* gemm_launches, double* gemm_flops, int reset) {
+int umx_profile_read(umx_engine* eng, umx_profile_stats* out, int reset) {
   if (!eng) return UMX_ERR_ARG;
+  if (out) std::memset(out, 0, sizeof(*out));
   HIPCHK(eng, hipSetDevice(eng->dev));
   HIPCHK(eng, hipStreamSynchronize(eng->stream));
   double ms = 0.0, fl = 0.0;
@@ -986,12 +1017,15 @@ int umx_profile_read(umx_engine* eng, double* gemm_ms, int64_t* gemm_launches, d
     HIPCHK(eng, hipEventElapsedTime(&t, eng->prof[i].a, eng->prof[i].b));
     ms += t; fl += eng->prof[i].flops;
     const ProfRec& r = eng->prof[i];
+    if (out) {
+      const int fam = r.prec > 0 ? 0 : 1;
+      out->ms[fam] += t; out->launches[fam] += 1; out->alg_flops[fam] += r.flops;
+      out->mfma_flops[fam] += r.flops * (r.prec == 3 ? 6.0 : r.prec == 2 ? 3.0 : 1.0);
+    }
     if (dump) std::fprintf(dump, "%d,%d,%d,%d,%d,%d,%d,%.6f,%.6e\n", r.M, r.N, r.K, r.amode, r.cplx, r.prec, r.gz, t, r.flops);
   }
   if (dump) std::fclose(dump);
-  if (gemm_ms) *gemm_ms = ms;
-  if (gemm_launches) *gemm_launches = (int64_t)eng->prof_used;
-  if (gemm_flops) *gemm_flops = fl;
+  (void)ms; (void)fl;
   if (reset) eng->prof_used = 0;
   return UMX_OK;
 }

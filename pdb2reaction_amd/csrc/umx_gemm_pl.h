@@ -55,11 +55,11 @@ template <int P> __device__ __forceinline__ int pl_perm(int s, int r) {
 // request one k-tile (32 columns, all planes) of A and B into the ring stage at `sbase`.
 // (A plain __device__ function: a lambda calling the LDS-DMA builtin silently drops the host-side kernel stub, and
 //  hipcc 7.2 rejects a second kernel re-using one specialization of such a function -- hence the TAG parameter.)
-template <int JA, int JB, int TA_B, int TAG>
+template <int JA, int JB, int TA_B, int TAG, int AUXA = 0>
 __device__ __forceinline__ void pl_issue(const GemmPL& p, unsigned char* sbase, const long (&a_off)[JA], const long (&b_off)[JB], long kofs, int piece) {
 #pragma unroll
   for (int j = 0; j < JA; ++j)
-    __builtin_amdgcn_global_load_lds(p.Apl + a_off[j] + kofs, (__attribute__((address_space(3))) void*)(sbase + piece + j * 4096), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(p.Apl + a_off[j] + kofs, (__attribute__((address_space(3))) void*)(sbase + piece + j * 4096), 16, 0, AUXA);
 #pragma unroll
   for (int j = 0; j < JB; ++j)
     __builtin_amdgcn_global_load_lds(p.Bpl + b_off[j] + kofs, (__attribute__((address_space(3))) void*)(sbase + TA_B + piece + j * 4096), 16, 0, 0);
@@ -131,15 +131,16 @@ __global__ __launch_bounds__(256, 1) void umx_gemm_pl_kernel(const GemmPL p) {
 
   const int nk = p.K / 32;
   constexpr int TAG = ABL * 10000 + CPLX * 1000 + P * 100 + S * 10 + WNT;
+  constexpr int AUXA = (ABL & 16) ? 2 : 0;   // dev: non-temporal A stream
 #pragma unroll
   for (int s = 0; s < S - 1; ++s)
-    if (s < nk) pl_issue<JA, JB, TA_B, TAG>(p, ring + s * STAGE_B, a_off, b_off, (long)s * 32 * P, piece);
+    if (s < nk) pl_issue<JA, JB, TA_B, TAG, AUXA>(p, ring + s * STAGE_B, a_off, b_off, (long)s * 32 * P, piece);
 
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + S - 2 < nk) wait_vmcnt<(S - 2) * G>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // everyone's tile kt landed; everyone finished reading tile kt-1
     if (kt + S - 1 < nk && !(ABL & 1))
-      pl_issue<JA, JB, TA_B, TAG>(p, ring + ((kt + S - 1) % S) * STAGE_B, a_off, b_off, (long)(kt + S - 1) * 32 * P, piece);
+      pl_issue<JA, JB, TA_B, TAG, AUXA>(p, ring + ((kt + S - 1) % S) * STAGE_B, a_off, b_off, (long)(kt + S - 1) * 32 * P, piece);
     const unsigned char* sbase = ring + (kt % S) * STAGE_B;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {

@@ -19,6 +19,12 @@ LIB_PATH = os.path.join(_HERE, "libumx.so")
 _lib = None
 
 
+class ProfileStats(C.Structure):
+    """Mirror of ``umx_profile_stats`` (include/umx.h): [0] split-bf16 PL GEMM family, [1] fp32-MFMA GEMM family."""
+
+    _fields_ = [("ms", C.c_double * 2), ("launches", C.c_int64 * 2), ("alg_flops", C.c_double * 2), ("mfma_flops", C.c_double * 2)]
+
+
 class UmxError(RuntimeError):
     """A libumx call returned a non-zero status."""
 
@@ -49,7 +55,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "umx_synchronize": ([vp], i32),
         "umx_last_graph_stats": ([vp, i64p, C.POINTER(C.c_int32)], i32),
         "umx_profile_enable": ([vp, i32], i32),
-        "umx_profile_read": ([vp, dp, i64p, dp, i32], i32),
+        "umx_profile_read": ([vp, C.POINTER(ProfileStats), i32], i32),
         "umx_debug_fetch": ([vp, C.c_char_p, vp, C.c_size_t, C.POINTER(C.c_size_t)], i32),
         "umx_debug_keep": ([vp, i32], i32),
     }
@@ -149,9 +155,11 @@ class Engine:
         self._chk(self.lib.umx_profile_enable(self._h, int(on)), "umx_profile_enable")
 
     def profile_read(self, reset: bool = True):
-        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
-        self._chk(self.lib.umx_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(fl), int(reset)), "umx_profile_read")
-        return {"gemm_ms": ms.value, "gemm_launches": int(n.value), "gemm_flops": fl.value}
+        st = ProfileStats()
+        self._chk(self.lib.umx_profile_read(self._h, C.byref(st), int(reset)), "umx_profile_read")
+        fam = [{"ms": st.ms[i], "launches": int(st.launches[i]), "alg_flops": st.alg_flops[i], "mfma_flops": st.mfma_flops[i]} for i in range(2)]
+        return {"split_bf16": fam[0], "fp32": fam[1], "gemm_ms": fam[0]["ms"] + fam[1]["ms"], "gemm_launches": fam[0]["launches"] + fam[1]["launches"],
+                "gemm_flops": fam[0]["alg_flops"] + fam[1]["alg_flops"]}
 
     def debug_keep(self, on: bool = True):
         self._chk(self.lib.umx_debug_keep(self._h, int(on)), "umx_debug_keep")

@@ -26,5 +26,5 @@ for k in ks:
     flops = 30.98e6 * ne
     print(f"N={n} K={k} edges={ne} maxdeg={md}: {dt*1e3:.1f} ms/call  {k*n/dt:.3e} atom-img/s  "
           f"alg {flops/dt/1e12:.1f} TFLOP/s | gemm {pr['gemm_ms']:.1f} ms over {pr['gemm_launches']} launches, "
-          f"{pr['gemm_flops']/pr['gemm_ms']/1e9:.1f} TFLOP/s in-kernel | sumF {np.abs(f.sum(1)).max():.2e}", flush=True)
+          f"{pr['gemm_flops']/max(pr['gemm_ms'],1e-9)/1e9:.1f} TFLOP/s in-kernel | sumF {np.abs(f.sum(1)).max():.2e}", flush=True)
     t = time.time(); e2, _ = eng.energy_forces(p, forces=False); print(f"   energy-only {1e3*(time.time()-t):.1f} ms")

@@ -182,7 +182,7 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
   q.Cp = Cp; q.ldc = ldc; q.offC = offC; q.offCi = offCi; q.bias = bias; q.conj = conj; q.M = (int)M; q.N = N; q.K = K;
   const int bmr = cplx ? 128 : 256, bnc = cplx ? 64 : 128;
   const long nM = (M + bmr - 1) / bmr, nN = (N + bnc - 1) / bnc;
-  dim3 grid((unsigned)(((nM + 7) / 8) * 8 * nN)), block(256);
+  dim3 grid((unsigned)(((nM + 7) / 8) * 8 * nN)), block(512);
   ProfRec* pr = nullptr;
   if (eng->prof_on) {
     if (eng->prof_used == eng->prof.size()) {
@@ -194,11 +194,11 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
     HIPCHK(eng, hipEventRecord(pr->a, eng->stream));
   }
   if (P == 3) {
-    if (cplx) hipLaunchKernelGGL((umx_gemm_pl_kernel<1, 3, 2, 2>), grid, block, 0, eng->stream, q);
-    else hipLaunchKernelGGL((umx_gemm_pl_kernel<0, 3, 2, 2>), grid, block, 0, eng->stream, q);
+    if (cplx) hipLaunchKernelGGL((umx_gemm_pl_kernel<1, 3, 2, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
+    else hipLaunchKernelGGL((umx_gemm_pl_kernel<0, 3, 2, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
   } else {
-    if (cplx) hipLaunchKernelGGL((umx_gemm_pl_kernel<1, 2, 2, 2>), grid, block, 0, eng->stream, q);
-    else hipLaunchKernelGGL((umx_gemm_pl_kernel<0, 2, 2, 2>), grid, block, 0, eng->stream, q);
+    if (cplx) hipLaunchKernelGGL((umx_gemm_pl_kernel<1, 2, 3, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
+    else hipLaunchKernelGGL((umx_gemm_pl_kernel<0, 2, 3, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
   }
   HIPCHK(eng, hipGetLastError());
   if (pr) HIPCHK(eng, hipEventRecord(pr->b, eng->stream));

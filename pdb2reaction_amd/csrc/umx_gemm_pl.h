@@ -55,35 +55,43 @@ template <int P> __device__ __forceinline__ int pl_perm(int s, int r) {
 // request one k-tile (32 columns, all planes) of A and B into the ring stage at `sbase`.
 // (A plain __device__ function: a lambda calling the LDS-DMA builtin silently drops the host-side kernel stub, and
 //  hipcc 7.2 rejects a second kernel re-using one specialization of such a function -- hence the TAG parameter.)
-template <int JA, int JB, int TA_B, int TAG, int AUXA = 0>
+template <int JA, int JB, int TA_B, int WSTR, int TAG, int AUXA = 0>
 __device__ __forceinline__ void pl_issue(const GemmPL& p, unsigned char* sbase, const long (&a_off)[JA], const long (&b_off)[JB], long kofs, int piece) {
 #pragma unroll
   for (int j = 0; j < JA; ++j)
-    __builtin_amdgcn_global_load_lds(p.Apl + a_off[j] + kofs, (__attribute__((address_space(3))) void*)(sbase + piece + j * 4096), 16, 0, AUXA);
+    __builtin_amdgcn_global_load_lds(p.Apl + a_off[j] + kofs, (__attribute__((address_space(3))) void*)(sbase + piece + j * WSTR), 16, 0, AUXA);
 #pragma unroll
   for (int j = 0; j < JB; ++j)
-    __builtin_amdgcn_global_load_lds(p.Bpl + b_off[j] + kofs, (__attribute__((address_space(3))) void*)(sbase + TA_B + piece + j * 4096), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(p.Bpl + b_off[j] + kofs, (__attribute__((address_space(3))) void*)(sbase + TA_B + piece + j * WSTR), 16, 0, 0);
 }
 
-// WNT = MFMA tiles per wave along N (4 -> 256-wide block tile, 2 -> 128-wide).
-// ABL (dev only): 1 = no DMA in the main loop, 2 = no MFMA, 4 = no C stores, 8 = no LDS fragment reads
-template <int CPLX, int P, int S, int WNT, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void umx_gemm_pl_kernel(const GemmPL p) {
-  constexpr int BN = 64 * WNT;                 // block tile columns (B rows)
+// Geometry: WVM x WVN waves, each owning WMT x WNT MFMA tiles (32x32): block tile = (32*WVM*WMT) x (32*WVN*WNT).
+//   <.., WVM=2, WVN=2, WMT=4, WNT=2>  256x128, 4 waves (one per SIMD, 128 accumulator registers)
+//   <.., WVM=4, WVN=2, WMT=2, WNT=2>  256x128, 8 waves (two per SIMD: one wave's LDS-read latency hides under the other's MFMAs)
+//   <.., WVM=2, WVN=4, WMT=4, WNT=2>  256x256, 8 waves (half the fill bytes per FLOP; P=2 only, LDS)
+// ABL (dev only): 1 = no DMA in the main loop, 2 = no MFMA, 4 = no C stores, 8 = no LDS fragment reads, 16 = nt A stream
+template <int CPLX, int P, int S, int WVM, int WVN, int WMT, int WNT, int ABL = 0>
+__global__ __launch_bounds__(64 * WVM * WVN, 1) void umx_gemm_pl_kernel(const GemmPL p) {
+  constexpr int NT = 64 * WVM * WVN;           // threads
+  constexpr int BM = 32 * WVM * WMT;           // block tile rows (A rows)
+  constexpr int BN = 32 * WVN * WNT;           // block tile columns (B rows)
+  static_assert(!CPLX || (WMT % 2 == 0 && WNT % 2 == 0), "complex tiles need re/im and A/B halves in every wave");
   constexpr int SEG = 4 * P;                   // 16-B chunks per row per k-tile
   constexpr int ROWB = SEG * 16;               // bytes per row per k-tile (128 or 192)
-  constexpr int TA_B = 256 * ROWB;
+  constexpr int TA_B = BM * ROWB;
   constexpr int TB_B = BN * ROWB;
   constexpr int STAGE_B = TA_B + TB_B;
   static_assert(S * STAGE_B <= 160 * 1024, "ring does not fit the 160 KiB LDS");
   __shared__ __attribute__((aligned(1024))) unsigned char ring[S * STAGE_B];
-  constexpr int BMR = CPLX ? 128 : 256;        // logical rows (edges) per block
+  constexpr int BMR = CPLX ? BM / 2 : BM;      // logical rows (edges) per block
   constexpr int BNC = CPLX ? BN / 2 : BN;      // logical cols (channels) per block
-  constexpr int JA = SEG;                      // A chunks per lane per k-tile (256 rows * SEG / 256 lanes)
-  constexpr int JB = BN * SEG / 256;
+  constexpr int JA = BM * SEG / NT;            // A chunks per lane per k-tile
+  constexpr int JB = BN * SEG / NT;
+  static_assert(BM * SEG % NT == 0 && BN * SEG % NT == 0, "tile does not divide over the threads");
   constexpr int G = JA + JB;                   // global_load_lds instructions per wave per k-tile
+  constexpr int WSTR = NT * 16;                // LDS bytes covered by one DMA round of the whole block
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WVN, wn = wave % WVN;
   const int l31 = lane & 31, h = lane >> 5;
 
   const int nN = (p.N + BNC - 1) / BNC;
@@ -96,60 +104,62 @@ __global__ __launch_bounds__(256, 1) void umx_gemm_pl_kernel(const GemmPL p) {
   long a_off[JA], b_off[JB];
 #pragma unroll
   for (int j = 0; j < JA; ++j) {
-    const int c = tid + 256 * j, trow = c / SEG, s = c % SEG;
+    const int c = tid + NT * j, trow = c / SEG, s = c % SEG;
     long grow; int offA;
-    if (CPLX) { grow = (long)mt * 128 + (trow & 127); offA = (trow >> 7) ? p.offA1 : p.offA0; }
-    else      { grow = (long)mt * 256 + trow;         offA = p.offA0; }
+    if (CPLX) { grow = (long)mt * BMR + (trow % BMR); offA = (trow / BMR) ? p.offA1 : p.offA0; }
+    else      { grow = (long)mt * BM + trow;          offA = p.offA0; }
     if (grow >= p.M) grow = p.M - 1;
     a_off[j] = grow * p.lda + (long)offA * P + pl_perm<P>(s, trow) * 8;
   }
 #pragma unroll
   for (int j = 0; j < JB; ++j) {
-    const int c = tid + 256 * j, trow = c / SEG, s = c % SEG;
+    const int c = tid + NT * j, trow = c / SEG, s = c % SEG;
     int brow;
     if (CPLX) { int cc = nt * BNC + (trow % BNC); if (cc >= p.N) cc = p.N - 1; brow = (trow / BNC) * p.bHalf + cc; }
     else      { brow = nt * BN + trow; if (brow >= p.N) brow = p.N - 1; }
     b_off[j] = (long)brow * p.ldb + pl_perm<P>(s, trow) * 8;
   }
-  const int piece = __builtin_amdgcn_readfirstlane(wave * 1024);   // this wave's 1-KiB piece inside a 4-KiB group
+  const int piece = __builtin_amdgcn_readfirstlane(wave * 1024);   // this wave's 1-KiB piece inside one DMA round
 
-  f32x16 acc[4][WNT];
+  f32x16 acc[WMT][WNT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < WMT; ++i)
 #pragma unroll
     for (int j = 0; j < WNT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // fragment rows inside the tile
-  int a_row[4], b_row[WNT];
+  // CPLX: tile t of a wave = (half = t / (W?T/2), group = t % (W?T/2)); halves are re/im rows and A/B weight rows
+  int a_row[WMT], b_row[WNT];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) a_row[t] = CPLX ? ((t >> 1) * 128 + wm * 64 + (t & 1) * 32 + l31) : (wm * 128 + t * 32 + l31);
+  for (int t = 0; t < WMT; ++t)
+    a_row[t] = CPLX ? ((t / (WMT / 2)) * BMR + wm * (16 * WMT) + (t % (WMT / 2)) * 32 + l31) : (wm * (32 * WMT) + t * 32 + l31);
 #pragma unroll
   for (int t = 0; t < WNT; ++t)
-    b_row[t] = CPLX ? ((t / (WNT / 2)) * BNC + wn * (BNC / 2) + (t % (WNT / 2)) * 32 + l31) : (wn * (BN / 2) + t * 32 + l31);
+    b_row[t] = CPLX ? ((t / (WNT / 2)) * BNC + wn * (16 * WNT) + (t % (WNT / 2)) * 32 + l31) : (wn * (32 * WNT) + t * 32 + l31);
 
   const int nk = p.K / 32;
-  constexpr int TAG = ABL * 10000 + CPLX * 1000 + P * 100 + S * 10 + WNT;
+  constexpr int TAG = ((((ABL * 2 + CPLX) * 4 + P) * 8 + S) * 8 + WVM) * 64 + WVN * 16 + WMT * 2 + WNT / 2;
   constexpr int AUXA = (ABL & 16) ? 2 : 0;   // dev: non-temporal A stream
 #pragma unroll
   for (int s = 0; s < S - 1; ++s)
-    if (s < nk) pl_issue<JA, JB, TA_B, TAG, AUXA>(p, ring + s * STAGE_B, a_off, b_off, (long)s * 32 * P, piece);
+    if (s < nk) pl_issue<JA, JB, TA_B, WSTR, TAG, AUXA>(p, ring + s * STAGE_B, a_off, b_off, (long)s * 32 * P, piece);
 
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + S - 2 < nk) wait_vmcnt<(S - 2) * G>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // everyone's tile kt landed; everyone finished reading tile kt-1
     if (kt + S - 1 < nk && !(ABL & 1))
-      pl_issue<JA, JB, TA_B, TAG, AUXA>(p, ring + ((kt + S - 1) % S) * STAGE_B, a_off, b_off, (long)(kt + S - 1) * 32 * P, piece);
+      pl_issue<JA, JB, TA_B, WSTR, TAG, AUXA>(p, ring + ((kt + S - 1) % S) * STAGE_B, a_off, b_off, (long)(kt + S - 1) * 32 * P, piece);
     const unsigned char* sbase = ring + (kt % S) * STAGE_B;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t a[4][P], b[WNT][P];
+      bf16x8_t a[WMT][P], b[WNT][P];
 #pragma unroll
       for (int q = 0; q < P; ++q) {
         const int u = q * 4 + ks * 2 + h;      // source chunk wanted: plane q, k-chunk 2 ks + h
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < WMT; ++t) {
           if (ABL & 8) { for (int z = 0; z < 8; ++z) a[t][q][z] = (__bf16)(float)(kt + t); }
           else a[t][q] = *reinterpret_cast<const bf16x8_t*>(sbase + a_row[t] * ROWB + pl_perm<P>(u, a_row[t]) * 16);
         }
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(256, 1) void umx_gemm_pl_kernel(const GemmPL p) {
         for (int qa = 0; qa <= ord; ++qa) {
           const int qb = ord - qa;
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < WMT; ++i)
 #pragma unroll
             for (int j = 0; j < WNT; ++j) {
               if (ABL & 2) acc[i][j][0] += (float)a[i][qa][0] * (float)b[j][qb][1];
@@ -180,24 +190,24 @@ __global__ __launch_bounds__(256, 1) void umx_gemm_pl_kernel(const GemmPL p) {
   const bool full = ((long)mt * BMR + BMR <= p.M) && (nt * BNC + BNC <= p.N);
   if (ABL & 4) {
     float sum = 0.f;
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < WNT; ++j) for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+    for (int i = 0; i < WMT; ++i) for (int j = 0; j < WNT; ++j) for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
     if (sum == 1.2345f) p.Cp[0] = sum;
     return;
   }
   if (CPLX) {
 #pragma unroll
-    for (int eg = 0; eg < 2; ++eg)
+    for (int eg = 0; eg < WMT / 2; ++eg)
 #pragma unroll
       for (int cg = 0; cg < WNT / 2; ++cg) {
-        const int chan = nt * BNC + wn * (BNC / 2) + cg * 32 + l31;
-        const long e0 = (long)mt * 128 + wm * 64 + eg * 32 + 4 * h;
+        const int chan = nt * BNC + wn * (16 * WNT) + cg * 32 + l31;
+        const long e0 = (long)mt * BMR + wm * (16 * WMT) + eg * 32 + 4 * h;
         float* c = p.Cp + e0 * p.ldc + chan;
         if (full) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float* cr = c + (long)((r & 3) + 8 * (r >> 2)) * p.ldc;
-            cr[p.offC] = acc[eg][cg][r] - p.conj * acc[2 + eg][WNT / 2 + cg][r];
-            cr[p.offCi] = acc[2 + eg][cg][r] + p.conj * acc[eg][WNT / 2 + cg][r];
+            cr[p.offC] = acc[eg][cg][r] - p.conj * acc[WMT / 2 + eg][WNT / 2 + cg][r];
+            cr[p.offCi] = acc[WMT / 2 + eg][cg][r] + p.conj * acc[eg][WNT / 2 + cg][r];
           }
         } else if (chan < p.N) {
 #pragma unroll
@@ -205,8 +215,8 @@ __global__ __launch_bounds__(256, 1) void umx_gemm_pl_kernel(const GemmPL p) {
             const int dr = (r & 3) + 8 * (r >> 2);
             if (e0 + dr < p.M) {
               float* cr = c + (long)dr * p.ldc;
-              cr[p.offC] = acc[eg][cg][r] - p.conj * acc[2 + eg][WNT / 2 + cg][r];
-              cr[p.offCi] = acc[2 + eg][cg][r] + p.conj * acc[eg][WNT / 2 + cg][r];
+              cr[p.offC] = acc[eg][cg][r] - p.conj * acc[WMT / 2 + eg][WNT / 2 + cg][r];
+              cr[p.offCi] = acc[WMT / 2 + eg][cg][r] + p.conj * acc[eg][WNT / 2 + cg][r];
             }
           }
         }
@@ -215,15 +225,15 @@ __global__ __launch_bounds__(256, 1) void umx_gemm_pl_kernel(const GemmPL p) {
     float bv[WNT];
 #pragma unroll
     for (int j = 0; j < WNT; ++j) {
-      const int col = nt * BN + wn * (BN / 2) + j * 32 + l31;
+      const int col = nt * BN + wn * (32 * WNT) + j * 32 + l31;
       bv[j] = (p.bias && col < p.N) ? p.bias[col] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WMT; ++i)
 #pragma unroll
       for (int j = 0; j < WNT; ++j) {
-        const int col = nt * BN + wn * (BN / 2) + j * 32 + l31;
-        const long row0 = (long)mt * 256 + wm * 128 + i * 32 + 4 * h;
+        const int col = nt * BN + wn * (32 * WNT) + j * 32 + l31;
+        const long row0 = (long)mt * BM + wm * (32 * WMT) + i * 32 + 4 * h;
         float* c = p.Cp + row0 * p.ldc + p.offC + col;
         if (full) {
 #pragma unroll

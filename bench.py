@@ -40,6 +40,17 @@ PEAK_FP32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparse headline)
 
 
+def pmc_traffic_per_launch(split: bool):
+    """HBM bytes per launch of the dominant GEMM family from the committed rocprofv3 PMC passes (profiles/), or None.
+    bench.py cannot collect PMC counters itself; the figure is for exactly this workload and build."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")
+    try:
+        d = json.load(open(path))
+        return float(d["dominant_family"]["hbm_bytes_per_launch_avg"]) if split else None
+    except Exception:
+        return None
+
+
 def usable_cores() -> int:
     """Host cores this process may actually use (affinity and cgroup quota, not the machine total)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -180,7 +191,8 @@ def main():
                                    f"(batched UMA-S E+F of all images + string update), UMA-S shapes, synthetic weights",
                        "atoms": n, "images": k, "directed_edges_per_iteration": int(edges_iter), "max_degree": maxdeg,
                        "parallelism": f"images sharded {k}/{world} per GPU, 1 all-gather/iteration" if world > 1 else "single GPU, all images batched"},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                         "traffic": pmc_traffic_per_launch(split) if (n == 2000 and k == 16 and world == 1) else None,
                          "kernel": ("umx_gemm_pl_kernel<*> (split-bf16 LDS-DMA GEMM: SO(2)/radial linears + transposes, rank 0)" if split
                                     else "umx_gemm_kernel<*> (fp32-MFMA GEMM, rank 0)"),
                          "launches": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),

@@ -87,3 +87,40 @@ def test_error_behaviour(setup):
         c._core.compute(imgs[0], forces=True, hessian=True)
     with pytest.raises(ValueError):
         c.get_energy(elem, np.zeros(9))                 # wrong atom count for the bound system
+
+
+class FakeAtoms:
+    """Minimal ASE-Atoms-like object (ASE is not installed here)."""
+
+    def __init__(self, z, pos, charge=0, spin=1):
+        self.numbers = np.asarray(z)
+        self._p = np.asarray(pos, dtype=float)
+        self.info = {"charge": charge, "spin": spin}
+        self.calc = None
+
+    def get_positions(self):
+        return self._p
+
+    def get_atomic_numbers(self):
+        return self.numbers
+
+
+def test_ase_style_calculator(oracle, setup):
+    """Secondary boundary (reference path_opt.py:351-363,418-423): eV / eV/A, atoms.info charge & spin honoured."""
+    from pdb2reaction_amd.ase_calculator import UMXCalculator
+
+    z, elem, imgs = setup
+    calc = UMXCalculator(task_name="omol")
+    images = [FakeAtoms(z, imgs[k].astype(np.float32)) for k in range(3)]
+    for im in images:
+        im.calc = calc
+    e0 = calc.get_potential_energy(images[0])
+    f0 = calc.get_forces(images[0])
+    e_ref, f_ref = oracle.energy_forces(z, imgs[0].astype(np.float32).astype(np.float64))
+    assert abs(e0 - e_ref) <= 1e-4 and np.abs(f0 - f_ref).max() <= 1e-3 and f0.dtype == np.float64
+    eb, fb = calc.calculate_images(images)
+    assert eb[0] == e0 and np.array_equal(fb[0], f0) and fb.shape == (3, 14, 3)
+    charged = FakeAtoms(z, imgs[0].astype(np.float32), charge=-1, spin=2)
+    e_c = calc.get_potential_energy(charged)
+    e_cref, _ = oracle.energy_forces(z, imgs[0].astype(np.float32).astype(np.float64), charge=-1, spin=2, forces=False)
+    assert abs(e_c - e_cref) <= 1e-4 and abs(e_c - e0) > 1e-3

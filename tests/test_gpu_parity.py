@@ -267,3 +267,17 @@ def test_c3_forces_are_energy_gradient(engine, c3):
     em, _ = engine.energy_forces(imgs[0] - h * d, forces=False)
     fd = -(ep[0] - em[0]) / (2 * h)
     assert abs(fd - float((f[0].astype(np.float64) * d).sum())) <= 2e-2 * max(1.0, abs(fd))
+
+
+def test_c5_size_invariants(engine):
+    """Largest BASELINE config (c5: ~20 000 atoms, 1.6 M directed edges per image): runs inside the HBM workspace budget,
+    chunked == single bit for bit, Newton's third law."""
+    z, imgs, _ = synth.make_images(20000, 2)
+    engine.set_system(z)
+    e1, f1 = engine.energy_forces(imgs[:1])
+    ne, maxdeg = engine.graph_stats()
+    assert ne > 1_500_000 and maxdeg < 300
+    assert np.isfinite(e1).all() and np.isfinite(f1).all()
+    assert np.abs(f1.astype(np.float64).sum(axis=1)).max() <= 2e-3
+    e2, f2 = engine.energy_forces(imgs)
+    assert e2[0] == e1[0] and np.array_equal(f2[0], f1[0])

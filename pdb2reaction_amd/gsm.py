@@ -1,0 +1,280 @@
+"""Batched Growing-String driver.
+
+The reference runs ``GrowingString(images, calc_getter, **GS_KW)`` + ``StringOptimizer(gs, **STOPT_KW).run()`` from
+pysisyphus (reference ``path_opt.py:959-977``, ``path_search.py:664-681``); pysisyphus evaluates the images one after
+another through the shared calculator.  This driver restates that loop so that ALL images needing an evaluation in a
+cycle go through ONE ``calc.get_forces_batch`` call (and, across GPUs, one sharded call + all-gather).
+
+PARITY UNPINNED: pysisyphus is not installed here, so the loop follows the published GSM semantics summarised in
+SURVEY.md Appendix B -- frontier growth at ``perp_thresh``, equal-arc ("equi") reparametrisation, perpendicular-force
+steps scaled to ``max_step``, climbing image once the fully grown string is below ``climb_rms``, convergence on the
+``thresh`` presets of reference ``opt.py:176-187`` -- not pysisyphus' source.  Keyword names and defaults are those of
+reference ``GS_KW`` / ``STOPT_KW`` (``path_opt.py:168-200``); ``climb_lanczos`` (Lanczos HEI tangent) and DLC
+coordinates are not implemented: the climbing tangent is the string tangent, coordinates are Cartesian.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .string import select_hei_index
+
+# reference path_opt.py:168-185
+GS_KW: Dict[str, Any] = {
+    "fix_first": True, "fix_last": True, "max_nodes": 10, "perp_thresh": 5e-3, "reparam_check": "rms",
+    "reparam_every": 1, "reparam_every_full": 1, "param": "equi", "max_micro_cycles": 10, "reset_dlc": True,
+    "climb": True, "climb_rms": 5e-4, "climb_lanczos": True, "climb_lanczos_rms": 5e-4, "climb_fixed": False,
+    "scheduler": None,
+}
+# reference path_opt.py:188-200 (+ max_step / thresh from OPT_BASE_KW, opt.py:172-187)
+STOPT_KW: Dict[str, Any] = {
+    "type": "string", "stop_in_when_full": 300, "align": False, "scale_step": "global", "max_cycles": 300, "dump": False,
+    "dump_restart": False, "reparam_thresh": 0.0, "coord_diff_thresh": 0.0, "out_dir": "./result_path_opt/",
+    "print_every": 10, "max_step": 0.1, "thresh": "gau_loose",
+}
+# convergence presets in Hartree/Bohr and Bohr: (max_force, rms_force, max_step, rms_step) -- reference opt.py:176-187
+THRESH = {
+    "gau_loose": (2.5e-3, 1.7e-3, 1.0e-2, 6.7e-3),
+    "gau": (4.5e-4, 3.0e-4, 1.8e-3, 1.2e-3),
+    "gau_tight": (1.5e-5, 1.0e-5, 6.0e-5, 4.0e-5),
+    "gau_vtight": (2.0e-6, 1.0e-6, 6.0e-6, 4.0e-6),
+}
+
+
+@dataclass
+class GSMResult:
+    coords: np.ndarray              # (K, 3N) Bohr
+    energies: np.ndarray            # (K,) Hartree
+    converged: bool
+    cycles: int
+    fully_grown: bool
+    hei_index: int
+    force_evaluations: int          # image evaluations (sum over cycles of images in the batch)
+    history: List[Dict[str, float]] = field(default_factory=list)
+
+
+def _tangents(x: np.ndarray) -> np.ndarray:
+    t = np.empty_like(x)
+    t[1:-1] = x[2:] - x[:-2]
+    t[0] = x[1] - x[0]
+    t[-1] = x[-1] - x[-2]
+    return t / np.maximum(np.linalg.norm(t, axis=1, keepdims=True), 1e-30)
+
+
+def _place(x: np.ndarray, targets: np.ndarray) -> np.ndarray:
+    """Points at normalised arc-length positions `targets` (in [0,1]) along the polyline through x."""
+    seg = np.linalg.norm(x[1:] - x[:-1], axis=1)
+    s = np.concatenate([[0.0], np.cumsum(seg)])
+    total = s[-1] if s[-1] > 0 else 1.0
+    out = np.empty((len(targets), x.shape[1]))
+    for n, tg in enumerate(targets):
+        u = tg * total
+        i = int(np.clip(np.searchsorted(s, u, side="right"), 1, len(s) - 1))
+        w = (u - s[i - 1]) / max(s[i] - s[i - 1], 1e-30)
+        out[n] = x[i - 1] * (1 - w) + x[i] * w
+    return out
+
+
+class GrowingStringDriver:
+    """Growing string between two endpoints; every cycle issues one batched E+F call.
+
+    calc: object with ``get_forces_batch(atoms, coords[K,3N] Bohr) -> {"energy": (K,), "forces": (K,3N)}``
+    (``pdb2reaction_amd.uma_pysis.uma_pysis`` or any stand-in); ``evaluate`` may override how a batch is evaluated
+    (e.g. ``ShardedImageEvaluator`` for one-process-per-GPU sharding).
+    """
+
+    def __init__(self, atoms: Sequence[str], reactant: np.ndarray, product: np.ndarray, calc: Any = None,
+                 evaluate: Optional[Callable[[np.ndarray], Any]] = None, gs_kw: Optional[Dict[str, Any]] = None,
+                 stopt_kw: Optional[Dict[str, Any]] = None, log: Optional[Callable[[str], None]] = None):
+        self.atoms = list(atoms)
+        self.gs = {**GS_KW, **(gs_kw or {})}
+        self.opt = {**STOPT_KW, **(stopt_kw or {})}
+        if self.gs["param"] != "equi":
+            raise NotImplementedError("only param='equi' (equal arc length) is implemented")
+        r = np.asarray(reactant, dtype=np.float64).reshape(-1)
+        p = np.asarray(product, dtype=np.float64).reshape(-1)
+        if r.shape != p.shape or r.size != 3 * len(self.atoms):
+            raise ValueError("reactant/product must both be (3N,) for the given atoms")
+        self.calc, self._evaluate, self.log = calc, evaluate, (log or (lambda s: None))
+        self.max_images = int(self.gs["max_nodes"]) + 2
+        step = 1.0 / (self.max_images - 1)
+        if self.max_images <= 3:
+            self.left, self.right = [r], [p]
+            if self.max_images == 3:
+                self.left.append(0.5 * (r + p))
+        else:                                                # endpoints + first frontier node on either side
+            self.left = [r, r + step * (p - r)]
+            self.right = [p - step * (p - r), p]
+        self.energies: Optional[np.ndarray] = None
+        self.forces: Optional[np.ndarray] = None
+        self.n_eval = 0
+        self._lbfgs_s: List[np.ndarray] = []
+        self._lbfgs_y: List[np.ndarray] = []
+        self._prev = None
+
+    # ---- helpers -------------------------------------------------------------------------------------
+    @property
+    def coords(self) -> np.ndarray:
+        return np.stack(self.left + self.right)
+
+    @property
+    def fully_grown(self) -> bool:
+        return len(self.left) + len(self.right) >= self.max_images
+
+    def _set_coords(self, x: np.ndarray):
+        nl = len(self.left)
+        self.left = [x[i].copy() for i in range(nl)]
+        self.right = [x[i].copy() for i in range(nl, len(x))]
+
+    def _eval(self, x: np.ndarray, need: np.ndarray):
+        """Batched E+F for the images flagged in `need`."""
+        idx = np.nonzero(need)[0]
+        if self.energies is None or len(self.energies) != len(x):
+            self.energies, self.forces = np.zeros(len(x)), np.zeros_like(x)
+        if len(idx) == 0:
+            return
+        if self._evaluate is not None:
+            e, f = self._evaluate(x[idx])
+        else:
+            res = self.calc.get_forces_batch(self.atoms, x[idx])
+            e, f = res["energy"], res["forces"]
+        self.energies[idx] = np.asarray(e, dtype=np.float64)
+        self.forces[idx] = np.asarray(f, dtype=np.float64).reshape(len(idx), -1)
+        self.n_eval += len(idx)
+
+    def _reparametrize(self, x: np.ndarray) -> np.ndarray:
+        k, nl = len(x), len(self.left)
+        if self.fully_grown:
+            tg = np.linspace(0.0, 1.0, k)
+        else:                                                # growing: left nodes at i*step, right nodes mirrored from the end
+            step = 1.0 / (self.max_images - 1)
+            tg = np.concatenate([np.arange(nl) * step, 1.0 - np.arange(k - nl - 1, -1, -1) * step])
+        out = _place(x, tg)
+        out[0], out[-1] = x[0], x[-1]
+        return out
+
+    def _grow(self, x: np.ndarray, fperp_rms: np.ndarray) -> bool:
+        """Add a node next to a frontier whose perpendicular force is below perp_thresh; True if the string changed."""
+        grew = False
+        nl = len(self.left)
+        for side in ("left", "right"):
+            if self.fully_grown:
+                break
+            fl, fr = self.left[-1], self.right[0]
+            gap_nodes = self.max_images - len(self.left) - len(self.right)
+            frontier = nl - 1 if side == "left" else nl
+            if fperp_rms[frontier] >= self.gs["perp_thresh"]:
+                continue
+            d = (fr - fl) / (gap_nodes + 1)
+            if side == "left":
+                self.left.append(fl + d)
+            else:
+                self.right.insert(0, fr - d)
+            grew = True
+        return grew
+
+    # ---- main loop -----------------------------------------------------------------------------------
+    def run(self) -> GSMResult:
+        gs, opt = self.gs, self.opt
+        max_f, rms_f, _, _ = THRESH[opt["thresh"]] if isinstance(opt["thresh"], str) else opt["thresh"]
+        history: List[Dict[str, float]] = []
+        converged = False
+        full_cycles = 0
+        need = None
+        climbing = False
+        cycle = 0
+        for cycle in range(1, int(opt["max_cycles"]) + 1):
+            x = self.coords
+            k = len(x)
+            if need is None or len(need) != k:
+                need = np.ones(k, dtype=bool)
+            self._eval(x, need)
+            moving = np.ones(k, dtype=bool)
+            moving[0] = not gs["fix_first"]
+            moving[-1] = not gs["fix_last"]
+            t = _tangents(x)
+            f = self.forces
+            fpar = np.einsum("ij,ij->i", f, t)[:, None] * t
+            fperp = f - fpar
+            fperp[~moving] = 0.0
+            n_dof = x.shape[1]
+            rms_img = np.sqrt((fperp ** 2).sum(1) / n_dof)
+            rms_all = float(np.sqrt((fperp[moving] ** 2).mean())) if moving.any() else 0.0
+            max_all = float(np.abs(fperp[moving]).max()) if moving.any() else 0.0
+            hei = select_hei_index(self.energies)
+            full = self.fully_grown
+            if full and gs["climb"] and not climbing and rms_all <= gs["climb_rms"] and 0 < hei < k - 1:
+                climbing = True
+                self._lbfgs_s.clear(); self._lbfgs_y.clear(); self._prev = None
+            step_force = fperp.copy()
+            if climbing and 0 < hei < k - 1:
+                step_force[hei] = f[hei] - 2.0 * fpar[hei]           # invert the parallel component on the climbing image
+            history.append({"cycle": cycle, "images": k, "rms_fperp": rms_all, "max_fperp": max_all, "e_hei": float(self.energies[hei]),
+                            "climbing": float(climbing)})
+            if cycle % max(int(opt["print_every"]), 1) == 0:
+                self.log(f"cycle {cycle:4d} images {k:3d} rms(F_perp) {rms_all:.3e} max {max_all:.3e} E_HEI {self.energies[hei]:.8f}")
+            if full:
+                full_cycles += 1
+                ci_ok = True
+                if climbing:
+                    ci = step_force[hei]
+                    ci_ok = np.abs(ci).max() <= max_f and np.sqrt((ci ** 2).mean()) <= rms_f
+                if max_all <= max_f and rms_all <= rms_f and ci_ok and (climbing or not gs["climb"] or not (0 < hei < k - 1)):
+                    converged = True
+                    break
+                if full_cycles > int(opt["stop_in_when_full"]):
+                    break
+            # ---- step: steepest descent while growing, L-BFGS once fully grown (history reset on any size change)
+            g = -step_force[moving].reshape(-1)
+            direction = -g
+            if full:
+                xm = x[moving].reshape(-1)
+                if self._prev is not None and len(self._prev[0]) == len(xm):
+                    s_, y_ = xm - self._prev[0], g - self._prev[1]
+                    if float(s_ @ y_) > 1e-12:
+                        self._lbfgs_s.append(s_); self._lbfgs_y.append(y_)
+                        self._lbfgs_s, self._lbfgs_y = self._lbfgs_s[-10:], self._lbfgs_y[-10:]
+                self._prev = (xm.copy(), g.copy())
+                q = g.copy()
+                al = []
+                for s_, y_ in zip(reversed(self._lbfgs_s), reversed(self._lbfgs_y)):
+                    a = float(s_ @ q) / float(y_ @ s_); al.append(a); q -= a * y_
+                if self._lbfgs_s:
+                    q *= float(self._lbfgs_s[-1] @ self._lbfgs_y[-1]) / float(self._lbfgs_y[-1] @ self._lbfgs_y[-1])
+                for (s_, y_), a in zip(zip(self._lbfgs_s, self._lbfgs_y), reversed(al)):
+                    b = float(y_ @ q) / float(y_ @ s_); q += (a - b) * s_
+                direction = -q
+                if float(direction @ g) >= 0:                   # not a descent direction: fall back
+                    direction = -g
+                    self._lbfgs_s.clear(); self._lbfgs_y.clear()
+            biggest = np.abs(direction).max()
+            if biggest > opt["max_step"]:                         # scale_step="global"
+                direction = direction * (opt["max_step"] / biggest)
+            xn = x.copy()
+            xn[moving] = x[moving] + direction.reshape(-1, n_dof)
+            # ---- reparametrise / grow
+            every = gs["reparam_every_full"] if full else gs["reparam_every"]
+            self._set_coords(xn)
+            changed = False
+            if not full:
+                changed = self._grow(xn, rms_img)
+            if changed or (every and cycle % int(every) == 0):
+                xr = self._reparametrize(self.coords)
+                if climbing and 0 < hei < len(xr) - 1 and len(xr) == k:
+                    xr[hei] = self.coords[hei]                    # the climbing image is not redistributed
+                self._set_coords(xr)
+            if changed:
+                self._lbfgs_s.clear(); self._lbfgs_y.clear(); self._prev = None
+                self.energies, self.forces = None, None
+                need = None
+            else:
+                need = np.ones(len(self.coords), dtype=bool)
+                need[0] = not gs["fix_first"]
+                need[-1] = not gs["fix_last"]
+        x = self.coords
+        if self.energies is None or len(self.energies) != len(x):
+            self._eval(x, np.ones(len(x), dtype=bool))
+        return GSMResult(coords=x, energies=self.energies.copy(), converged=converged, cycles=cycle, fully_grown=self.fully_grown,
+                         hei_index=select_hei_index(self.energies), force_evaluations=self.n_eval, history=history)

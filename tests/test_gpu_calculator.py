@@ -124,3 +124,25 @@ def test_ase_style_calculator(oracle, setup):
     e_c = calc.get_potential_energy(charged)
     e_cref, _ = oracle.energy_forces(z, imgs[0].astype(np.float32).astype(np.float64), charge=-1, spin=2, forces=False)
     assert abs(e_c - e_cref) <= 1e-4 and abs(e_c - e0) > 1e-3
+
+
+def test_gsm_driver_on_the_engine(tmp_path, setup):
+    """Row f1 end to end: growing string between two geometries, every cycle ONE batched engine call; outputs written
+    in the reference's .trj format (row f2)."""
+    from pdb2reaction_amd import formats
+    from pdb2reaction_amd.gsm import GrowingStringDriver
+
+    z, elem, imgs = setup
+    calc = U.uma_pysis(freeze_atoms=[0])
+    r, p = (imgs[0] * U.ANG2BOHR).reshape(-1), (imgs[3] * U.ANG2BOHR).reshape(-1)
+    drv = GrowingStringDriver(elem, r, p, calc, gs_kw={"max_nodes": 4, "perp_thresh": 1e3, "climb": False}, stopt_kw={"max_cycles": 4, "max_step": 0.05})
+    res = drv.run()
+    assert res.fully_grown and res.coords.shape == (6, 42) and np.isfinite(res.energies).all()
+    assert res.force_evaluations >= 4 + 6 + 4 + 4
+    e_first = calc.get_energy(elem, res.coords[0])["energy"]
+    assert e_first == pytest.approx(res.energies[0], abs=1e-9)
+    path = tmp_path / "final_geometries.trj"
+    formats.write_trj_with_energy([e.capitalize() for e in elem], res.coords.reshape(6, -1, 3) * U.BOHR2ANG, res.energies, path)
+    assert np.allclose(formats.read_energies_xyz(path), res.energies, atol=1e-12)
+    syms, xyz, _ = formats.read_trj(path)
+    assert xyz.shape == (6, 14, 3)

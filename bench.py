@@ -105,11 +105,17 @@ def main():
             raise SystemExit("--gpus N>1 must be launched through torch.distributed.run with N processes")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X GPU (no CPU fallback exists for the engine)")
+    backend = os.environ.get("UMX_BENCH_BACKEND", "nccl")        # "gloo" = rehearsal: ranks may share one GPU, host-staged gather
+    if backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     n, k = args.atoms, args.images
     z, imgs, frozen = synth.make_images(n, k)
@@ -160,7 +166,7 @@ def main():
     prof = eng.profile_read(True)
     eng.profile_enable(False)
     ne_local, maxdeg = eng.graph_stats()            # edges of this rank's images in the last step
-    tt = torch.tensor([dt, float(ne_local)], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt, float(ne_local)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

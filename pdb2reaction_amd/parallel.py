@@ -42,6 +42,8 @@ class ShardedImageEvaluator:
         self.slot = -(-n_images // self.world)
         self._send = torch.zeros(self.slot, self.width, dtype=torch.float64, device=device)
         self._recv = torch.zeros(self.world * self.slot, self.width, dtype=torch.float64, device=device)
+        # gloo has no device collectives: stage through the host (rehearsal of the N>1 path on boxes without RCCL peers)
+        self._stage_cpu = self.distributed and device.type != "cpu" and dist.get_backend(group) == "gloo"
 
     def __call__(self, coords: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         k = self.hi - self.lo
@@ -52,7 +54,12 @@ class ShardedImageEvaluator:
         if not self.distributed:
             out = self._send[: self.n_images]
         else:
-            dist.all_gather_into_tensor(self._recv, self._send, group=self.group)
+            if self._stage_cpu:
+                recv = torch.empty(self._recv.shape, dtype=torch.float64)
+                dist.all_gather_into_tensor(recv, self._send.cpu(), group=self.group)
+                self._recv.copy_(recv)
+            else:
+                dist.all_gather_into_tensor(self._recv, self._send, group=self.group)
             rows = []
             for r in range(self.world):
                 lo, hi = shard_bounds(self.n_images, self.world, r)

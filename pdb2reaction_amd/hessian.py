@@ -1,0 +1,81 @@
+"""Finite-difference Hessian assembly and atomic-unit conversion for the calculator boundary.
+
+Semantics follow the reference calculator (``pdb2reaction/uma_pysis.py``): central differences of the float32 model
+forces with h = 1e-3 Angstrom over the ACTIVE degrees of freedom only (``:595-686``), optional reduction to the
+active block (``:678-684``), symmetrisation 0.5 (H + H^T), eV/A^2 -> Hartree/Bohr^2, float64 when ``hessian_double``
+and torch-on-device or NumPy output (``:515-551``).  The implementation is ours: the 2 * 3N_active displaced geometries
+are evaluated as batches of images through one engine call each instead of 2 serial calls per column.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Sequence, Tuple
+
+import numpy as np
+
+from ._calculator_base import ANG2BOHR, AU2EV
+
+EV_TO_HARTREE = 1.0 / AU2EV
+EV_PER_ANG_TO_AU = EV_TO_HARTREE / ANG2BOHR
+EV_PER_ANG2_TO_AU = EV_TO_HARTREE / ANG2BOHR / ANG2BOHR
+FD_STEP_ANG = 1.0e-3
+
+
+def dof_partition(n_atoms: int, frozen: Sequence[int]) -> Tuple[List[int], List[int]]:
+    """(active DOF indices, frozen DOF indices) for 0-based frozen atom indices."""
+    fz = set(int(i) for i in frozen)
+    active = [3 * a + c for a in range(n_atoms) if a not in fz for c in range(3)]
+    dead = [3 * a + c for a in sorted(fz) for c in range(3)]
+    return active, dead
+
+
+def mask_frozen(forces: np.ndarray, frozen: Sequence[int]) -> np.ndarray:
+    """Copy of `forces` ((N,3) or (K,N,3), eV/A) with the rows of frozen atoms set to zero."""
+    if forces is None or len(frozen) == 0:
+        return forces
+    out = np.array(forces, copy=True)
+    out[..., np.asarray(list(frozen), dtype=int), :] = 0.0
+    return out
+
+
+def fd_hessian(batch_forces: Callable[[np.ndarray], np.ndarray], coord_ang: np.ndarray, frozen: Sequence[int], *, device,
+               double: bool, partial: bool, batch: int = 64, step: float = FD_STEP_ANG):
+    """Central-difference Hessian in eV/A^2 as a torch tensor (n_out, 3, n_out, 3) on `device`.
+
+    batch_forces(coords[K,N,3]) -> forces [K,N,3] float32.  Columns of frozen DOF stay zero (full output) or are
+    dropped together with their rows (`partial`).
+    """
+    import torch
+
+    x0 = np.asarray(coord_ang, dtype=np.float64)
+    n = x0.shape[0]
+    dof = 3 * n
+    active, _ = dof_partition(n, frozen)
+    dtype = torch.float64 if double else torch.float32
+    hess = torch.zeros((dof, dof), device=device, dtype=dtype)
+    per_call = max(batch // 2, 1)
+    for start in range(0, len(active), per_call):
+        cols = active[start: start + per_call]
+        disp = np.repeat(x0[None], 2 * len(cols), axis=0)
+        for m, k in enumerate(cols):
+            a, c = divmod(k, 3)
+            disp[2 * m, a, c] += step
+            disp[2 * m + 1, a, c] -= step
+        f = torch.from_numpy(np.ascontiguousarray(batch_forces(disp)).reshape(2 * len(cols), dof)).to(device, dtype=dtype)
+        hess[:, torch.as_tensor(cols, device=device, dtype=torch.long)] = (-(f[0::2] - f[1::2]) / (2.0 * step)).T
+    if partial:
+        idx = torch.as_tensor(active, device=device, dtype=torch.long)
+        hess = hess.index_select(0, idx).index_select(1, idx)
+        n = len(active) // 3
+    return hess.view(n, 3, n, 3)
+
+
+def hessian_to_au(hess, *, double: bool, as_torch: bool):
+    """(n,3,n,3) eV/A^2 -> symmetrised (3n,3n) Hartree/Bohr^2 (torch on device or NumPy)."""
+    import torch
+
+    n = hess.size(0)
+    h2 = hess.reshape(3 * n, 3 * n)
+    h2 = 0.5 * (h2 + h2.T) * EV_PER_ANG2_TO_AU
+    if double:
+        h2 = h2.to(torch.float64)
+    return h2.detach() if as_torch else h2.detach().cpu().numpy()

@@ -27,14 +27,15 @@ from typing import Any, Dict, List, Optional, Sequence
 
 import numpy as np
 
-from ._calculator_base import ANG2BOHR, AU2EV, BOHR2ANG, Calculator
+from ._calculator_base import ANG2BOHR, AU2EV, BOHR2ANG, Calculator  # noqa: F401
+from . import hessian as H
 from . import synth
 from . import weights as W
 
 # ------------ unit conversion constants (reference uma_pysis.py:127-129) ----------------------
-EV2AU = 1.0 / AU2EV                       # eV -> Hartree
-F_EVAA_2_AU = EV2AU / ANG2BOHR            # eV/A -> Hartree/Bohr
-H_EVAA_2_AU = EV2AU / ANG2BOHR / ANG2BOHR  # eV/A^2 -> Hartree/Bohr^2
+EV2AU = H.EV_TO_HARTREE                   # eV -> Hartree
+F_EVAA_2_AU = H.EV_PER_ANG_TO_AU          # eV/A -> Hartree/Bohr
+H_EVAA_2_AU = H.EV_PER_ANG2_TO_AU         # eV/A^2 -> Hartree/Bohr^2
 
 # reference uma_pysis.py:132-135
 GEOM_KW_DEFAULT: Dict[str, Any] = {
@@ -201,107 +202,32 @@ class uma_pysis(Calculator):
         self.return_partial_hessian = bool(return_partial_hessian)
         self.hessian_double = bool(hessian_double)
 
-    # ---------- helpers ---------------------------------------------
+    # ---------- internals -------------------------------------------
     def _ensure_core(self, elem: Sequence[str]):
-        # first `elem` binds the instance for its lifetime, as in the reference (:502-504)
+        # the first `elem` binds the instance for its lifetime, as in the reference (:502-504)
         if self._core is None:
             self._core = UMAcore(elem, **self._core_kw)
+        return self._core
 
-    @staticmethod
-    def _au_energy(E: float) -> float:
-        return E * EV2AU
-
-    @staticmethod
-    def _au_forces(F: np.ndarray) -> np.ndarray:
-        F64 = np.asarray(F, dtype=np.float64)
-        return (F64 * F_EVAA_2_AU).reshape(-1)
-
-    def _au_hessian(self, H):
-        """(N,3,N,3) eV/A^2 -> symmetrised (3N,3N) Hartree/Bohr^2; dtype/format as reference ``:515-551``."""
-        import torch
-
-        n = H.size(0)
-        H = H.view(n * 3, n * 3)
-        H = 0.5 * (H + H.T)
-        H = H * H_EVAA_2_AU
-        if self.hessian_double:
-            H = H.to(dtype=torch.float64)
-        if self.out_hess_torch:
-            return H.detach()
-        return H.detach().cpu().numpy()
-
-    def _active_and_frozen_dof_idx(self, n_atoms: int):
-        frozen_set = set(self.freeze_atoms)
-        active_atoms = [i for i in range(n_atoms) if i not in frozen_set]
-        active_dof_idx = [3 * i + j for i in active_atoms for j in range(3)]
-        frozen_dof_idx = [3 * i + j for i in self.freeze_atoms for j in range(3)]
-        return active_atoms, active_dof_idx, frozen_dof_idx
-
-    def _zero_frozen_forces_ev(self, F: np.ndarray) -> np.ndarray:
-        """Zero forces (eV/A) on frozen atoms; works on (N,3) and on batched (K,N,3) arrays."""
-        if (F is None) or (len(self.freeze_atoms) == 0):
-            return F
-        Fz = F.copy()
-        Fz[..., np.asarray(self.freeze_atoms, dtype=int), :] = 0.0
-        return Fz
-
-    # ---------- Finite-Difference Hessian (device assembly, batched displacements) -------------
-    def _build_fd_hessian_gpu(self, elem: Sequence[str], coord_ang: np.ndarray, *, eps_ang: float = 1.0e-3) -> Dict[str, Any]:
-        """H[:, k] = -(F(x + h e_k) - F(x - h e_k)) / (2h) over active DOF (reference ``:595-686``).
-
-        The reference issues 2 serial force calls per active DOF; here the displaced geometries are
-        evaluated ``FD_BATCH`` at a time as images of one batch.  Arithmetic per column is unchanged.
-        """
-        import torch
-
-        self._ensure_core(elem)
-        core = self._core
-        dev = core.device
-        n_atoms = len(elem)
-        dof = n_atoms * 3
-        active_atoms, active_dof_idx, _ = self._active_and_frozen_dof_idx(n_atoms)
-
-        res0 = core.compute(coord_ang, forces=True, hessian=False)
-        energy0_eV = res0["energy"]
-        F0 = res0["forces"]
-        force_dtype = torch.from_numpy(F0).dtype
-        hessian_dtype = torch.float64 if self.hessian_double else force_dtype
-        H = torch.zeros((dof, dof), device=dev, dtype=hessian_dtype)
-
-        half = max(FD_BATCH // 2, 1)
-        for s in range(0, len(active_dof_idx), half):
-            ks = active_dof_idx[s: s + half]
-            batch = np.repeat(np.asarray(coord_ang, dtype=np.float64)[None], 2 * len(ks), axis=0)
-            for m, k in enumerate(ks):
-                a, c = divmod(k, 3)
-                batch[2 * m, a, c] = coord_ang[a, c] + eps_ang
-                batch[2 * m + 1, a, c] = coord_ang[a, c] - eps_ang
-            F = core.compute_batch(batch, forces=True)["forces"].reshape(2 * len(ks), dof)
-            Ft = torch.from_numpy(F).to(dev, dtype=hessian_dtype)
-            cols = -(Ft[0::2] - Ft[1::2]) / (2.0 * eps_ang)          # (len(ks), 3N)
-            H[:, torch.as_tensor(ks, device=dev, dtype=torch.long)] = cols.T
-
-        if self.return_partial_hessian:
-            idx = torch.tensor(active_dof_idx, device=dev, dtype=torch.long)
-            H = H.index_select(0, idx).index_select(1, idx)
-            H = H.view(len(active_atoms), 3, len(active_atoms), 3)
-        else:
-            H = H.view(n_atoms, 3, n_atoms, 3)
-        return {"energy": energy0_eV, "forces": F0, "hessian": H}
+    def _fd_hessian_ev(self, elem: Sequence[str], coord_ang: np.ndarray) -> Dict[str, Any]:
+        """Base-point E/F plus the finite-difference Hessian (eV/A^2, torch on the core's device); hessian.fd_hessian."""
+        core = self._ensure_core(elem)
+        base = core.compute(coord_ang, forces=True, hessian=False)
+        hess = H.fd_hessian(lambda c: core.compute_batch(c, forces=True)["forces"], coord_ang, self.freeze_atoms, device=core.device,
+                            double=self.hessian_double, partial=self.return_partial_hessian, batch=FD_BATCH)
+        return {"energy": base["energy"], "forces": base["forces"], "hessian": hess}
 
     # ---------- PySisyphus API --------------------------------------
     def get_energy(self, elem, coords):
-        self._ensure_core(elem)
-        coord_ang = np.asarray(coords, dtype=np.float64).reshape(-1, 3) * BOHR2ANG
-        res = self._core.compute(coord_ang, forces=False, hessian=False)
-        return {"energy": self._au_energy(res["energy"])}
+        core = self._ensure_core(elem)
+        res = core.compute(_bohr_to_ang(coords), forces=False, hessian=False)
+        return {"energy": res["energy"] * EV2AU}
 
     def get_forces(self, elem, coords):
-        self._ensure_core(elem)
-        coord_ang = np.asarray(coords, dtype=np.float64).reshape(-1, 3) * BOHR2ANG
-        res = self._core.compute(coord_ang, forces=True, hessian=False)
-        F_ev = self._zero_frozen_forces_ev(res["forces"])
-        return {"energy": self._au_energy(res["energy"]), "forces": self._au_forces(F_ev)}
+        core = self._ensure_core(elem)
+        res = core.compute(_bohr_to_ang(coords), forces=True, hessian=False)
+        f_ev = H.mask_frozen(res["forces"], self.freeze_atoms)            # zeroed in eV/A before conversion (:701)
+        return {"energy": res["energy"] * EV2AU, "forces": (np.asarray(f_ev, dtype=np.float64) * F_EVAA_2_AU).reshape(-1)}
 
     def get_forces_batch(self, elem, coords_batch):
         """All images of a string in ONE engine call.
@@ -309,41 +235,36 @@ class uma_pysis(Calculator):
         ``coords_batch``: (K, 3N) or (K, N, 3) Bohr.  Returns ``{"energy": (K,) Hartree,
         "forces": (K, 3N) Hartree/Bohr float64}`` -- per image exactly what ``get_forces`` returns.
         """
-        self._ensure_core(elem)
+        core = self._ensure_core(elem)
         c = np.asarray(coords_batch, dtype=np.float64)
         k = c.shape[0]
-        coord_ang = c.reshape(k, -1, 3) * BOHR2ANG
-        res = self._core.compute_batch(coord_ang, forces=True)
-        F_ev = self._zero_frozen_forces_ev(res["forces"])
-        return {
-            "energy": np.asarray(res["energy"], dtype=np.float64) * EV2AU,
-            "forces": (np.asarray(F_ev, dtype=np.float64) * F_EVAA_2_AU).reshape(k, -1),
-        }
+        res = core.compute_batch(c.reshape(k, -1, 3) * BOHR2ANG, forces=True)
+        f_ev = H.mask_frozen(res["forces"], self.freeze_atoms)
+        return {"energy": np.asarray(res["energy"], dtype=np.float64) * EV2AU,
+                "forces": (np.asarray(f_ev, dtype=np.float64) * F_EVAA_2_AU).reshape(k, -1)}
 
     def get_energy_batch(self, elem, coords_batch):
-        self._ensure_core(elem)
+        core = self._ensure_core(elem)
         c = np.asarray(coords_batch, dtype=np.float64)
-        k = c.shape[0]
-        res = self._core.compute_batch(c.reshape(k, -1, 3) * BOHR2ANG, forces=False)
+        res = core.compute_batch(c.reshape(c.shape[0], -1, 3) * BOHR2ANG, forces=False)
         return {"energy": np.asarray(res["energy"], dtype=np.float64) * EV2AU}
 
     def get_hessian(self, elem, coords):
-        """Hessian per ``hessian_calc_mode``; the engine exposes no differentiable torch model, so --
-        exactly like the reference with ``workers > 1`` (``:736-737``) -- FiniteDifference is always used."""
-        self._ensure_core(elem)
-        coord_ang = np.asarray(coords, dtype=np.float64).reshape(-1, 3) * BOHR2ANG
-        core = self._core
-        force_fd = core.parallel_predict or (not core.has_torch_model)
+        """Hessian per ``hessian_calc_mode``.  The engine exposes no differentiable torch model, so -- exactly like the
+        reference with ``workers > 1`` (``:736-737``) -- every mode resolves to FiniteDifference."""
+        core = self._ensure_core(elem)
+        coord_ang = _bohr_to_ang(coords)
         mode = (self.hessian_calc_mode or "FiniteDifference").strip().lower()
-        if (not force_fd) and (mode in ("analytical", "analytic")):   # unreachable here; kept for parity of control flow
-            core.compute(coord_ang, forces=True, hessian=True)
-        res = self._build_fd_hessian_gpu(elem, coord_ang)
-        res_forces_ev = self._zero_frozen_forces_ev(res["forces"])
-        return {
-            "energy": self._au_energy(res["energy"]),
-            "forces": self._au_forces(res_forces_ev),
-            "hessian": self._au_hessian(res["hessian"]),
-        }
+        if mode in ("analytical", "analytic") and not (core.parallel_predict or not core.has_torch_model):
+            core.compute(coord_ang, forces=True, hessian=True)           # unreachable: raises the reference's RuntimeError
+        res = self._fd_hessian_ev(elem, coord_ang)
+        f_ev = H.mask_frozen(res["forces"], self.freeze_atoms)
+        return {"energy": res["energy"] * EV2AU, "forces": (np.asarray(f_ev, dtype=np.float64) * F_EVAA_2_AU).reshape(-1),
+                "hessian": H.hessian_to_au(res["hessian"], double=self.hessian_double, as_torch=self.out_hess_torch)}
+
+
+def _bohr_to_ang(coords) -> np.ndarray:
+    return np.asarray(coords, dtype=np.float64).reshape(-1, 3) * BOHR2ANG
 
 
 # ---------- CLI ----------------------------------------

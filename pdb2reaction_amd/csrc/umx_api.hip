@@ -84,7 +84,7 @@ struct umx_engine {
   char* arena = nullptr;
   size_t arena_bytes = 0;
   long cap_nodes = 0, cap_edges = 0;
-  int* d_deg_all = nullptr; long deg_all_cap = 0;
+  int* d_deg_all = nullptr; int* d_cand_all = nullptr; long deg_all_cap = 0;
   int* d_img_edges = nullptr; long img_edges_cap = 0;
   // host io staging for the host-pointer entry point
   float* d_io_pos = nullptr; double* d_io_e = nullptr; float* d_io_f = nullptr; long io_cap = 0, io_img_cap = 0;
@@ -216,7 +216,7 @@ struct WS {
   float* ffh[NL];
   float *G0, *G1, *G2, *ggs, *n128a, *n128b;
   // edge level
-  int *esrc, *edst, *rev;
+  int *esrc, *edst, *out_ptr, *out_cur, *out_edge;
   float *evec, *frame, *dedd, *tau, *gvec;
   float* h1pre[NL + 1];
   float* h2pre[NL + 1];
@@ -251,7 +251,8 @@ size_t carve(char* base, long nn, long ne, WS* w, bool pl) {
   for (auto& x : t.ffh) x = b.take<float>(nn * ROW);
   t.G0 = b.take<float>(nn * ROW); t.G1 = b.take<float>(nn * ROW); t.G2 = b.take<float>(nn * ROW);
   t.ggs = b.take<float>(nn * 2 * H); t.n128a = b.take<float>(nn * H); t.n128b = b.take<float>(nn * H);
-  t.esrc = b.take<int>(ne); t.edst = b.take<int>(ne); t.rev = b.take<int>(ne);
+  t.esrc = b.take<int>(ne); t.edst = b.take<int>(ne); t.out_edge = b.take<int>(ne);
+  t.out_ptr = b.take<int>(nn + 1); t.out_cur = b.take<int>(nn + 1);
   t.evec = b.take<float>(ne * 4); t.frame = b.take<float>(ne * FRAME); t.dedd = b.take<float>(ne);
   t.tau = b.take<float>(ne * 4); t.gvec = b.take<float>(ne * 4);
   for (auto& x : t.h1pre) x = b.take<float>(ne * RH);
@@ -330,7 +331,7 @@ int so3_linear(umx_engine* eng, const float* A, const float* Wl, const float* bi
 }
 
 // ---- one chunk: nn nodes (= images * natoms), edges counted on the fly --------------------------
-int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, long nimg, long ne, double* d_energy, float* d_forces) {
+int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, const int* d_cand, long nimg, long ne, double* d_energy, float* d_forces) {
   hipStream_t s = eng->stream;
   const int N = eng->natoms;
   const long nn = nimg * N;
@@ -338,13 +339,18 @@ int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, long
   const dim3 B256(256);
   // K1 graph
   hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, d_deg, nn, w.row_ptr, w.stats);
-  hipLaunchKernelGGL(k_graph_fill, dim3(nblk(nn, 4)), B256, 0, s, d_pos, N, nn, rc2, w.row_ptr, w.esrc, w.edst, w.evec);
+  hipLaunchKernelGGL(k_graph_fill, dim3(nblk(nn, 4)), B256, 0, s, d_pos, N, nn, rc2, eng->max_neigh, d_cand, w.row_ptr, w.esrc, w.edst, w.evec);
+  HIPCHK(eng, hipMemsetAsync(w.out_cur, 0, (nn + 1) * sizeof(int), s));
+  if (ne > 0) hipLaunchKernelGGL(k_out_count, dim3(nblk(ne, 256)), B256, 0, s, w.esrc, ne, w.out_cur);
+  hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, w.out_cur, nn, w.out_ptr, w.stats + 2);
+  HIPCHK(eng, hipMemsetAsync(w.out_cur, 0, (nn + 1) * sizeof(int), s));
   if (ne > 0) {
-    hipLaunchKernelGGL(k_rev, dim3(nblk(ne, 256)), B256, 0, s, w.esrc, w.edst, w.row_ptr, ne, w.rev);
+    hipLaunchKernelGGL(k_out_fill, dim3(nblk(ne, 256)), B256, 0, s, w.esrc, ne, w.out_ptr, w.out_cur, w.out_edge);
+    hipLaunchKernelGGL(k_out_sort, dim3(nblk(nn, 256)), B256, 0, s, w.out_ptr, nn, w.out_edge);
     hipLaunchKernelGGL(k_edge_geom, dim3(nblk(ne, 256)), B256, 0, s, w.evec, ne, eng->cutoff, w.frame);
   }
   HIPCHK(eng, hipGetLastError());
-  DBG("row_ptr", w.row_ptr, nn + 1); DBG("src", w.esrc, ne); DBG("dst", w.edst, ne); DBG("rev", w.rev, ne);
+  DBG("row_ptr", w.row_ptr, nn + 1); DBG("src", w.esrc, ne); DBG("dst", w.edst, ne); DBG("out_ptr", w.out_ptr, nn + 1); DBG("out_edge", w.out_edge, ne);
   DBG("evec", w.evec, ne * 4); DBG("frame", w.frame, ne * FRAME);
   // K4 + K5
   hipLaunchKernelGGL(k_node_init, dim3(nblk(nn * ROW, 256)), B256, 0, s, eng->d_z, N, nn, eng->emb_sphere, eng->d_sysemb, w.xs[0]);
@@ -469,7 +475,7 @@ int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, long
       DBG("g_xrot" + t, w.gy1, ne * XROT); DBG("g_rad" + t, w.grad, ne * RAD);
       CHK(radial_bwd(eng, w, L.rad, i, ne, w.grad));
     }
-    hipLaunchKernelGGL(k_gather_rotate_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.gy1, w.frame, w.row_ptr, w.rev, w.G1, nn);   // G1 = g_xn
+    hipLaunchKernelGGL(k_gather_rotate_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.gy1, w.frame, w.row_ptr, w.out_ptr, w.out_edge, w.G1, nn);   // G1 = g_xn
     hipLaunchKernelGGL(k_norm_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.G1, xin, L.n1w, w.G2, w.G0, nn);                      // G0 = g_xin
     HIPCHK(eng, hipGetLastError());
     DBG("g_xn" + t, w.G1, nn * ROW); DBG("g_xin" + t, w.G0, nn * ROW);
@@ -480,7 +486,7 @@ int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, long
     CHK(radial_bwd(eng, w, eng->rdeg, NL, ne, w.gmsg));
     hipLaunchKernelGGL(k_force_edge, dim3(nblk(ne, 256)), B256, 0, s, w.dedd, w.tau, w.frame, w.evec, w.gvec, ne);
   }
-  hipLaunchKernelGGL(k_force_node, dim3(nblk(nn, 4)), B256, 0, s, w.gvec, w.row_ptr, w.rev, (float)eng->rmsd, d_forces, nn);
+  hipLaunchKernelGGL(k_force_node, dim3(nblk(nn, 4)), B256, 0, s, w.gvec, w.row_ptr, w.out_ptr, w.out_edge, (float)eng->rmsd, d_forces, nn);
   HIPCHK(eng, hipGetLastError());
   DBG("dedd", w.dedd, ne); DBG("tau", w.tau, ne * 4); DBG("gvec", w.gvec, ne * 4);
   return UMX_OK;
@@ -552,7 +558,7 @@ int umx_destroy(umx_engine* eng) {
   (void)hipSetDevice(eng->dev);
   (void)hipStreamSynchronize(eng->stream);
   for (auto& r : eng->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-  void* ptrs[] = {eng->d_w, eng->d_dw, eng->d_bw, eng->d_gmu, eng->d_z, eng->d_sysemb, eng->arena, eng->d_deg_all, eng->d_img_edges, eng->d_io_pos, eng->d_io_e, eng->d_io_f};
+  void* ptrs[] = {eng->d_w, eng->d_dw, eng->d_bw, eng->d_gmu, eng->d_z, eng->d_sysemb, eng->arena, eng->d_deg_all, eng->d_cand_all, eng->d_img_edges, eng->d_io_pos, eng->d_io_e, eng->d_io_f};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   (void)hipStreamSynchronize(eng->stream2);
   (void)hipEventDestroy(eng->ev_fork); (void)hipEventDestroy(eng->ev_join);
@@ -870,7 +876,10 @@ int umx_energy_forces_dev(umx_engine* eng, int n_images, const float* d_pos, dou
   if (eng->deg_all_cap < nt) {
     HIPCHK(eng, hipStreamSynchronize(s));
     if (eng->d_deg_all) HIPCHK(eng, hipFree(eng->d_deg_all));
+    if (eng->d_cand_all) HIPCHK(eng, hipFree(eng->d_cand_all));
+    eng->d_deg_all = nullptr; eng->d_cand_all = nullptr; eng->deg_all_cap = 0;
     HIPCHK(eng, hipMalloc(&eng->d_deg_all, nt * sizeof(int)));
+    HIPCHK(eng, hipMalloc(&eng->d_cand_all, nt * sizeof(int)));
     eng->deg_all_cap = nt;
   }
   if (eng->img_edges_cap < K + 1) {
@@ -880,7 +889,7 @@ int umx_energy_forces_dev(umx_engine* eng, int n_images, const float* d_pos, dou
     eng->img_edges_cap = K + 1;
   }
   HIPCHK(eng, hipMemsetAsync(eng->d_img_edges + K, 0, sizeof(int), s));
-  hipLaunchKernelGGL(k_graph_count, dim3(nblk(nt, 4)), dim3(256), 0, s, d_pos, N, nt, eng->cutoff * eng->cutoff, eng->d_deg_all);
+  hipLaunchKernelGGL(k_graph_count, dim3(nblk(nt, 4)), dim3(256), 0, s, d_pos, N, nt, eng->cutoff * eng->cutoff, eng->max_neigh, eng->d_deg_all, eng->d_cand_all);
   hipLaunchKernelGGL(k_image_edges, dim3((unsigned)K), dim3(256), 0, s, eng->d_deg_all, N, eng->d_img_edges, eng->d_img_edges + K);
   HIPCHK(eng, hipGetLastError());
   std::vector<int> img_edges(K + 1);
@@ -889,9 +898,6 @@ int umx_energy_forces_dev(umx_engine* eng, int n_images, const float* d_pos, dou
   eng->last_maxdeg = img_edges[K];
   eng->last_edges = 0;
   for (long k = 0; k < K; ++k) eng->last_edges += img_edges[k];
-  if (eng->last_maxdeg > eng->max_neigh)
-    return fail(eng, UMX_ERR_CAPACITY, "neighbour count " + std::to_string(eng->last_maxdeg) + " exceeds max_neigh " +
-                                           std::to_string(eng->max_neigh) + " (nearest-M truncation is not implemented)");
   // chunk planning under the workspace budget
   size_t budget = eng->ws_limit;
   if (!budget) {
@@ -948,7 +954,7 @@ int umx_energy_forces_dev(umx_engine* eng, int n_images, const float* d_pos, dou
     for (long k = k0; k < k1; ++k) e += img_edges[k];
     const int lane = (lanes == 2) ? (int)(ci & 1) : 0;
     eng->stream = lane ? eng->stream2 : s;
-    st = run_chunk(eng, wl[lane], d_pos + k0 * N * 3, eng->d_deg_all + k0 * N, k1 - k0, e, d_energy + k0, d_forces ? d_forces + k0 * N * 3 : nullptr);
+    st = run_chunk(eng, wl[lane], d_pos + k0 * N * 3, eng->d_deg_all + k0 * N, eng->d_cand_all + k0 * N, k1 - k0, e, d_energy + k0, d_forces ? d_forces + k0 * N * 3 : nullptr);
     eng->stream = s;
     if (st != UMX_OK) break;
     ++ci;

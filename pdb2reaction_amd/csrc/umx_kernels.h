@@ -16,12 +16,15 @@ namespace umx {
   const long idx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))); \
   if (idx >= (count)) return;
 
+// one definition of the squared distance so every site rounds identically (the candidate ranking compares them)
+__device__ __forceinline__ float dist2_f(float dx, float dy, float dz) { return fmaf(dz, dz, fmaf(dy, dy, dx * dx)); }
+
 // ------------------------------------------------------------------------------------------------
 // K1 radius graph: brute force inside each image, wave per target, ballot compaction (ascending
 // source order => CSR rows sorted by source).  pos: [NT][3] f32.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_graph_count(const float* __restrict__ pos, int natoms, long nt, float rc2,
-                                                     int* __restrict__ deg) {
+__global__ __launch_bounds__(256) void k_graph_count(const float* __restrict__ pos, int natoms, long nt, float rc2, int max_neigh,
+                                                     int* __restrict__ deg, int* __restrict__ cand) {
   UMX_WAVE_ITEM(node, nt)
   const long base = (node / natoms) * natoms;
   const float xi = pos[node * 3 + 0], yi = pos[node * 3 + 1], zi = pos[node * 3 + 2];
@@ -31,12 +34,12 @@ __global__ __launch_bounds__(256) void k_graph_count(const float* __restrict__ p
     bool ok = false;
     if (j < natoms) {
       const float dx = pos[(base + j) * 3 + 0] - xi, dy = pos[(base + j) * 3 + 1] - yi, dz = pos[(base + j) * 3 + 2] - zi;
-      const float d2 = dx * dx + dy * dy + dz * dz;
-      ok = (d2 <= rc2) && (base + j != node);
+      const float d2 = dist2_f(dx, dy, dz);
+      ok = (d2 <= rc2) && (d2 > 0.0f) && (base + j != node);        // 0 < d <= cutoff
     }
     cnt += __popcll(__ballot(ok));
   }
-  if (lane == 0) deg[node] = cnt;
+  if (lane == 0) { cand[node] = cnt; deg[node] = cnt < max_neigh ? cnt : max_neigh; }
 }
 
 // exclusive scan of deg[0..n) into row_ptr[0..n]; single block of 1024 threads; also max degree
@@ -63,12 +66,15 @@ __global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ deg, long
   if (t == 1023) { row_ptr[n] = part[1023]; stats[0] = part[1023]; stats[1] = pmax[1023]; }
 }
 
-__global__ __launch_bounds__(256) void k_graph_fill(const float* __restrict__ pos, int natoms, long nt, float rc2,
-                                                    const int* __restrict__ row_ptr, int* __restrict__ esrc,
+// Rows keep ascending source order.  A target with more than max_neigh candidates keeps its max_neigh nearest
+// (rank by (d^2, source index), the oracle's stable argsort) -- the rare path scans the image once per candidate chunk.
+__global__ __launch_bounds__(256) void k_graph_fill(const float* __restrict__ pos, int natoms, long nt, float rc2, int max_neigh,
+                                                    const int* __restrict__ cand, const int* __restrict__ row_ptr, int* __restrict__ esrc,
                                                     int* __restrict__ edst, float* __restrict__ evec) {
   UMX_WAVE_ITEM(node, nt)
   const long base = (node / natoms) * natoms;
   const float xi = pos[node * 3 + 0], yi = pos[node * 3 + 1], zi = pos[node * 3 + 2];
+  const bool truncate = cand[node] > max_neigh;
   int w = row_ptr[node];
   for (int j0 = 0; j0 < natoms; j0 += 64) {
     const int j = j0 + lane;
@@ -76,8 +82,25 @@ __global__ __launch_bounds__(256) void k_graph_fill(const float* __restrict__ po
     float dx = 0.f, dy = 0.f, dz = 0.f, d2 = 0.f;
     if (j < natoms) {
       dx = pos[(base + j) * 3 + 0] - xi; dy = pos[(base + j) * 3 + 1] - yi; dz = pos[(base + j) * 3 + 2] - zi;
-      d2 = dx * dx + dy * dy + dz * dz;
-      ok = (d2 <= rc2) && (base + j != node);
+      d2 = dist2_f(dx, dy, dz);
+      ok = (d2 <= rc2) && (d2 > 0.0f) && (base + j != node);
+    }
+    if (truncate && __ballot(ok)) {
+      int rank = 0;
+      for (int q0 = 0; q0 < natoms; q0 += 64) {
+        const int q = q0 + lane;
+        float e2 = -1.0f;                                             // -1 marks "not a candidate"
+        if (q < natoms && base + q != node) {
+          const float ex = pos[(base + q) * 3 + 0] - xi, ey = pos[(base + q) * 3 + 1] - yi, ez = pos[(base + q) * 3 + 2] - zi;
+          const float t = dist2_f(ex, ey, ez);
+          if (t <= rc2 && t > 0.0f) e2 = t;
+        }
+        for (int l = 0; l < 64; ++l) {
+          const float o2 = __shfl(e2, l, 64);
+          if (o2 >= 0.0f && q0 + l != j && (o2 < d2 || (o2 == d2 && q0 + l < j))) ++rank;
+        }
+      }
+      ok = ok && rank < max_neigh;
     }
     const unsigned long long m = __ballot(ok);
     if (ok) {
@@ -91,18 +114,29 @@ __global__ __launch_bounds__(256) void k_graph_fill(const float* __restrict__ po
   }
 }
 
-// reverse edge: position of (dst -> src) in row src (rows sorted by source)
-__global__ void k_rev(const int* __restrict__ esrc, const int* __restrict__ edst, const int* __restrict__ row_ptr,
-                      long ne, int* __restrict__ rev) {
+// CSR by SOURCE (out-edges), valid for any graph (max_neigh truncation makes it asymmetric): count, scan (k_scan), fill
+// through per-row cursors, then sort every row by edge id so the summation order is deterministic.
+__global__ void k_out_count(const int* __restrict__ esrc, long ne, int* __restrict__ out_deg) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < ne) atomicAdd(out_deg + esrc[e], 1);
+}
+__global__ void k_out_fill(const int* __restrict__ esrc, long ne, const int* __restrict__ out_ptr, int* __restrict__ cursor,
+                           int* __restrict__ out_edge) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= ne) return;
-  const int j = esrc[e], i = edst[e];
-  int lo = row_ptr[j], hi = row_ptr[j + 1] - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (esrc[mid] < i) lo = mid + 1; else hi = mid;
+  const int n = esrc[e];
+  out_edge[out_ptr[n] + atomicAdd(cursor + n, 1)] = (int)e;
+}
+__global__ void k_out_sort(const int* __restrict__ out_ptr, long nt, int* __restrict__ out_edge) {
+  const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nt) return;
+  const int b = out_ptr[n], e = out_ptr[n + 1];
+  for (int i = b + 1; i < e; ++i) {
+    const int v = out_edge[i];
+    int k = i - 1;
+    while (k >= b && out_edge[k] > v) { out_edge[k + 1] = out_edge[k]; --k; }
+    out_edge[k + 1] = v;
   }
-  rev[e] = lo;
 }
 
 // K2 edge frames: R (R nhat = +y, minimal rotation, flipped branch for nhat_y < -0.9), D2, envelope
@@ -546,29 +580,30 @@ __global__ __launch_bounds__(256) void k_modulate_bwd(float* __restrict__ gy1, c
   if (lane == 0) { tau[e * 4 + 0] += tx; tau[e * 4 + 1] += ty; tau[e * 4 + 2] += tz; }
 }
 
-// backward of K7a (gather+rotate): g_xn[n] = sum_{e in in(n)} W_e^T gxrot[e][:, dst half] + W_rev^T gxrot[rev e][:, src half]
+// backward of K7a (gather+rotate): g_xn[n] = sum_{e in in(n)} W_e^T gxrot[e][:, dst half] + sum_{e in out(n)} W_e^T gxrot[e][:, src half]
 __global__ __launch_bounds__(256) void k_gather_rotate_bwd(const float* __restrict__ gxrot, const float* __restrict__ frame,
-                                                           const int* __restrict__ row_ptr, const int* __restrict__ rev,
-                                                           float* __restrict__ gxn, long nt) {
+                                                           const int* __restrict__ row_ptr, const int* __restrict__ out_ptr,
+                                                           const int* __restrict__ out_edge, float* __restrict__ gxn, long nt) {
   UMX_WAVE_ITEM(node, nt)
   const int c0 = lane * 2;
   float ax[9], ay[9];
 #pragma unroll
   for (int r = 0; r < 9; ++r) { ax[r] = 0.f; ay[r] = 0.f; }
-  const int e0 = row_ptr[node], e1 = row_ptr[node + 1];
-  for (int e = e0; e < e1; ++e) {
-    const long re = rev[e];
-    float vx[9], vy[9];
+  float vx[9], vy[9];
+  for (int e = row_ptr[node]; e < row_ptr[node + 1]; ++e) {
     const float* a = gxrot + (long)e * XROT + C + c0;
 #pragma unroll
     for (int r = 0; r < 9; ++r) { const float2 t = *reinterpret_cast<const float2*>(a + r * 2 * C); vx[r] = t.x; vy[r] = t.y; }
     const float* f = frame + (long)e * FRAME;
     rot_bwd_acc(f, vx, 1.0f, ax); rot_bwd_acc(f, vy, 1.0f, ay);
-    const float* b = gxrot + re * XROT + c0;
+  }
+  for (int k = out_ptr[node]; k < out_ptr[node + 1]; ++k) {
+    const long e = out_edge[k];
+    const float* b = gxrot + e * XROT + c0;
 #pragma unroll
     for (int r = 0; r < 9; ++r) { const float2 t = *reinterpret_cast<const float2*>(b + r * 2 * C); vx[r] = t.x; vy[r] = t.y; }
-    const float* f2 = frame + re * FRAME;
-    rot_bwd_acc(f2, vx, 1.0f, ax); rot_bwd_acc(f2, vy, 1.0f, ay);
+    const float* f = frame + e * FRAME;
+    rot_bwd_acc(f, vx, 1.0f, ax); rot_bwd_acc(f, vy, 1.0f, ay);
   }
 #pragma unroll
   for (int r = 0; r < 9; ++r) *reinterpret_cast<float2*>(gxn + node * ROW + r * C + c0) = make_float2(ax[r], ay[r]);
@@ -600,16 +635,19 @@ __global__ void k_force_edge(const float* __restrict__ dedd, const float* __rest
   *reinterpret_cast<float4*>(gvec + e * 4) = make_float4(g * v.x + tx * inv, g * v.y + ty * inv, g * v.z + tz * inv, 0.f);
 }
 
-// F[n] = -rmsd * sum_{e in in(n)} (gvec[rev e] - gvec[e])   (vec = pos[src] - pos[dst])
+// F[n] = -dE/dpos[n] * rmsd,  dE/dpos[n] = sum_{e in out(n)} gvec[e] - sum_{e in in(n)} gvec[e]   (vec = pos[src] - pos[dst])
 __global__ __launch_bounds__(256) void k_force_node(const float* __restrict__ gvec, const int* __restrict__ row_ptr,
-                                                    const int* __restrict__ rev, float rmsd, float* __restrict__ forces, long nt) {
+                                                    const int* __restrict__ out_ptr, const int* __restrict__ out_edge, float rmsd,
+                                                    float* __restrict__ forces, long nt) {
   UMX_WAVE_ITEM(node, nt)
-  const int e0 = row_ptr[node], e1 = row_ptr[node + 1];
   float fx = 0.f, fy = 0.f, fz = 0.f;
-  for (int e = e0 + lane; e < e1; e += 64) {
+  for (int e = row_ptr[node] + lane; e < row_ptr[node + 1]; e += 64) {
     const float4 a = *reinterpret_cast<const float4*>(gvec + (long)e * 4);
-    const float4 b = *reinterpret_cast<const float4*>(gvec + (long)rev[e] * 4);
-    fx += b.x - a.x; fy += b.y - a.y; fz += b.z - a.z;
+    fx -= a.x; fy -= a.y; fz -= a.z;
+  }
+  for (int k = out_ptr[node] + lane; k < out_ptr[node + 1]; k += 64) {
+    const float4 b = *reinterpret_cast<const float4*>(gvec + (long)out_edge[k] * 4);
+    fx += b.x; fy += b.y; fz += b.z;
   }
   fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
   if (lane == 0) { forces[node * 3 + 0] = -rmsd * fx; forces[node * 3 + 1] = -rmsd * fy; forces[node * 3 + 2] = -rmsd * fz; }

@@ -108,13 +108,29 @@ def test_pole_aligned_edges(engine, oracle):
     check(engine, oracle, z, p)
 
 
-def test_max_neigh_is_enforced_loudly(engine):
-    from pdb2reaction_amd.engine import UmxError
+@pytest.mark.parametrize("max_neigh", [3, 8, 20])
+def test_max_neigh_truncation(engine, weights, max_neigh):
+    """`max_neigh` keeps the nearest M sources per target (fairchem's per-centre cap, reference uma_pysis.py:301-318):
+    the graph becomes asymmetric, so this also exercises the CSR-by-source reverse pass."""
+    import torch
+    from oracle.escn_md_oracle import Oracle, radius_graph
 
-    z, imgs, _ = synth.make_images(40, 1, seed=3)
-    engine.set_system(z, max_neigh=5)
-    with pytest.raises(UmxError, match="max_neigh"):
-        engine.energy_forces(imgs)
+    z, imgs, _ = synth.make_images(40, 2, seed=3)
+    p32 = imgs.astype(np.float32)
+    orc = Oracle(weights, max_neigh=max_neigh)
+    engine.set_system(z, max_neigh=max_neigh)
+    engine.debug_keep(True)
+    try:
+        e, f = engine.energy_forces(p32[1:2])
+        src, dst = radius_graph(torch.as_tensor(p32[1].astype(np.float64)), W.CUTOFF, max_neigh)
+        assert np.array_equal(engine.debug_fetch("src", np.int32), src.numpy()) and np.array_equal(engine.debug_fetch("dst", np.int32), dst.numpy())
+        assert engine.graph_stats()[1] == max_neigh
+    finally:
+        engine.debug_keep(False)
+    e, f = engine.energy_forces(p32)
+    for k in range(2):
+        e_ref, f_ref = orc.energy_forces(z, p32[k].astype(np.float64))
+        assert abs(e[k] - e_ref) <= TOL_E and np.abs(f[k] - f_ref).max() <= TOL_F
     engine.set_system(z, radius=3.0)
     e, _ = engine.energy_forces(imgs)
     assert np.isfinite(e).all()
@@ -182,8 +198,11 @@ def test_stage_by_stage_against_staged_oracle(weights, mode, monkeypatch):
         engine.energy_forces(p32)
         assert np.array_equal(engine.debug_fetch("src", np.int32), t["src"])
         assert np.array_equal(engine.debug_fetch("dst", np.int32), t["dst"])
-        rev = engine.debug_fetch("rev", np.int32)
-        assert np.array_equal(t["src"][rev], t["dst"]) and np.array_equal(t["dst"][rev], t["src"])
+        out_ptr, out_edge = engine.debug_fetch("out_ptr", np.int32), engine.debug_fetch("out_edge", np.int32)
+        assert out_ptr[-1] == ne and np.array_equal(np.sort(out_edge), np.arange(ne))            # CSR by source is a permutation
+        for n in range(len(z)):
+            row = out_edge[out_ptr[n]:out_ptr[n + 1]]
+            assert np.all(t["src"][row] == n) and np.all(np.diff(row) > 0)                      # right rows, deterministic order
         names = ["x0", "rad.deg", "e_node", "g_xfinal", "dedd"]
         per_layer = ["xn", "rad", "msg", "xmid", "xn2", "gspre", "ffh", "x", "g_xmid", "g_hid", "g_xrot", "g_xn", "g_xin"]
         if mode == "fp32":

@@ -38,13 +38,22 @@ def mask_frozen(forces: np.ndarray, frozen: Sequence[int]) -> np.ndarray:
 
 
 def fd_hessian(batch_forces: Callable[[np.ndarray], np.ndarray], coord_ang: np.ndarray, frozen: Sequence[int], *, device,
-               double: bool, partial: bool, batch: int = 64, step: float = FD_STEP_ANG):
+               double: bool, partial: bool, batch: int = 64, step: float = FD_STEP_ANG, group=None):
     """Central-difference Hessian in eV/A^2 as a torch tensor (n_out, 3, n_out, 3) on `device`.
 
     batch_forces(coords[K,N,3]) -> forces [K,N,3] float32.  Columns of frozen DOF stay zero (full output) or are
     dropped together with their rows (`partial`).
+
+    Multi-GPU: when torch.distributed is initialised with more than one rank, active columns are dealt
+    round-robin (column k of the active list -> rank k mod G), every rank evaluates only its own displaced geometries and
+    ONE all-reduce of the (3N x 3N) matrix at the end assembles the result on every rank (columns are disjoint, so the
+    sum is an exact gather).
     """
     import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
 
     x0 = np.asarray(coord_ang, dtype=np.float64)
     n = x0.shape[0]
@@ -53,8 +62,9 @@ def fd_hessian(batch_forces: Callable[[np.ndarray], np.ndarray], coord_ang: np.n
     dtype = torch.float64 if double else torch.float32
     hess = torch.zeros((dof, dof), device=device, dtype=dtype)
     per_call = max(batch // 2, 1)
-    for start in range(0, len(active), per_call):
-        cols = active[start: start + per_call]
+    mine = active[rank::world] if world > 1 else active
+    for start in range(0, len(mine), per_call):
+        cols = mine[start: start + per_call]
         disp = np.repeat(x0[None], 2 * len(cols), axis=0)
         for m, k in enumerate(cols):
             a, c = divmod(k, 3)
@@ -62,6 +72,13 @@ def fd_hessian(batch_forces: Callable[[np.ndarray], np.ndarray], coord_ang: np.n
             disp[2 * m + 1, a, c] -= step
         f = torch.from_numpy(np.ascontiguousarray(batch_forces(disp)).reshape(2 * len(cols), dof)).to(device, dtype=dtype)
         hess[:, torch.as_tensor(cols, device=device, dtype=torch.long)] = (-(f[0::2] - f[1::2]) / (2.0 * step)).T
+    if world > 1:
+        if dist.get_backend(group) == "gloo" and hess.device.type != "cpu":
+            host = hess.cpu()
+            dist.all_reduce(host, group=group)
+            hess.copy_(host)
+        else:
+            dist.all_reduce(hess, group=group)
     if partial:
         idx = torch.as_tensor(active, device=device, dtype=torch.long)
         hess = hess.index_select(0, idx).index_select(1, idx)

@@ -98,6 +98,17 @@ typedef struct umx_profile_stats {
 int umx_profile_enable(umx_engine* eng, int on);
 int umx_profile_read(umx_engine* eng, umx_profile_stats* out, int reset);
 
+/* Bond-change detection between two geometries of the same atoms (pairwise distances in float64 on the GPU).
+ * r1, r2: [n][3] float64 coordinates (any length unit); cov: [n] covalent radii in the SAME unit.
+ * Outputs (host): d1, d2: [n][n] float64 distance matrices (either may be NULL); code: [n][n] uint8 with, for i < j,
+ * 1 = covalent bond formed (absent in 1, present in 2), 2 = broken, 0 = neither; diagonal and lower triangle 0.
+ * bonded <=> D <= T - margin_fraction*T with T = bond_factor*(cov_i + cov_j); a pair is only classified when
+ * |D2 - D1| >= delta_fraction*T.  Does not need weights or a bound system.
+ * Replaces: compare_structures (torch.cdist + masks), bond_changes.py:142-187.                               */
+int umx_bond_changes(umx_engine* eng, int n, const double* r1, const double* r2, const double* cov,
+                     double bond_factor, double margin_fraction, double delta_fraction, double* d1, double* d2,
+                     uint8_t* code);
+
 /* Test hook: copy a named intermediate buffer of the most recent evaluation's last chunk to the
  * host.  Returns the buffer size in bytes through *nbytes_out when host_buf == NULL.           */
 int umx_debug_fetch(umx_engine* eng, const char* name, void* host_buf, size_t capacity,

@@ -523,7 +523,7 @@ std::vector<float> transpose(const float* src, int rows, int cols) {
 // ================================================================================================
 extern "C" {
 
-int umx_abi_version(void) { return 2; }
+int umx_abi_version(void) { return 3; }
 
 const char* umx_last_error(const umx_engine* eng) { return eng ? eng->err.c_str() : g_create_err.c_str(); }
 
@@ -1053,6 +1053,40 @@ int umx_debug_fetch(umx_engine* eng, const char* name, void* host_buf, size_t ca
     std::memcpy(host_buf, it->second.data(), it->second.size());
   }
   return UMX_OK;
+}
+
+int umx_bond_changes(umx_engine* eng, int n, const double* r1, const double* r2, const double* cov, double bond_factor,
+                     double margin_fraction, double delta_fraction, double* d1, double* d2, uint8_t* code) {
+  if (!eng) return UMX_ERR_ARG;
+  if (n <= 0 || !r1 || !r2 || !cov || !code) return fail(eng, UMX_ERR_ARG, "umx_bond_changes: bad arguments");
+  if ((long)n * n > (1L << 31)) return fail(eng, UMX_ERR_CAPACITY, "umx_bond_changes: n*n exceeds 2^31 pairs");
+  HIPCHK(eng, hipSetDevice(eng->dev));
+  const size_t nn = (size_t)n * n, vb = (size_t)n * 3 * sizeof(double);
+  double *d_r = nullptr, *d_d = nullptr; unsigned char* d_c = nullptr;
+  HIPCHK(eng, hipMalloc(&d_r, 2 * vb + (size_t)n * sizeof(double)));
+  hipError_t e1 = hipMalloc(&d_d, 2 * nn * sizeof(double)), e2 = hipMalloc(&d_c, nn);
+  if (e1 != hipSuccess || e2 != hipSuccess) {
+    (void)hipFree(d_r); if (d_d) (void)hipFree(d_d); if (d_c) (void)hipFree(d_c);
+    return fail(eng, UMX_ERR_HIP, "umx_bond_changes: hipMalloc of the pair matrices failed");
+  }
+  double* d_r2 = d_r + (size_t)n * 3; double* d_cov = d_r2 + (size_t)n * 3;
+  hipStream_t s = eng->stream;
+  int st = UMX_OK;
+  auto ok = [&](hipError_t e, const char* what) { if (e != hipSuccess && st == UMX_OK) st = fail(eng, UMX_ERR_HIP, std::string(what) + ": " + hipGetErrorName(e)); };
+  ok(hipMemcpyAsync(d_r, r1, vb, hipMemcpyHostToDevice, s), "copy r1");
+  ok(hipMemcpyAsync(d_r2, r2, vb, hipMemcpyHostToDevice, s), "copy r2");
+  ok(hipMemcpyAsync(d_cov, cov, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s), "copy cov");
+  if (st == UMX_OK) {
+    dim3 grid((n + 63) / 64, (n + 3) / 4);
+    umx::k_bond_changes<<<grid, 256, 0, s>>>(d_r, d_r2, d_cov, n, bond_factor, margin_fraction, delta_fraction, d_d, d_d + nn, d_c);
+    ok(hipGetLastError(), "k_bond_changes");
+    if (d1) ok(hipMemcpyAsync(d1, d_d, nn * sizeof(double), hipMemcpyDeviceToHost, s), "copy d1");
+    if (d2) ok(hipMemcpyAsync(d2, d_d + nn, nn * sizeof(double), hipMemcpyDeviceToHost, s), "copy d2");
+    ok(hipMemcpyAsync(code, d_c, nn, hipMemcpyDeviceToHost, s), "copy code");
+  }
+  ok(hipStreamSynchronize(s), "sync");
+  (void)hipFree(d_r); (void)hipFree(d_d); (void)hipFree(d_c);
+  return st;
 }
 
 }  // extern "C"

@@ -653,4 +653,34 @@ __global__ __launch_bounds__(256) void k_force_node(const float* __restrict__ gv
   if (lane == 0) { forces[node * 3 + 0] = -rmsd * fx; forces[node * 3 + 1] = -rmsd * fy; forces[node * 3 + 2] = -rmsd * fz; }
 }
 
+// ---- pairwise-distance bond-change classification (float64; reference bond_changes.py:142-187) ----------------------
+// One thread per (i, j): D1, D2 in full and a code for i < j: 1 = bond formed, 2 = bond broken, 0 = neither.
+// The arithmetic keeps the reference's operation order (no FMA contraction): T = bf (c_i + c_j); eps = mf T;
+// bonded <=> D <= T - eps; considered only when |D2 - D1| >= df T.
+__global__ __launch_bounds__(256) void k_bond_changes(const double* __restrict__ r1, const double* __restrict__ r2,
+                                                      const double* __restrict__ cov, int n, double bf, double mf, double df,
+                                                      double* __restrict__ d1, double* __restrict__ d2,
+                                                      unsigned char* __restrict__ code) {
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (i >= n || j >= n) return;
+  auto dist = [](const double* r, int a, int b) {
+    const double dx = r[a * 3 + 0] - r[b * 3 + 0], dy = r[a * 3 + 1] - r[b * 3 + 1], dz = r[a * 3 + 2] - r[b * 3 + 2];
+    return sqrt(__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz)));
+  };
+  const double a = dist(r1, i, j), b = dist(r2, i, j);
+  const long o = (long)i * n + j;
+  if (d1) d1[o] = a;
+  if (d2) d2[o] = b;
+  unsigned char c = 0;
+  if (i < j) {
+    const double T = __dmul_rn(bf, __dadd_rn(cov[i], cov[j]));
+    const double thr = __dsub_rn(T, __dmul_rn(mf, T));
+    const bool A1 = a <= thr, A2 = b <= thr;
+    const bool need = fabs(__dsub_rn(b, a)) >= __dmul_rn(df, T);
+    c = need ? ((!A1 && A2) ? 1 : (A1 && !A2) ? 2 : 0) : 0;
+  }
+  code[o] = c;
+}
+
 }  // namespace umx

@@ -56,6 +56,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "umx_last_graph_stats": ([vp, i64p, C.POINTER(C.c_int32)], i32),
         "umx_profile_enable": ([vp, i32], i32),
         "umx_profile_read": ([vp, C.POINTER(ProfileStats), i32], i32),
+        "umx_bond_changes": ([vp, i32, dp, dp, dp, C.c_double, C.c_double, C.c_double, dp, dp, C.POINTER(C.c_uint8)], i32),
         "umx_debug_fetch": ([vp, C.c_char_p, vp, C.c_size_t, C.POINTER(C.c_size_t)], i32),
         "umx_debug_keep": ([vp, i32], i32),
     }
@@ -70,7 +71,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 EXPORTED_SYMBOLS = (
     "umx_abi_version", "umx_create", "umx_destroy", "umx_last_error", "umx_load_weights", "umx_set_system",
     "umx_set_workspace_limit", "umx_energy_forces", "umx_energy_forces_dev", "umx_synchronize",
-    "umx_last_graph_stats", "umx_profile_enable", "umx_profile_read", "umx_debug_fetch", "umx_debug_keep",
+    "umx_last_graph_stats", "umx_profile_enable", "umx_profile_read", "umx_bond_changes", "umx_debug_fetch", "umx_debug_keep",
 )
 
 
@@ -144,6 +145,25 @@ class Engine:
 
     def synchronize(self):
         self._chk(self.lib.umx_synchronize(self._h), "umx_synchronize")
+
+    def bond_changes(self, r1: np.ndarray, r2: np.ndarray, cov: np.ndarray, bond_factor: float = 1.20,
+                     margin_fraction: float = 0.05, delta_fraction: float = 0.05, distances: bool = True):
+        """Pairwise float64 distances of two geometries + formed/broken code matrix (uint8, i<j: 1 formed, 2 broken)."""
+        a = np.ascontiguousarray(r1, dtype=np.float64).reshape(-1, 3)
+        b = np.ascontiguousarray(r2, dtype=np.float64).reshape(-1, 3)
+        c = np.ascontiguousarray(cov, dtype=np.float64).reshape(-1)
+        n = a.shape[0]
+        if b.shape[0] != n or c.shape[0] != n or n == 0:
+            raise ValueError(f"bond_changes: inconsistent sizes {a.shape}, {b.shape}, {c.shape}")
+        dp = C.POINTER(C.c_double)
+        d1 = np.empty((n, n), dtype=np.float64) if distances else None
+        d2 = np.empty((n, n), dtype=np.float64) if distances else None
+        code = np.empty((n, n), dtype=np.uint8)
+        self._chk(self.lib.umx_bond_changes(self._h, n, a.ctypes.data_as(dp), b.ctypes.data_as(dp), c.ctypes.data_as(dp),
+                                            float(bond_factor), float(margin_fraction), float(delta_fraction),
+                                            d1.ctypes.data_as(dp) if distances else None, d2.ctypes.data_as(dp) if distances else None,
+                                            code.ctypes.data_as(C.POINTER(C.c_uint8))), "umx_bond_changes")
+        return d1, d2, code
 
     # ---- diagnostics -----------------------------------------------------------------------------
     def graph_stats(self) -> Tuple[int, int]:

@@ -146,3 +146,32 @@ def test_gsm_driver_on_the_engine(tmp_path, setup):
     assert np.allclose(formats.read_energies_xyz(path), res.energies, atol=1e-12)
     syms, xyz, _ = formats.read_trj(path)
     assert xyz.shape == (6, 14, 3)
+
+
+def test_staged_scan_with_batched_lbfgs_on_the_engine(setup):
+    """Row f3 end to end: two mobile images are rigidly fitted onto a reference and their anchors dragged onto it while
+    the rest relaxes -- every L-BFGS cycle is ONE batched engine call for both images."""
+    from pdb2reaction_amd import prestep as PS
+
+    z, elem, imgs = setup
+    calc = U.uma_pysis()
+    ref = imgs[0] * U.ANG2BOHR
+    anchors = [0, 5, 9]
+    rot = PS._rodrigues(np.array([0.3, -1.0, 0.5]), 0.7)
+    mobs = []
+    for k in (1, 2):
+        m = imgs[k] * U.ANG2BOHR
+        m[anchors] += 0.25 * (k + 1) * np.array([0.0, 1.0, 0.0])       # anchors displaced by 0.26 / 0.40 A before the rigid move
+        mobs.append(m @ rot.T + np.array([3.0, -1.0, 2.0]))
+    out, res = PS.align_and_refine_sequence(calc, elem, [ref] + mobs, [anchors] * 3, step_A=0.1, per_step_cycles=3, final_cycles=6,
+                                            thresh="gau_loose")
+    assert [r["align"]["mode"] for r in res] == ["kabsch", "kabsch"] and all(r["scan"]["converged"] for r in res)
+    assert all(2 <= r["scan"]["n_steps"] <= 8 for r in res)
+    for o in out[1:]:
+        np.testing.assert_array_equal(o[anchors], ref[anchors])
+        assert np.isfinite(o).all() and PS.rmsd_ang(o, ref) < 3.0          # synthetic weights: no physical minimum nearby
+    # relaxation lowers the energy relative to the same anchors-on-target geometry without relaxation
+    start = PS.align_second_to_first(ref, mobs[0], anchors)[0]
+    start[anchors] = ref[anchors]
+    e = calc.get_energy_batch(elem, np.stack([start, out[1]]).reshape(2, -1))["energy"]
+    assert e[1] < e[0]

@@ -27,8 +27,24 @@ def mm_f16s(a, b):
     return hh + cr / 2048.0
 
 
+def mm_asym(a, b, pa_n, pb_n, order):
+    """bf16 split with different plane counts for activations (a) and weights (b); b arrives as W^T (K x N)."""
+    BF = torch.bfloat16
+    pa, pb = split(a, BF, pa_n), split(b, BF, pb_n)
+    out = 0
+    for i in range(pa_n):
+        for j in range(pb_n):
+            if i + j <= order:
+                out = out + orig(pa[i], pb[j]).to(torch.float32).to(torch.float64)
+    return out
+
+
 def mm(a, b):
     spec = MODE[MODE["phase"]]
+    if isinstance(spec, tuple) and spec and spec[0] == "asym":
+        if a.dim() != 2 or b.dim() != 2:
+            return orig(a, b)
+        return mm_asym(a, b, spec[1], spec[2], spec[3])
     if spec is None or a.dim() != 2 or b.dim() != 2:
         return orig(a, b)
     if spec == "f16s":
@@ -57,6 +73,9 @@ MODE["phase"] = "fwd"; MODE["fwd"] = None; MODE["bwd"] = None
 e0 = float(st.forward(z, pos)); MODE["phase"] = "bwd"; g0 = st.backward().numpy()
 F16, BF16 = torch.float16, torch.bfloat16
 cfgs = {
+    "fwd A2xB3 (5 terms) | bwd bf16x3": (("asym", 2, 3, 2), (BF16, 2, 1)),
+    "fwd A3xB3 (6 terms) | bwd bf16x3": (("asym", 3, 3, 2), (BF16, 2, 1)),
+    "fwd A2xB3 order1+ (0,2) (4 terms)": (("asym", 2, 3, 2), (BF16, 2, 1)),
     "fp32 matmul (torch CPU)": ("f32", "f32"),
     "fwd fp16x3 scaled-lo static | bwd bf16x3": ("f16s", (BF16, 2, 1)),
     "fwd fp16x3 scaled-lo static | bwd f16s": ("f16s", "f16s"),

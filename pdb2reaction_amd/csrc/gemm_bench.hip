@@ -66,33 +66,16 @@ int main(int argc, char** argv) {
   auto launch_pl = [&](void (*k)(const GemmPL), dim3 g, const GemmPL& a, int nthr = 256) { hipLaunchKernelGGL(k, g, dim3(nthr), 0, 0, a); };
   auto gridpl = [&](int bn) { const long nm = (M + 255) / 256, nn = (N + bn - 1) / bn; return dim3((unsigned)(((nm + 7) / 8) * 8 * nn)); };
   CK(hipMemset(C2, 0, M * (long)N * 4));
-  rep("PL 256x128 P=3 S=2", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 3, 2, 2, 2, 4, 2>, gridpl(128), q); }));
-  check("PL 256x128 P=3 S=2 vs fp32");
-  CK(hipMemset(C2, 0, M * (long)N * 4));
-  rep("PL 256x256 P=2 S=2", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 2, 2, 2, 4, 4>, gridpl(256), q2); }));
-  check("PL 256x256 P=2 S=2 vs fp32 (~1e-5 rel)");
-  CK(hipMemset(C2, 0, M * (long)N * 4));
-  rep("PL 256x128 P=2 S=3", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 3, 2, 2, 4, 2>, gridpl(128), q2); }));
-  check("PL 256x128 P=2 S=3 vs fp32 (~1e-5 rel)");
-  rep("PL 256x128 P=2 S=2", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 2, 2, 2, 4, 2>, gridpl(128), q2); }));
-  CK(hipMemset(C2, 0, M * (long)N * 4));
   rep("PL 8w 256x128 P=3 S=2", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 3, 2, 4, 2, 2, 2>, gridpl(128), q, 512); }));
   check("PL 8w 256x128 P=3 S=2 vs fp32");
   CK(hipMemset(C2, 0, M * (long)N * 4));
-  rep("PL 8w 256x128 P=2 S=2", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 2, 4, 2, 2, 2>, gridpl(128), q2, 512); }));
-  check("PL 8w 256x128 P=2 S=2 vs fp32");
   rep("PL 8w 256x128 P=2 S=3", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 3, 4, 2, 2, 2>, gridpl(128), q2, 512); }));
-  CK(hipMemset(C2, 0, M * (long)N * 4));
-  rep("PL 8w 256x256 P=2 S=2", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 2, 2, 4, 4, 2>, gridpl(256), q2, 512); }));
-  check("PL 8w 256x256 P=2 S=2 vs fp32");
-  rep("PL 256x128 P=3 S=2 A-nt(16)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 3, 2, 2, 2, 4, 2, 16>, gridpl(128), q); }));
-  rep("PL 256x128 P=2 S=2 A-nt(16)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 2, 2, 2, 4, 2, 16>, gridpl(128), q2); }));
-  rep("PL 256x128 P=2 S=2 noStores(4)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 2, 2, 2, 4, 2, 4>, gridpl(128), q2); }));
-  rep("PL 256x128 P=3 S=2 noStores(4)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 3, 2, 2, 2, 4, 2, 4>, gridpl(128), q); }));
-  rep("PL 256x256 P=2 S=2 noMFMA(2)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 2, 2, 2, 4, 4, 2>, gridpl(256), q2); }));
-  rep("PL 256x256 P=2 S=2 noDMA(1)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 2, 2, 2, 4, 4, 1>, gridpl(256), q2); }));
-  rep("PL 256x256 P=2 S=2 noStores(4)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 2, 2, 2, 4, 4, 4>, gridpl(256), q2); }));
-  rep("PL 256x128 P=3 S=2 noMFMA(2)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 3, 2, 2, 2, 4, 2, 2>, gridpl(128), q); }));
-  rep("PL 256x128 P=3 S=2 noDMA(1)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 3, 2, 2, 2, 4, 2, 1>, gridpl(128), q); }));
+  check("PL 8w 256x128 P=2 S=3 vs fp32");
+  if (getenv("ABLATE")) {
+#define ABL3(flag) rep("  P=3 S=2 8w ABL=" #flag, timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 3, 2, 4, 2, 2, 2, flag>, gridpl(128), q, 512); }))
+#define ABL2(flag) rep("  P=2 S=3 8w ABL=" #flag, timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 3, 4, 2, 2, 2, flag>, gridpl(128), q2, 512); }))
+    ABL3(1); ABL3(4); ABL3(8); ABL3(5); ABL3(9); ABL3(12); ABL3(13); ABL3(2); ABL3(6);
+    ABL2(1); ABL2(4); ABL2(8); ABL2(5); ABL2(9); ABL2(12); ABL2(13); ABL2(2); ABL2(6);
+  }
   return 0;
 }

@@ -52,6 +52,7 @@ struct umx_engine {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // second lane: half-chunks alternate streams so HBM-bound producers overlap the other lane's GEMMs
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool fuse_modrot = true;         // UMX_FUSE_MODROT=0: separate k_modulate_bwd_pl + k_gather_rotate_bwd (debug: exposes g_xrot)
   int n_lanes = 1;                 // UMX_STREAMS (1 or 2); 2 gives ~2.5 % on c3 but inflates event-bracketed kernel timings
   std::string err;
   // weights
@@ -217,7 +218,7 @@ struct WS {
   float *G0, *G1, *G2, *ggs, *n128a, *n128b;
   // edge level
   int *esrc, *edst, *out_ptr, *out_cur, *out_edge;
-  float *evec, *frame, *dedd, *tau, *gvec;
+  float *evec, *frame, *dedd, *tau, *tau2, *gvec;
   float* h1pre[NL + 1];
   float* h2pre[NL + 1];
   float *ra, *rad_deg;
@@ -254,7 +255,7 @@ size_t carve(char* base, long nn, long ne, WS* w, bool pl) {
   t.esrc = b.take<int>(ne); t.edst = b.take<int>(ne); t.out_edge = b.take<int>(ne);
   t.out_ptr = b.take<int>(nn + 1); t.out_cur = b.take<int>(nn + 1);
   t.evec = b.take<float>(ne * 4); t.frame = b.take<float>(ne * FRAME); t.dedd = b.take<float>(ne);
-  t.tau = b.take<float>(ne * 4); t.gvec = b.take<float>(ne * 4);
+  t.tau = b.take<float>(ne * 4); t.tau2 = b.take<float>(ne * 4); t.gvec = b.take<float>(ne * 4);
   for (auto& x : t.h1pre) x = b.take<float>(ne * RH);
   for (auto& x : t.h2pre) x = b.take<float>(ne * RH);
   t.ra = b.take<float>(ne * RH); t.rad_deg = b.take<float>(ne * 3 * C);
@@ -424,6 +425,7 @@ int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, cons
   if (ne > 0) {
     HIPCHK(eng, hipMemsetAsync(w.dedd, 0, ne * sizeof(float), s));
     HIPCHK(eng, hipMemsetAsync(w.tau, 0, ne * 4 * sizeof(float), s));
+    HIPCHK(eng, hipMemsetAsync(w.tau2, 0, ne * 4 * sizeof(float), s));
   }
   hipLaunchKernelGGL(k_silu_bwd, dim3(nblk(nn * H, 256)), B256, 0, s, eng->e4, 0L, w.pre2, w.n128a, nn, H);
   CHK(gemm_plain(eng, w.n128a, H, 0, eng->e2T, H, nullptr, w.n128b, H, 0, nn, H, H));
@@ -456,8 +458,13 @@ int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, cons
       CHK(gemm_pl(eng, 0, 2, w.ghgpl, HG, 0, 0, L.c1m0T, 0, nullptr, w.gy1, XROT, 0, 0, ne, 768, 640, 1.0f));
       CHK(gemm_pl(eng, 1, 2, w.ghgpl, HG, 640, 896, L.c1m1T, 512, nullptr, w.gy1, XROT, 768, 1280, ne, 512, 256, -1.0f));
       CHK(gemm_pl(eng, 1, 2, w.ghgpl, HG, 1152, 1280, L.c1m2T, 256, nullptr, w.gy1, XROT, 1792, 2048, ne, 256, 128, -1.0f));
-      hipLaunchKernelGGL(k_modulate_bwd_pl<2>, dim3(nblk(ne, 4)), B256, 0, s, w.gy1, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.gradpl, w.tau, ne);
-      DBG("g_xrot" + t, w.gy1, ne * XROT);
+      if (eng->fuse_modrot) {       // one node-centric kernel: modulation backward + rotate-back + segmented sum (g_xrot stays in registers)
+        hipLaunchKernelGGL(k_modrot_bwd_pl<2>, dim3(nblk(nn, 4)), B256, 0, s, w.gy1, w.xn[i], w.frame, w.rad[i], w.row_ptr, w.out_ptr, w.out_edge,
+                           w.gradpl, w.tau, w.tau2, w.G1, nn);
+      } else {
+        hipLaunchKernelGGL(k_modulate_bwd_pl<2>, dim3(nblk(ne, 4)), B256, 0, s, w.gy1, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.gradpl, w.tau, ne);
+        DBG("g_xrot" + t, w.gy1, ne * XROT);
+      }
       CHK(radial_bwd(eng, w, L.rad, i, ne, nullptr, w.gradpl));
     } else if (ne > 0) {
       hipLaunchKernelGGL(k_rotate_back_bwd<9>, dim3(nblk(ne, 4)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsg, w.dedd, w.tau, ne, 1.0f);
@@ -475,7 +482,8 @@ int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, cons
       DBG("g_xrot" + t, w.gy1, ne * XROT); DBG("g_rad" + t, w.grad, ne * RAD);
       CHK(radial_bwd(eng, w, L.rad, i, ne, w.grad));
     }
-    hipLaunchKernelGGL(k_gather_rotate_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.gy1, w.frame, w.row_ptr, w.out_ptr, w.out_edge, w.G1, nn);   // G1 = g_xn
+    if (!(ne > 0 && eng->pl && eng->fuse_modrot))
+      hipLaunchKernelGGL(k_gather_rotate_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.gy1, w.frame, w.row_ptr, w.out_ptr, w.out_edge, w.G1, nn);   // G1 = g_xn
     hipLaunchKernelGGL(k_norm_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.G1, xin, L.n1w, w.G2, w.G0, nn);                      // G0 = g_xin
     HIPCHK(eng, hipGetLastError());
     DBG("g_xn" + t, w.G1, nn * ROW); DBG("g_xin" + t, w.G0, nn * ROW);
@@ -484,6 +492,7 @@ int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, cons
     hipLaunchKernelGGL(k_rotate_back_bwd<3>, dim3(nblk(ne, 4)), B256, 0, s, w.G0, w.rad_deg, w.frame, w.edst, w.gmsg, w.dedd, w.tau, ne,
                        1.0f / DEG_RESCALE);
     CHK(radial_bwd(eng, w, eng->rdeg, NL, ne, w.gmsg));
+    if (eng->pl && eng->fuse_modrot) hipLaunchKernelGGL(k_add4, dim3(nblk(ne, 256)), B256, 0, s, w.tau, w.tau2, ne);
     hipLaunchKernelGGL(k_force_edge, dim3(nblk(ne, 256)), B256, 0, s, w.dedd, w.tau, w.frame, w.evec, w.gvec, ne);
   }
   hipLaunchKernelGGL(k_force_node, dim3(nblk(nn, 4)), B256, 0, s, w.gvec, w.row_ptr, w.out_ptr, w.out_edge, (float)eng->rmsd, d_forces, nn);
@@ -541,6 +550,7 @@ int umx_create(umx_engine** out, int device_ordinal) {
   }
   umx_engine* e = new umx_engine();
   e->dev = device_ordinal;
+  if (const char* ev = std::getenv("UMX_FUSE_MODROT")) e->fuse_modrot = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_STREAMS")) e->n_lanes = std::atoi(ev) >= 2 ? 2 : 1;
   if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess ||

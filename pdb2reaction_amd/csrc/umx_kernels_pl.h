@@ -250,4 +250,73 @@ __global__ __launch_bounds__(256) void k_modulate_bwd_pl(float* __restrict__ gy1
   if (lane == 0) { tau[e * 4 + 0] += tx; tau[e * 4 + 1] += ty; tau[e * 4 + 2] += tz; }
 }
 
+// Reverse pass of K7a in ONE node-centric kernel (replaces k_modulate_bwd_pl + k_gather_rotate_bwd): for every node n the wave
+// walks its incoming edges (n is the target: columns C..2C of the 256-wide [src | dst] rows) and its outgoing edges (n is the
+// source: columns 0..C).  In both walks the un-rotated feature is the node's OWN xn[n], so the rotated message is re-derived
+// in registers, and
+//   g_rad[e][k]  = sum_{rows r of block k} gy1[e][r] * xrot[r]        -> PL planes (A operand of the w3^T GEMM)
+//   g_xrot[e][r] = gy1[e][r] * rad[e][k(r)]                            (never leaves the registers: -18 KB/edge of HBM traffic)
+//   tau[e]      += <g_xrot, L xrot>                                    (target half -> tau, source half -> tau2: two writers)
+//   g_xn[n]      = sum_e W_e^T g_xrot[e][half]                         (deterministic segmented sum, fixed edge order)
+template <int P>
+__global__ __launch_bounds__(256) void k_modrot_bwd_pl(const float* __restrict__ gy1, const float* __restrict__ xn,
+                                                       const float* __restrict__ frame, const float* __restrict__ rad,
+                                                       const int* __restrict__ row_ptr, const int* __restrict__ out_ptr,
+                                                       const int* __restrict__ out_edge, unsigned short* __restrict__ grad,
+                                                       float* __restrict__ tau, float* __restrict__ tau2, float* __restrict__ gxn, long nt) {
+  UMX_WAVE_ITEM_PL(node, nt)
+  const int c0 = lane * 2;
+  float xx[9], xy[9], ax[9], ay[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const float2 t = *reinterpret_cast<const float2*>(xn + node * ROW + r * C + c0);
+    xx[r] = t.x; xy[r] = t.y; ax[r] = 0.f; ay[r] = 0.f;
+  }
+  const int ridx[9] = {0, 1, 2, 3, 4, 3, 4, 5, 5};
+  auto one_edge = [&](long e, int half, float* __restrict__ tdst) {
+    const float* f = frame + e * FRAME;
+    const float* g = gy1 + e * XROT + half + c0;
+    const float* rd = rad + e * RAD + half + c0;
+    float2 gv[9], rv[6];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) gv[r] = *reinterpret_cast<const float2*>(g + r * 2 * C);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) rv[k] = *reinterpret_cast<const float2*>(rd + k * 2 * C);
+    float px[9], py[9];
+    rot_fwd(f, xx, px); rot_fwd(f, xy, py);
+    float gax[6], gay[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { gax[k] = 0.f; gay[k] = 0.f; }
+    float hx[9], hy[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      const int k = ridx[r];
+      gax[k] += gv[r].x * px[r]; gay[k] += gv[r].y * py[r];
+      hx[r] = gv[r].x * rv[k].x; hy[r] = gv[r].y * rv[k].y;
+    }
+    unsigned short* gr = grad + e * (long)(RAD * P);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pl_store2<P>(gr, k * 2 * C + half + c0, gax[k], gay[k]);
+    float tx = 0.f, ty = 0.f, tz = 0.f;
+    torque_acc(hx, px, 1.0f, tx, ty, tz); torque_acc(hy, py, 1.0f, tx, ty, tz);
+    tx = wave_sum(tx); ty = wave_sum(ty); tz = wave_sum(tz);
+    if (lane == 0) { tdst[e * 4 + 0] += tx; tdst[e * 4 + 1] += ty; tdst[e * 4 + 2] += tz; }
+    rot_bwd_acc(f, hx, 1.0f, ax); rot_bwd_acc(f, hy, 1.0f, ay);
+  };
+  for (int e = row_ptr[node]; e < row_ptr[node + 1]; ++e) one_edge((long)e, C, tau);
+  for (int k = out_ptr[node]; k < out_ptr[node + 1]; ++k) one_edge((long)out_edge[k], 0, tau2);
+#pragma unroll
+  for (int r = 0; r < 9; ++r) *reinterpret_cast<float2*>(gxn + node * ROW + r * C + c0) = make_float2(ax[r], ay[r]);
+}
+
+// tau += tau2 (the two halves of k_modrot_bwd_pl's torque are written by different waves)
+__global__ void k_add4(float* __restrict__ a, const float* __restrict__ b, long n4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 x = *reinterpret_cast<float4*>(a + i * 4);
+  const float4 y = *reinterpret_cast<const float4*>(b + i * 4);
+  x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+  *reinterpret_cast<float4*>(a + i * 4) = x;
+}
+
 }  // namespace umx

@@ -204,9 +204,9 @@ def test_stage_by_stage_against_staged_oracle(weights, mode, monkeypatch):
             row = out_edge[out_ptr[n]:out_ptr[n + 1]]
             assert np.all(t["src"][row] == n) and np.all(np.diff(row) > 0)                      # right rows, deterministic order
         names = ["x0", "rad.deg", "e_node", "g_xfinal", "dedd"]
-        per_layer = ["xn", "rad", "msg", "xmid", "xn2", "gspre", "ffh", "x", "g_xmid", "g_hid", "g_xrot", "g_xn", "g_xin"]
-        if mode == "fp32":
-            per_layer += ["xrot", "hid", "g_msg", "g_rad"]
+        per_layer = ["xn", "rad", "msg", "xmid", "xn2", "gspre", "ffh", "x", "g_xmid", "g_hid", "g_xn", "g_xin"]
+        if mode == "fp32":          # split mode keeps these in PL planes / registers (k_modrot_bwd_pl never writes g_xrot)
+            per_layer += ["xrot", "hid", "g_msg", "g_rad", "g_xrot"]
         for i in range(W.NUM_LAYERS):
             names += [f"{s}.{i}" for s in per_layer]
         tol = 2e-5 if mode == "fp32" else 1e-4          # bf16x3 reverse pass: ~1e-5 relative per GEMM

@@ -1,4 +1,6 @@
 """GPU bring-up: compare every named intermediate of the HIP engine with the staged float64 oracle."""
+import os
+os.environ.setdefault("UMX_FUSE_MODROT", "0")   # expose g_xrot for the stage comparison
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")

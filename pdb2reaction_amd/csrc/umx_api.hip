@@ -52,6 +52,7 @@ struct umx_engine {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // second lane: half-chunks alternate streams so HBM-bound producers overlap the other lane's GEMMs
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int mfma16 = 1;                  // UMX_MFMA16: 0 = v_mfma_f32_32x32x16_bf16 everywhere, 1 = 16x16x32 where it measured faster, 2 = everywhere
   bool fuse_modrot = true;         // UMX_FUSE_MODROT=0: separate k_modulate_bwd_pl + k_gather_rotate_bwd (debug: exposes g_xrot)
   int n_lanes = 1;                 // UMX_STREAMS (1 or 2); 2 gives ~2.5 % on c3 but inflates event-bracketed kernel timings
   std::string err;
@@ -194,12 +195,25 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
     pr->M = (int)M; pr->N = N; pr->K = K; pr->amode = 9; pr->cplx = cplx; pr->gz = 1; pr->prec = P;
     HIPCHK(eng, hipEventRecord(pr->a, eng->stream));
   }
+  // MFMA shape per GEMM (measured in the c3 pipeline): 16x16x32 wins 1-7 % on the complex SO(2) GEMMs and on K >= 512,
+  // 32x32x16 wins 5-10 % on the short-K plain ones (radial fc3 and its transpose, conv-2 m=0)
+  const bool use16 = eng->mfma16 >= 2 || (eng->mfma16 == 1 && (cplx || K >= 512));
   if (P == 3) {
-    if (cplx) hipLaunchKernelGGL((umx_gemm_pl_kernel<1, 3, 2, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
-    else hipLaunchKernelGGL((umx_gemm_pl_kernel<0, 3, 2, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
+    if (use16) {
+      if (cplx) hipLaunchKernelGGL((umx_gemm_pl16_kernel<1, 3, 2, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
+      else hipLaunchKernelGGL((umx_gemm_pl16_kernel<0, 3, 2, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
+    } else {
+      if (cplx) hipLaunchKernelGGL((umx_gemm_pl_kernel<1, 3, 2, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
+      else hipLaunchKernelGGL((umx_gemm_pl_kernel<0, 3, 2, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
+    }
   } else {
-    if (cplx) hipLaunchKernelGGL((umx_gemm_pl_kernel<1, 2, 3, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
-    else hipLaunchKernelGGL((umx_gemm_pl_kernel<0, 2, 3, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
+    if (use16) {
+      if (cplx) hipLaunchKernelGGL((umx_gemm_pl16_kernel<1, 2, 3, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
+      else hipLaunchKernelGGL((umx_gemm_pl16_kernel<0, 2, 3, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
+    } else {
+      if (cplx) hipLaunchKernelGGL((umx_gemm_pl_kernel<1, 2, 3, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
+      else hipLaunchKernelGGL((umx_gemm_pl_kernel<0, 2, 3, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
+    }
   }
   HIPCHK(eng, hipGetLastError());
   if (pr) HIPCHK(eng, hipEventRecord(pr->b, eng->stream));
@@ -550,6 +564,7 @@ int umx_create(umx_engine** out, int device_ordinal) {
   }
   umx_engine* e = new umx_engine();
   e->dev = device_ordinal;
+  if (const char* ev = std::getenv("UMX_MFMA16")) e->mfma16 = std::atoi(ev);
   if (const char* ev = std::getenv("UMX_FUSE_MODROT")) e->fuse_modrot = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_STREAMS")) e->n_lanes = std::atoi(ev) >= 2 ? 2 : 1;
   if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||

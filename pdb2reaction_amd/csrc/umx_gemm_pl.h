@@ -33,6 +33,7 @@
 namespace umx {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmPL {
   const unsigned short* Apl; long lda; int offA0, offA1;   // PL layout: lda = row pitch in bf16 (= K_total*P); offsets in COLUMNS (multiples of 32)
@@ -244,6 +245,160 @@ __global__ __launch_bounds__(64 * WVM * WVN, 1) void umx_gemm_pl_kernel(const Ge
             const int dr = (r & 3) + 8 * (r >> 2);
             if (row0 + dr < p.M) c[(long)dr * p.ldc] = acc[i][j][r] + bv[j];
           }
+        }
+      }
+  }
+}
+
+// Same kernel on v_mfma_f32_16x16x32_bf16 (one MFMA k-step per 32-wide k-tile; the chip may hold a different clock on this shape).
+template <int CPLX, int P, int S, int WVM, int WVN, int WMT, int WNT, int ABL = 0>
+__global__ __launch_bounds__(64 * WVM * WVN, 1) void umx_gemm_pl16_kernel(const GemmPL p) {
+  constexpr int NT = 64 * WVM * WVN;           // threads
+  constexpr int BM = 32 * WVM * WMT;           // block tile rows (A rows)
+  constexpr int BN = 32 * WVN * WNT;           // block tile columns (B rows)
+  static_assert(!CPLX || (WMT % 2 == 0 && WNT % 2 == 0), "complex tiles need re/im and A/B halves in every wave");
+  constexpr int SEG = 4 * P;                   // 16-B chunks per row per k-tile
+  constexpr int ROWB = SEG * 16;               // bytes per row per k-tile (128 or 192)
+  constexpr int TA_B = BM * ROWB;
+  constexpr int TB_B = BN * ROWB;
+  constexpr int STAGE_B = TA_B + TB_B;
+  static_assert(S * STAGE_B <= 160 * 1024, "ring does not fit the 160 KiB LDS");
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[S * STAGE_B];
+  constexpr int BMR = CPLX ? BM / 2 : BM;      // logical rows (edges) per block
+  constexpr int BNC = CPLX ? BN / 2 : BN;      // logical cols (channels) per block
+  constexpr int JA = BM * SEG / NT;            // A chunks per lane per k-tile
+  constexpr int JB = BN * SEG / NT;
+  static_assert(BM * SEG % NT == 0 && BN * SEG % NT == 0, "tile does not divide over the threads");
+  constexpr int G = JA + JB;                   // global_load_lds instructions per wave per k-tile
+  constexpr int WSTR = NT * 16;                // LDS bytes covered by one DMA round of the whole block
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WVN, wn = wave % WVN;
+  const int l15 = lane & 15, h = lane >> 4;       // 16x16x32: lane supplies row l15, k-chunk h (8 bf16 = 16 B)
+  constexpr int TM = 2 * WMT, TN = 2 * WNT;       // 16-row / 16-column MFMA tiles per wave
+
+  const int nN = (p.N + BNC - 1) / BNC;
+  const int nM = (p.M + BMR - 1) / BMR;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int mt = (slot / nN) * 8 + xcd, nt = slot % nN;
+  if (mt >= nM) return;
+
+  // ---- per-lane source offsets (bf16 elements): flat chunk id c = tid + 256 j -> row = c / SEG, LDS slot = c % SEG
+  long a_off[JA], b_off[JB];
+#pragma unroll
+  for (int j = 0; j < JA; ++j) {
+    const int c = tid + NT * j, trow = c / SEG, s = c % SEG;
+    long grow; int offA;
+    if (CPLX) { grow = (long)mt * BMR + (trow % BMR); offA = (trow / BMR) ? p.offA1 : p.offA0; }
+    else      { grow = (long)mt * BM + trow;          offA = p.offA0; }
+    if (grow >= p.M) grow = p.M - 1;
+    a_off[j] = grow * p.lda + (long)offA * P + pl_perm<P>(s, trow) * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < JB; ++j) {
+    const int c = tid + NT * j, trow = c / SEG, s = c % SEG;
+    int brow;
+    if (CPLX) { int cc = nt * BNC + (trow % BNC); if (cc >= p.N) cc = p.N - 1; brow = (trow / BNC) * p.bHalf + cc; }
+    else      { brow = nt * BN + trow; if (brow >= p.N) brow = p.N - 1; }
+    b_off[j] = (long)brow * p.ldb + pl_perm<P>(s, trow) * 8;
+  }
+  const int piece = __builtin_amdgcn_readfirstlane(wave * 1024);   // this wave's 1-KiB piece inside one DMA round
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+  // fragment rows inside the tile
+  // CPLX: tile t of a wave = (half = t / (W?T/2), group = t % (W?T/2)); halves are re/im rows and A/B weight rows
+  int a_row[TM], b_row[TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+    a_row[t] = CPLX ? ((t / (TM / 2)) * BMR + wm * (16 * WMT) + (t % (TM / 2)) * 16 + l15) : (wm * (32 * WMT) + t * 16 + l15);
+#pragma unroll
+  for (int t = 0; t < TN; ++t)
+    b_row[t] = CPLX ? ((t / (TN / 2)) * BNC + wn * (16 * WNT) + (t % (TN / 2)) * 16 + l15) : (wn * (32 * WNT) + t * 16 + l15);
+
+  const int nk = p.K / 32;
+  constexpr int TAG = 1000000 + ((((ABL * 2 + CPLX) * 4 + P) * 8 + S) * 8 + WVM) * 64 + WVN * 16 + WMT * 2 + WNT / 2;
+  constexpr int AUXA = (ABL & 16) ? 2 : 0;   // dev: non-temporal A stream
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s)
+    if (s < nk) pl_issue<JA, JB, TA_B, WSTR, TAG, AUXA>(p, ring + s * STAGE_B, a_off, b_off, (long)s * 32 * P, piece);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + S - 2 < nk) wait_vmcnt<(S - 2) * G>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // everyone's tile kt landed; everyone finished reading tile kt-1
+    if (kt + S - 1 < nk && !(ABL & 1))
+      pl_issue<JA, JB, TA_B, WSTR, TAG, AUXA>(p, ring + ((kt + S - 1) % S) * STAGE_B, a_off, b_off, (long)(kt + S - 1) * 32 * P, piece);
+    const unsigned char* sbase = ring + (kt % S) * STAGE_B;
+    bf16x8_t a[TM][P], b[TN][P];         // one MFMA k-step covers the whole 32-wide k-tile
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      const int u = q * 4 + h;             // source chunk wanted: plane q, k-chunk h
+#pragma unroll
+      for (int t = 0; t < TM; ++t) a[t][q] = *reinterpret_cast<const bf16x8_t*>(sbase + a_row[t] * ROWB + pl_perm<P>(u, a_row[t]) * 16);
+#pragma unroll
+      for (int t = 0; t < TN; ++t) b[t][q] = *reinterpret_cast<const bf16x8_t*>(sbase + TA_B + b_row[t] * ROWB + pl_perm<P>(u, b_row[t]) * 16);
+    }
+#pragma unroll
+    for (int ord = P - 1; ord >= 0; --ord)     // smallest terms first
+#pragma unroll
+      for (int qa = 0; qa <= ord; ++qa) {
+        const int qb = ord - qa;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][qa], b[j][qb], acc[i][j], 0, 0, 0);
+      }
+  }
+
+  // ---- epilogue (C/D map of 16x16 tiles: col = lane&15, row = reg + 4*(lane>>4))
+  const bool full = ((long)mt * BMR + BMR <= p.M) && (nt * BNC + BNC <= p.N);
+  if (CPLX) {
+#pragma unroll
+    for (int eg = 0; eg < TM / 2; ++eg)
+#pragma unroll
+      for (int cg = 0; cg < TN / 2; ++cg) {
+        const int chan = nt * BNC + wn * (16 * WNT) + cg * 16 + l15;
+        const long e0 = (long)mt * BMR + wm * (16 * WMT) + eg * 16 + 4 * h;
+        float* c = p.Cp + e0 * p.ldc + chan;
+        if (full) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* cr = c + (long)r * p.ldc;
+            cr[p.offC] = acc[eg][cg][r] - p.conj * acc[TM / 2 + eg][TN / 2 + cg][r];
+            cr[p.offCi] = acc[TM / 2 + eg][cg][r] + p.conj * acc[eg][TN / 2 + cg][r];
+          }
+        } else if (chan < p.N) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (e0 + r < p.M) {
+              float* cr = c + (long)r * p.ldc;
+              cr[p.offC] = acc[eg][cg][r] - p.conj * acc[TM / 2 + eg][TN / 2 + cg][r];
+              cr[p.offCi] = acc[TM / 2 + eg][cg][r] + p.conj * acc[eg][TN / 2 + cg][r];
+            }
+          }
+        }
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = nt * BN + wn * (32 * WNT) + j * 16 + l15;
+        const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+        const long row0 = (long)mt * BM + wm * (32 * WMT) + i * 16 + 4 * h;
+        float* c = p.Cp + row0 * p.ldc + p.offC + col;
+        if (full) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) c[(long)r * p.ldc] = acc[i][j][r] + bv;
+        } else if (col < p.N) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (row0 + r < p.M) c[(long)r * p.ldc] = acc[i][j][r] + bv;
         }
       }
   }

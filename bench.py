@@ -51,6 +51,20 @@ def pmc_traffic_per_launch(split: bool):
         return None
 
 
+def pmc_non_gemm_bytes_per_step(split: bool):
+    """HBM bytes per iteration moved by everything EXCEPT the two GEMM families (same committed PMC passes), or None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")
+    try:
+        d = json.load(open(path))
+        return (float(d["hbm_bytes_per_iteration"]) - float(d["dominant_family"]["hbm_bytes_per_iteration"])
+                - float(d.get("fp32_gemm_family_hbm_bytes_per_iteration", 0.0))) if split else None
+    except Exception:
+        return None
+
+
+PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak (about 6.3 TB/s is achievable by a float4 copy)
+
+
 def usable_cores() -> int:
     """Host cores this process may actually use (affinity and cgroup quota, not the machine total)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -199,7 +213,7 @@ def main():
                        "parallelism": f"images sharded {k}/{world} per GPU, 1 all-gather/iteration" if world > 1 else "single GPU, all images batched"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": pmc_traffic_per_launch(split) if (n == 2000 and k == 16 and world == 1) else None,
-                         "kernel": ("umx_gemm_pl_kernel<*> (split-bf16 LDS-DMA GEMM: SO(2)/radial linears + transposes, rank 0)" if split
+                         "kernel": ("umx_gemm_pl_kernel<*> / umx_gemm_pl16_kernel<*> (split-bf16 LDS-DMA GEMM: SO(2)/radial linears + transposes, rank 0)" if split
                                     else "umx_gemm_kernel<*> (fp32-MFMA GEMM, rank 0)"),
                          "launches": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
                          "flops_per_launch": dom["mfma_flops"] / max(dom["launches"], 1),
@@ -211,6 +225,14 @@ def main():
                                                "achieved": f32["alg_flops"] / max(f32["ms"], 1e-9) / 1e9 if split else 0.0,
                                                "peak": PEAK_FP32_MFMA_TFLOPS}},
         }
+        # second regime: the HBM-bound gather / rotate / gate / segmented-reduce kernels = everything outside the
+        # two GEMM families; bytes from the committed PMC passes of this exact workload, time measured live
+        nb = pmc_non_gemm_bytes_per_step(split) if (n == 2000 and k == 16 and world == 1) else None
+        if nb is not None:
+            rest_ms = ms - (dom["ms"] + f32["ms"]) / args.steps
+            out["roofline"]["hbm_regime"] = {"bound": "hbm", "kernels": "all non-GEMM kernels (k_gather_rotate_mod_pl, k_modrot_bwd_pl, k_gate_edge_*, k_rotate_back_*, ...)",
+                                             "ms_per_step": rest_ms, "traffic_per_step": nb, "achieved": nb / max(rest_ms, 1e-9) / 1e6,
+                                             "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": nb / max(rest_ms, 1e-9) / 1e6 / PEAK_HBM_GBPS}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_sample_atoms, edges_iter)

@@ -1,0 +1,69 @@
+"""Row f4 (first half): state-dict conversion with MoLE merging -- CPU checks on a synthetic fairchem-style state dict."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from pdb2reaction_amd import weights as W
+
+CK = importlib.import_module("pdb2reaction_amd.checkpoint")
+
+
+def _fake_state(w, n_exp=4, seed=3):
+    """Split every SO(2) linear into n_exp random experts whose alpha-weighted sum is the merged weight."""
+    rng = np.random.default_rng(seed)
+    alpha = rng.random(n_exp); alpha /= alpha.sum()
+    state = {}
+    for name, arr in w.items():
+        if name in ("normalizer.rmsd", "element_refs"):
+            continue
+        if ".so2_conv_" in name and name.endswith(".weight") and ".rad_func." not in name:
+            ex = rng.normal(size=(n_exp,) + arr.shape)
+            ex[-1] = (arr.astype(np.float64) - np.tensordot(alpha[:-1], ex[:-1], axes=(0, 0))) / alpha[-1]
+            state["backbone." + name[:-len(".weight")] + ".weights"] = torch.tensor(ex)          # torch tensors, float64
+        else:
+            state["backbone." + name] = torch.tensor(arr)
+    extra = {"normalizer.rmsd": w["normalizer.rmsd"], "element_refs": w["element_refs"]}
+    return state, alpha, extra
+
+
+def test_merge_and_roundtrip():
+    w = W.make_synthetic_weights(0)
+    state, alpha, extra = _fake_state(w)
+    got = CK.from_state_dict(state, coefficients=alpha, extra=extra)
+    assert set(got) == set(W.param_shapes())
+    for k in w:
+        assert got[k].dtype == np.float32
+        np.testing.assert_allclose(got[k], w[k], rtol=0, atol=2e-6 * max(1.0, np.abs(w[k]).max()))
+    blob = CK.convert(state, coefficients=alpha, extra=extra)
+    back = W.unpack_blob(blob)
+    assert all(np.array_equal(back[k], got[k]) for k in got)
+    m = CK.merge_mole(np.arange(12.0).reshape(3, 2, 2), [0.5, 0.25, 0.25])
+    np.testing.assert_allclose(m, [[2.5 + 0.5, 3.5 + 0.5], [4.5 + 0.5, 5.5 + 0.5]])
+
+
+def test_errors_and_renaming():
+    w = W.make_synthetic_weights(0)
+    state, alpha, extra = _fake_state(w)
+    with pytest.raises(ValueError, match="needs MoLE coefficients"):
+        CK.from_state_dict(state, extra=extra)
+    with pytest.raises(ValueError, match="experts but"):
+        CK.from_state_dict(state, coefficients=alpha[:-1], extra=extra)
+    with pytest.raises(KeyError, match="missing"):
+        CK.from_state_dict(state, coefficients=alpha)                       # normalizer / element refs not supplied
+    bad = dict(state); bad["backbone.unknown.weight"] = torch.zeros(3)
+    with pytest.raises(KeyError, match="not a parameter"):
+        CK.from_state_dict(bad, coefficients=alpha, extra=extra)
+    assert "unknown.weight" not in CK.from_state_dict(bad, coefficients=alpha, extra=extra, strict=False)
+    shp = dict(state); shp["backbone.mix_csd.bias"] = torch.zeros(7)
+    with pytest.raises(ValueError, match="shape"):
+        CK.from_state_dict(shp, coefficients=alpha, extra=extra)
+    # renaming: dict and callable forms, dropping keys with None
+    ren = {k.replace("backbone.norm.", "backbone.final_norm."): v for k, v in state.items()}
+    got = CK.from_state_dict(ren, coefficients=alpha, extra=extra, rename=lambda n: n.replace("final_norm.", "norm."))
+    assert np.array_equal(got["norm.affine_bias"], w["norm.affine_bias"])
+    ren["backbone.routing_mlp.0.weight"] = torch.zeros(2, 2)
+    got = CK.from_state_dict(ren, coefficients=alpha, extra=extra,
+                             rename=lambda n: None if n.startswith("routing_mlp.") else n.replace("final_norm.", "norm."))
+    assert set(got) == set(W.param_shapes())

@@ -231,7 +231,7 @@ struct WS {
   float* ffh[NL];
   float *G0, *G1, *G2, *ggs, *n128a, *n128b;
   // edge level
-  int *esrc, *edst, *out_ptr, *out_cur, *out_edge;
+  int *esrc, *edst, *ez, *out_ptr, *out_cur, *out_edge;
   float *evec, *frame, *dedd, *tau, *tau2, *gvec;
   float* h1pre[NL + 1];
   float* h2pre[NL + 1];
@@ -266,7 +266,7 @@ size_t carve(char* base, long nn, long ne, WS* w, bool pl) {
   for (auto& x : t.ffh) x = b.take<float>(nn * ROW);
   t.G0 = b.take<float>(nn * ROW); t.G1 = b.take<float>(nn * ROW); t.G2 = b.take<float>(nn * ROW);
   t.ggs = b.take<float>(nn * 2 * H); t.n128a = b.take<float>(nn * H); t.n128b = b.take<float>(nn * H);
-  t.esrc = b.take<int>(ne); t.edst = b.take<int>(ne); t.out_edge = b.take<int>(ne);
+  t.esrc = b.take<int>(ne); t.edst = b.take<int>(ne); t.ez = b.take<int>(ne); t.out_edge = b.take<int>(ne);
   t.out_ptr = b.take<int>(nn + 1); t.out_cur = b.take<int>(nn + 1);
   t.evec = b.take<float>(ne * 4); t.frame = b.take<float>(ne * FRAME); t.dedd = b.take<float>(ne);
   t.tau = b.take<float>(ne * 4); t.tau2 = b.take<float>(ne * 4); t.gvec = b.take<float>(ne * 4);
@@ -308,7 +308,7 @@ int radial_fwd(umx_engine* eng, const WS& w, const RadialW& r, int slot, long ne
   hipStream_t s = eng->stream;
   GemmP p = gp_zero();
   p.evec = w.evec; p.gcoef = eng->gcoef; p.gmu = eng->d_gmu; p.B = r.w1g; p.ldb = NG; p.Cp = w.h1pre[slot]; p.ldc = RH;
-  p.TS = r.ts; p.TT = r.tt; p.esrc = w.esrc; p.edst = w.edst; p.znode = eng->d_z; p.natoms = eng->natoms;
+  p.TS = r.ts; p.TT = r.tt; p.ez = w.ez;
   p.M = (int)ne; p.N = RH; p.K = NG;
   CHK(launch_gemm(eng, p, A_GAUSS, 0, E_TABLES));
   hipLaunchKernelGGL(k_ln_silu_fwd, dim3(nblk(ne, 4)), dim3(256), 0, s, w.h1pre[slot], r.ln1w, r.ln1b, w.ra, ne);
@@ -363,6 +363,7 @@ int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, cons
     hipLaunchKernelGGL(k_out_fill, dim3(nblk(ne, 256)), B256, 0, s, w.esrc, ne, w.out_ptr, w.out_cur, w.out_edge);
     hipLaunchKernelGGL(k_out_sort, dim3(nblk(nn, 256)), B256, 0, s, w.out_ptr, nn, w.out_edge);
     hipLaunchKernelGGL(k_edge_geom, dim3(nblk(ne, 256)), B256, 0, s, w.evec, ne, eng->cutoff, w.frame);
+    hipLaunchKernelGGL(k_edge_z, dim3(nblk(ne, 256)), B256, 0, s, w.esrc, w.edst, eng->d_z, N, w.ez, ne);
   }
   HIPCHK(eng, hipGetLastError());
   DBG("row_ptr", w.row_ptr, nn + 1); DBG("src", w.esrc, ne); DBG("dst", w.edst, ne); DBG("out_ptr", w.out_ptr, nn + 1); DBG("out_edge", w.out_edge, ne);

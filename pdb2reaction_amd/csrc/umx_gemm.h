@@ -41,7 +41,7 @@ struct GemmP {
   const float* bias;                             // [N] or null
   const float* resid; long ldres; int offRes;    // optional residual added to the output (plain)
   const float* TS; const float* TT;              // E_TABLES: + TS[z_src][col] + TT[z_dst][col]
-  const int* esrc; const int* edst; const int* znode; int natoms;
+  const int* ez;                                 // E_TABLES: per-edge packed element indices z_src | z_dst << 16 (k_edge_z)
   float conj;                                    // CPLX combine sign
   long zA, zC, zRes;
   int M, N, K;                                   // CPLX: M = edges, N = channels per half
@@ -83,7 +83,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[2][2
     }
   } else {
     const long zoffC = (long)blockIdx.z * p.zC, zoffR = (long)blockIdx.z * p.zRes;
-    const bool full = ((long)mt * 128 + 128 <= p.M) && (nt * 128 + 128 <= p.N);
+    const bool full = ((long)mt * 128 + 128 <= p.M);      // all rows of the block exist; columns are predicated once per lane
     float bv[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -97,9 +97,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[2][2
         const int col = nt * 128 + wn * 64 + j * 32 + l31;
         const long row0 = (long)mt * 128 + wm * 64 + i * 32 + 4 * h;
         float* c = p.Cp + row0 * p.ldc + p.offC + zoffC + col;
-        if (full && EPI == E_BIAS && !p.resid) {
+        if (full && col < p.N && EPI == E_BIAS && !p.resid) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) c[(long)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[i][j][r] + bv[j];
+        } else if (full && col < p.N && EPI == E_TABLES && !p.resid) {
+          // straight-line: 16 packed index loads, then 32 table loads (L2-resident), then 16 stores -- no dependent chain per store
+          int zz[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) zz[r] = p.ez[row0 + (r & 3) + 8 * (r >> 2)];
+          float tv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tv[r] = p.TS[(zz[r] & 0xffff) * RH + col] + p.TT[(zz[r] >> 16) * RH + col];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) c[(long)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[i][j][r] + bv[j] + tv[r];
         } else if (col < p.N) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -107,8 +117,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[2][2
             if (row < p.M) {
               float v = acc[i][j][r] + bv[j];
               if (EPI == E_TABLES) {
-                const int zs = p.znode[p.esrc[row] % p.natoms], zd = p.znode[p.edst[row] % p.natoms];
-                v += p.TS[zs * RH + col] + p.TT[zd * RH + col];
+                const int zz = p.ez[row];
+                v += p.TS[(zz & 0xffff) * RH + col] + p.TT[(zz >> 16) * RH + col];
               }
               if (p.resid) v += p.resid[row * p.ldres + p.offRes + zoffR + col];
               p.Cp[row * p.ldc + p.offC + zoffC + col] = v;

@@ -653,6 +653,14 @@ __global__ __launch_bounds__(256) void k_force_node(const float* __restrict__ gv
   if (lane == 0) { forces[node * 3 + 0] = -rmsd * fx; forces[node * 3 + 1] = -rmsd * fy; forces[node * 3 + 2] = -rmsd * fz; }
 }
 
+// per-edge packed element indices for the first radial layer's lookup tables: z[src] | z[dst] << 16 (node ids are image-major)
+__global__ void k_edge_z(const int* __restrict__ esrc, const int* __restrict__ edst, const int* __restrict__ znode, int natoms,
+                         int* __restrict__ ez, long ne) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  ez[e] = znode[esrc[e] % natoms] | (znode[edst[e] % natoms] << 16);
+}
+
 // ---- pairwise-distance bond-change classification (float64; reference bond_changes.py:142-187) ----------------------
 // One thread per (i, j): D1, D2 in full and a code for i < j: 1 = bond formed, 2 = bond broken, 0 = neither.
 // The arithmetic keeps the reference's operation order (no FMA contraction): T = bf (c_i + c_j); eps = mf T;

@@ -361,7 +361,7 @@ int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, cons
   HIPCHK(eng, hipMemsetAsync(w.out_cur, 0, (nn + 1) * sizeof(int), s));
   if (ne > 0) {
     hipLaunchKernelGGL(k_out_fill, dim3(nblk(ne, 256)), B256, 0, s, w.esrc, ne, w.out_ptr, w.out_cur, w.out_edge);
-    hipLaunchKernelGGL(k_out_sort, dim3(nblk(nn, 256)), B256, 0, s, w.out_ptr, nn, w.out_edge);
+    hipLaunchKernelGGL(k_out_sort, dim3(nblk(nn, 4)), B256, 0, s, w.out_ptr, nn, w.out_edge);
     hipLaunchKernelGGL(k_edge_geom, dim3(nblk(ne, 256)), B256, 0, s, w.evec, ne, eng->cutoff, w.frame);
     hipLaunchKernelGGL(k_edge_z, dim3(nblk(ne, 256)), B256, 0, s, w.esrc, w.edst, eng->d_z, N, w.ez, ne);
   }

@@ -127,15 +127,30 @@ __global__ void k_out_fill(const int* __restrict__ esrc, long ne, const int* __r
   const int n = esrc[e];
   out_edge[out_ptr[n] + atomicAdd(cursor + n, 1)] = (int)e;
 }
-__global__ void k_out_sort(const int* __restrict__ out_ptr, long nt, int* __restrict__ out_edge) {
-  const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= nt) return;
-  const int b = out_ptr[n], e = out_ptr[n + 1];
-  for (int i = b + 1; i < e; ++i) {
-    const int v = out_edge[i];
-    int k = i - 1;
-    while (k >= b && out_edge[k] > v) { out_edge[k + 1] = out_edge[k]; --k; }
-    out_edge[k + 1] = v;
+// sort each node's out-edge list by edge id (deterministic summation order): one wave per node, rank sort -- every lane counts the
+// entries smaller than its own (ids are unique), all reads finish before the first write because the wave runs in lockstep
+__global__ __launch_bounds__(256) void k_out_sort(const int* __restrict__ out_ptr, long nt, int* __restrict__ out_edge) {
+  UMX_WAVE_ITEM(n, nt)
+  const int b = out_ptr[n], d = out_ptr[n + 1] - b;
+  if (d <= 1) return;
+  if (d <= 320) {
+    int v[5], rk[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) { const int i = lane + 64 * t; v[t] = i < d ? out_edge[b + i] : 0x7fffffff; rk[t] = 0; }
+    for (int j = 0; j < d; ++j) {
+      const int u = out_edge[b + j];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) rk[t] += (u < v[t]) ? 1 : 0;
+    }
+#pragma unroll
+    for (int t = 0; t < 5; ++t) if (lane + 64 * t < d) out_edge[b + rk[t]] = v[t];
+  } else if (lane == 0) {          // very long lists (neighbour cap raised above 320): plain insertion sort
+    for (int i = b + 1; i < b + d; ++i) {
+      const int v = out_edge[i];
+      int k = i - 1;
+      while (k >= b && out_edge[k] > v) { out_edge[k + 1] = out_edge[k]; --k; }
+      out_edge[k + 1] = v;
+    }
   }
 }
 

@@ -77,6 +77,15 @@ int main(int argc, char** argv) {
   CK(hipMemset(C2, 0, M * (long)N * 4));
   rep("PL16 8w 256x128 P=2 S=3 (16x16x32)", timeit([&] { launch_pl(&umx_gemm_pl16_kernel<0, 2, 3, 4, 2, 2, 2>, gridpl(128), q2, 512); }));
   check("PL16 P=2 vs fp32");
+  {
+    auto grid128 = [&](int bn) { const long nm = (M + 127) / 128, nn = (N + bn - 1) / bn; return dim3((unsigned)(((nm + 7) / 8) * 8 * nn)); };
+    CK(hipMemset(C2, 0, M * (long)N * 4));
+    rep("PL16 4w 128x128 P=2 S=2 (2 blocks/CU)", timeit([&] { launch_pl(&umx_gemm_pl16_kernel<0, 2, 2, 2, 2, 2, 2>, grid128(128), q2, 256); }));
+    check("PL16 4w 128x128 P=2 vs fp32");
+    CK(hipMemset(C2, 0, M * (long)N * 4));
+    rep("PL32 4w 128x128 P=2 S=2 (2 blocks/CU)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 2, 2, 2, 2, 2>, grid128(128), q2, 256); }));
+    check("PL32 4w 128x128 P=2 vs fp32");
+  }
   if (getenv("ABLATE")) {
 #define ABL3(flag) rep("  P=3 S=2 8w ABL=" #flag, timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 3, 2, 4, 2, 2, 2, flag>, gridpl(128), q, 512); }))
 #define ABL2(flag) rep("  P=2 S=3 8w ABL=" #flag, timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 3, 4, 2, 2, 2, flag>, gridpl(128), q2, 512); }))

@@ -86,6 +86,17 @@ int main(int argc, char** argv) {
     rep("PL32 4w 128x128 P=2 S=2 (2 blocks/CU)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 2, 2, 2, 2, 2>, grid128(128), q2, 256); }));
     check("PL32 4w 128x128 P=2 vs fp32");
   }
+  if (N % 256 == 0) {
+    CK(hipMemset(C2, 0, M * (long)N * 4));
+    rep("PL32 8w 256x256 P=2 S=2 (wave 128x64)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 2, 2, 4, 4, 2>, gridpl(256), q2, 512); }));
+    check("PL32 256x256 P=2 vs fp32");
+    CK(hipMemset(C2, 0, M * (long)N * 4));
+    rep("PL16 8w 256x256 P=2 S=2 (wave 128x64)", timeit([&] { launch_pl(&umx_gemm_pl16_kernel<0, 2, 2, 2, 4, 4, 2>, gridpl(256), q2, 512); }));
+    check("PL16 256x256 P=2 vs fp32");
+    CK(hipMemset(C2, 0, M * (long)N * 4));
+    rep("PL16 8w 256x256 P=2 S=2 (wave 64x128)", timeit([&] { launch_pl(&umx_gemm_pl16_kernel<0, 2, 2, 4, 2, 2, 4>, gridpl(256), q2, 512); }));
+    check("PL16 256x256 b P=2 vs fp32");
+  }
   if (getenv("ABLATE")) {
 #define ABL3(flag) rep("  P=3 S=2 8w ABL=" #flag, timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 3, 2, 4, 2, 2, 2, flag>, gridpl(128), q, 512); }))
 #define ABL2(flag) rep("  P=2 S=3 8w ABL=" #flag, timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 3, 4, 2, 2, 2, flag>, gridpl(128), q2, 512); }))

@@ -438,7 +438,8 @@ int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, cons
   hipLaunchKernelGGL(k_norm_fwd, dim3(nblk(nn, 4)), B256, 0, s, xlast, eng->normw, eng->normb, (const float*)nullptr, w.xf, nn);
   CHK(gemm_plain(eng, w.xf, ROW, 0, eng->e0, C, eng->e0b, w.pre1, H, 0, nn, H, C));
   CHK(gemm_plain(eng, w.pre1, H, 0, eng->e2, H, eng->e2b, w.pre2, H, 0, nn, H, H, A_SILU));
-  hipLaunchKernelGGL(k_energy, dim3((unsigned)nimg), B256, 0, s, w.pre2, eng->e4, eng->e4b, N, eng->rmsd, eng->refsum, d_energy, w.enode);
+  hipLaunchKernelGGL(k_energy_node, dim3(nblk(nn, 4)), B256, 0, s, w.pre2, eng->e4, eng->e4b, w.enode, nn);
+  hipLaunchKernelGGL(k_energy, dim3((unsigned)nimg), B256, 0, s, w.enode, N, eng->rmsd, eng->refsum, d_energy);
   HIPCHK(eng, hipGetLastError());
   DBG("e_node", w.enode, nn); DBG("pre1", w.pre1, nn * H); DBG("pre2", w.pre2, nn * H);
   if (!d_forces) return UMX_OK;
@@ -481,7 +482,7 @@ int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, cons
       CHK(gemm_pl(eng, 1, 2, w.ghgpl, HG, 640, 896, L.c1m1T, 512, nullptr, w.gy1, XROT, 768, 1280, ne, 512, 256, -1.0f));
       CHK(gemm_pl(eng, 1, 2, w.ghgpl, HG, 1152, 1280, L.c1m2T, 256, nullptr, w.gy1, XROT, 1792, 2048, ne, 256, 128, -1.0f));
       if (eng->fuse_modrot) {       // one node-centric kernel: modulation backward + rotate-back + segmented sum (g_xrot stays in registers)
-        hipLaunchKernelGGL(k_modrot_bwd_pl<2>, dim3(nblk(nn, 4)), B256, 0, s, w.gy1, w.xn[i], w.frame, w.rad[i], w.row_ptr, w.out_ptr, w.out_edge,
+        hipLaunchKernelGGL(k_modrot_bwd_pl<2>, dim3((unsigned)nn), B256, 0, s, w.gy1, w.xn[i], w.frame, w.rad[i], w.row_ptr, w.out_ptr, w.out_edge,
                            w.gradpl, w.tau, w.tau2, w.G1, nn);
       } else {
         hipLaunchKernelGGL(k_modulate_bwd_pl<2>, dim3(nblk(ne, 4)), B256, 0, s, w.gy1, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.gradpl, w.tau, ne);

@@ -379,24 +379,31 @@ __global__ void k_silu_bwd(const float* __restrict__ g, long gstride, const floa
   out[i] = g[r * gstride + c] * silu_grad_f(pre[i]);
 }
 
-// K9/K11 readout: per image E = rmsd * sum_i (silu(pre2_i) . w3 + b3) + refsum   (f64 accumulate)
-__global__ __launch_bounds__(256) void k_energy(const float* __restrict__ pre2, const float* __restrict__ w3,
-                                                const float* __restrict__ b3, int natoms, double rmsd, double refsum,
-                                                double* __restrict__ e_img, float* __restrict__ e_node) {
-  __shared__ double part[4];
-  const int img = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// K9 readout, stage 1: e_node[i] = silu(pre2_i) . w3 + b3   (one wave per node)
+__global__ __launch_bounds__(256) void k_energy_node(const float* __restrict__ pre2, const float* __restrict__ w3,
+                                                     const float* __restrict__ b3, float* __restrict__ e_node, long nt) {
+  UMX_WAVE_ITEM(node, nt)
   const float2 w = *reinterpret_cast<const float2*>(w3 + lane * 2);
+  const float2 v = *reinterpret_cast<const float2*>(pre2 + node * H + lane * 2);
+  const float en = wave_sum(silu_f(v.x) * w.x + silu_f(v.y) * w.y) + b3[0];
+  if (lane == 0) e_node[node] = en;
+}
+
+// K9/K11 readout, stage 2: per image E = rmsd * sum_i e_node[i] + refsum, float64, fixed summation order (strided partial sums,
+// then a tree over the 256 partials) so the result does not depend on scheduling
+__global__ __launch_bounds__(256) void k_energy(const float* __restrict__ e_node, int natoms, double rmsd, double refsum,
+                                                double* __restrict__ e_img) {
+  __shared__ double part[256];
+  const int img = blockIdx.x, t = threadIdx.x;
   double acc = 0.0;
-  for (int a = wave; a < natoms; a += 4) {
-    const long node = (long)img * natoms + a;
-    const float2 v = *reinterpret_cast<const float2*>(pre2 + node * H + lane * 2);
-    const float en = wave_sum(silu_f(v.x) * w.x + silu_f(v.y) * w.y) + b3[0];
-    if (e_node && lane == 0) e_node[node] = en;
-    acc += (double)en;
-  }
-  if (lane == 0) part[wave] = acc;
+  for (int a = t; a < natoms; a += 256) acc += (double)e_node[(long)img * natoms + a];
+  part[t] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) e_img[img] = (part[0] + part[1] + part[2] + part[3]) * rmsd + refsum;
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) part[t] += part[t + s];
+    __syncthreads();
+  }
+  if (t == 0) e_img[img] = part[0] * rmsd + refsum;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--atoms", type=int, default=2000)
     ap.add_argument("--images", type=int, default=16)
-    ap.add_argument("--cpu-sample-atoms", type=int, default=400)
+    ap.add_argument("--cpu-sample-atoms", type=int, default=700)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

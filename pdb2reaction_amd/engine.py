@@ -29,6 +29,20 @@ class UmxError(RuntimeError):
     """A libumx call returned a non-zero status."""
 
 
+def _init_torch_hip_first() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  If libumx.so (linked against /opt/rocm) brings
+    the GPU up first, a later ``torch.cuda`` initialisation in the same process finds "No HIP GPUs are available" (two HSA
+    runtimes, the second cannot open the device).  Initialising torch's runtime first makes both share one; without torch
+    (plain C consumers, CPU-only torch) there is nothing to order."""
+    try:
+        import torch
+
+        if getattr(torch.version, "hip", None) and torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
 def load_library(path: Optional[str] = None) -> C.CDLL:
     """dlopen libumx.so and declare every entry point of include/umx.h."""
     global _lib
@@ -40,6 +54,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
             f"{p} not found: the HIP engine is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `python -m pdb2reaction_amd.build`) in the repository root; there is no CPU fallback."
         )
+    _init_torch_hip_first()
     lib = C.CDLL(p)
     vp, i32, i64p, dp, fp = C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_float)
     sigs = {

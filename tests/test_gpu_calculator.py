@@ -175,3 +175,21 @@ def test_staged_scan_with_batched_lbfgs_on_the_engine(setup):
     start[anchors] = ref[anchors]
     e = calc.get_energy_batch(elem, np.stack([start, out[1]]).reshape(2, -1))["energy"]
     assert e[1] < e[0]
+
+
+def test_engine_first_then_torch_cuda_in_one_process():
+    """Regression: the engine brought the GPU up through /opt/rocm's HIP runtime and a LATER torch.cuda use in the same
+    process failed with "No HIP GPUs are available" (torch bundles its own runtime).  Fresh interpreter, engine first."""
+    import os
+    import subprocess
+    import sys
+
+    code = ("import numpy as np\n"
+            "from pdb2reaction_amd.engine import Engine\n"
+            "e = Engine(0)\n"
+            "d1, d2, c = e.bond_changes(np.zeros((2, 3)), np.ones((2, 3)), np.ones(2))\n"
+            "import torch\n"
+            "print('OK', float(torch.ones(3, device='cuda').sum().item()))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK 3.0" in out.stdout, out.stderr[-2000:]

@@ -920,6 +920,7 @@ int umx_energy_forces_dev(umx_engine* eng, int n_images, const float* d_pos, dou
   if (eng->img_edges_cap < K + 1) {
     HIPCHK(eng, hipStreamSynchronize(s));
     if (eng->d_img_edges) HIPCHK(eng, hipFree(eng->d_img_edges));
+    eng->d_img_edges = nullptr; eng->img_edges_cap = 0;          // a failed hipMalloc below must not leave a dangling pointer
     HIPCHK(eng, hipMalloc(&eng->d_img_edges, (K + 1) * sizeof(int)));
     eng->img_edges_cap = K + 1;
   }

@@ -392,7 +392,7 @@ int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, cons
     hipLaunchKernelGGL(k_norm_fwd, dim3(nblk(nn, 4)), B256, 0, s, xin, L.n1w, L.n1b, eng->d_sysemb, w.xn[i], nn);
     if (ne > 0 && eng->pl) {
       CHK(radial_fwd(eng, w, L.rad, i, ne, w.rad[i]));
-      hipLaunchKernelGGL(k_gather_rotate_mod_pl<3>, dim3(nblk(ne, 4)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne);
+      hipLaunchKernelGGL(k_gather_rotate_mod_pl<3>, dim3((nblk(ne, 4) + 7) / 8 * 8), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne);
       // SO(2) conv 1 on the pre-modulated planes -> hg = [gate | hpre]
       CHK(gemm_pl(eng, 0, 3, w.y1pl, XROT, 0, 0, L.c1m0, 0, L.c1m0b, w.hg[i], HG, 0, 0, ne, 640, 768, 1.0f));
       CHK(gemm_pl(eng, 1, 3, w.y1pl, XROT, 768, 1280, L.c1m1, 256, nullptr, w.hg[i], HG, 640, 896, ne, 256, 512, 1.0f));
@@ -472,7 +472,7 @@ int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, cons
     HIPCHK(eng, hipGetLastError());
     DBG("g_xmid" + t, w.G2, nn * ROW);
     if (ne > 0 && eng->pl) {
-      hipLaunchKernelGGL(k_rotate_back_bwd_pl<2>, dim3(nblk(ne, 4)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne);
+      hipLaunchKernelGGL(k_rotate_back_bwd_pl<2>, dim3((nblk(ne, 4) + 7) / 8 * 8), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne);
       CHK(gemm_pl(eng, 0, 2, w.gmsgpl, ROW, 0, 0, L.c2m0T, 0, nullptr, w.hid, ROW, 0, 0, ne, 384, 384, 1.0f));
       CHK(gemm_pl(eng, 1, 2, w.gmsgpl, ROW, 384, 640, L.c2m1T, 256, nullptr, w.hid, ROW, 384, 640, ne, 256, 256, -1.0f));
       CHK(gemm_pl(eng, 1, 2, w.gmsgpl, ROW, 896, 1024, L.c2m2T, 128, nullptr, w.hid, ROW, 896, 1024, ne, 128, 128, -1.0f));

@@ -41,6 +41,16 @@ template <int P> __device__ __forceinline__ void pl_store4(unsigned short* row, 
   const long idx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))); \
   if (idx >= (count)) return;
 
+// same, but consecutive work items go to the SAME XCD (blocks are dealt round-robin over the 8 XCDs, each with its own L2):
+// XCD x walks the contiguous range [x * per, (x+1) * per) -- rows gathered by neighbouring items are then shared in one L2.
+// The grid must be a multiple of 8 blocks (nblk8()).
+#define UMX_WAVE_ITEM_PL_XCD(idx, count)                                              \
+  const int lane = threadIdx.x & 63;                                                  \
+  const long _per = gridDim.x >> 3;                                                   \
+  const long _blk = (long)(blockIdx.x & 7) * _per + (blockIdx.x >> 3);                \
+  const long idx = __builtin_amdgcn_readfirstlane((int)(_blk * 4 + (threadIdx.x >> 6))); \
+  if (idx >= (count)) return;
+
 // LayerNorm(128)+SiLU of the radial MLP, output as PL planes (A operand of the fc3 GEMM)
 template <int P>
 __global__ __launch_bounds__(256) void k_ln_silu_fwd_pl(const float* __restrict__ x, const float* __restrict__ w,
@@ -61,7 +71,7 @@ template <int P>
 __global__ __launch_bounds__(256) void k_gather_rotate_mod_pl(const float* __restrict__ xn, const int* __restrict__ esrc,
                                                               const int* __restrict__ edst, const float* __restrict__ frame,
                                                               const float* __restrict__ rad, unsigned short* __restrict__ y1, long ne) {
-  UMX_WAVE_ITEM_PL(e, ne)
+  UMX_WAVE_ITEM_PL_XCD(e, ne)
   const int c0 = lane * 2;
   const float* f = frame + e * FRAME;
   const long js = esrc[e], jd = edst[e];
@@ -122,7 +132,7 @@ __global__ __launch_bounds__(256) void k_rotate_back_bwd_pl(const float* __restr
                                                             const float* __restrict__ frame, const int* __restrict__ edst,
                                                             unsigned short* __restrict__ gmsg, float* __restrict__ dedd,
                                                             float* __restrict__ tau, long ne) {
-  UMX_WAVE_ITEM_PL(e, ne)
+  UMX_WAVE_ITEM_PL_XCD(e, ne)
   const int c0 = lane * 2;
   const float* f = frame + e * FRAME;
   const long jd = edst[e];

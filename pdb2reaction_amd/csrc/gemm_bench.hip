@@ -8,6 +8,7 @@
 #include <cstring>
 #include <vector>
 #include "umx_gemm_pl.h"
+#include "umx_gemm_q.h"
 using namespace umx;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -26,6 +27,16 @@ __global__ void k_split(const float* __restrict__ src, long rows, long ld, int K
   const long r = i / K; const int k = (int)(i % K);
   float x = src[r * ld + k];
   for (int q = 0; q < P; ++q) { const __bf16 h = (__bf16)x; dst[r * K * P + (k / 32) * 32 * P + q * 32 + (k % 32)] = __builtin_bit_cast(unsigned short, h); x -= (float)h; }
+}
+
+// fp32 [rows][ld] columns [0,K) -> Q3 layout (umx_gemm_q.h)
+__global__ void k_split_q(const float* __restrict__ src, long rows, long ld, int K, unsigned char* __restrict__ dst) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * K) return;
+  const long r = i / K; const int k = (int)(i % K);
+  float x = src[r * ld + k];
+  unsigned short* d = reinterpret_cast<unsigned short*>(dst + ((r / 4) * (K / 16) + k / 16) * 384 + (r % 4) * 96 + (k % 16) * 2);
+  for (int q = 0; q < 3; ++q) { const __bf16 hh = (__bf16)x; d[q * 16] = __builtin_bit_cast(unsigned short, hh); x -= (float)hh; }
 }
 
 int main(int argc, char** argv) {
@@ -85,6 +96,25 @@ int main(int argc, char** argv) {
     CK(hipMemset(C2, 0, M * (long)N * 4));
     rep("PL32 4w 128x128 P=2 S=2 (2 blocks/CU)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 2, 2, 2, 2, 2>, grid128(128), q2, 256); }));
     check("PL32 4w 128x128 P=2 vs fp32");
+  }
+  if (N % 256 == 0) {
+    unsigned char *Aq, *Bq;
+    const long Mp = (M + 3) / 4 * 4;
+    CK(hipMalloc(&Aq, (size_t)Mp * K * 6)); CK(hipMalloc(&Bq, (size_t)N * K * 6));
+    CK(hipMemset(Aq, 0, (size_t)Mp * K * 6));
+    hipLaunchKernelGGL(k_split_q, dim3((unsigned)((M * K + 255) / 256)), dim3(256), 0, 0, A, M, lda, K, Aq);
+    hipLaunchKernelGGL(k_split_q, dim3((unsigned)(((long)N * K + 255) / 256)), dim3(256), 0, 0, B, (long)N, (long)K, K, Bq);
+    CK(hipDeviceSynchronize());
+    GemmPL gq; std::memset(&gq, 0, sizeof(gq)); gq.conj = 1.f;
+    gq.Apl = reinterpret_cast<const unsigned short*>(Aq); gq.lda = 3L * K; gq.Bpl = reinterpret_cast<const unsigned short*>(Bq); gq.ldb = 3L * K;
+    gq.Cp = C2; gq.ldc = N; gq.M = (int)M; gq.N = N; gq.K = K;
+    CK(hipMemset(C2, 0, M * (long)N * 4));
+    rep("Q3 256x256 P=3 (quad-row layout, BK=16)", timeit([&] { hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1>), gridpl(256), dim3(512), 0, 0, gq); }));
+    check("Q3 256x256 P=3 vs fp32");
+    CK(hipMemset(C2, 0, M * (long)N * 4));
+    rep("Q3 256x128 P=3", timeit([&] { hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0>), gridpl(128), dim3(512), 0, 0, gq); }));
+    check("Q3 256x128 P=3 vs fp32");
+    CK(hipFree(Aq)); CK(hipFree(Bq));
   }
   if (N % 256 == 0) {
     CK(hipMemset(C2, 0, M * (long)N * 4));

@@ -20,6 +20,7 @@
 #include "umx_common.h"
 #include "umx_gemm.h"
 #include "umx_gemm_pl.h"
+#include "umx_gemm_q.h"
 #include "umx_kernels_pl.h"
 #include "umx_kernels.h"
 
@@ -52,6 +53,7 @@ struct umx_engine {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // second lane: half-chunks alternate streams so HBM-bound producers overlap the other lane's GEMMs
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool q3 = true;                  // UMX_Q3=0: forward operands in the 32-column PL layout + 256x128 tiles (set before umx_load_weights)
   bool wide_tiles = true;          // UMX_WIDE=0: 256x128 tiles for every GEMM
   int mfma16 = 1;                  // UMX_MFMA16: 0 = v_mfma_f32_32x32x16_bf16 everywhere, 1 = 16x16x32 where it measured faster, 2 = everywhere
   bool fuse_modrot = true;         // UMX_FUSE_MODROT=0: separate k_modulate_bwd_pl + k_gather_rotate_bwd (debug: exposes g_xrot)
@@ -202,7 +204,15 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
   // MFMA shape per GEMM (measured in the c3 pipeline): 16x16x32 wins 1-7 % on the complex SO(2) GEMMs and on K >= 512,
   // 32x32x16 wins 5-10 % on the short-K plain ones (radial fc3 and its transpose, conv-2 m=0)
   const bool use16 = eng->mfma16 >= 2 || (eng->mfma16 == 1 && (cplx || K >= 512));
-  if (P == 3) {
+  if (P == 3 && eng->q3) {
+    // forward operands in the quad-row layout: 256x256 tiles where N fills them, else 256x128 (umx_gemm_q.h)
+    const bool wq = N % (cplx ? 128 : 256) == 0;
+    const int bnq = wq ? (cplx ? 128 : 256) : (cplx ? 64 : 128);
+    const long nNq = (N + bnq - 1) / bnq;
+    dim3 gq((unsigned)(((nM + 7) / 8) * 8 * nNq));
+    if (cplx) { if (wq) hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<1, 0>), gq, block, 0, eng->stream, q); }
+    else      { if (wq) hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0>), gq, block, 0, eng->stream, q); }
+  } else if (P == 3) {
     if (use16) {
       if (cplx) hipLaunchKernelGGL((umx_gemm_pl16_kernel<1, 3, 2, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
       else hipLaunchKernelGGL((umx_gemm_pl16_kernel<0, 3, 2, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
@@ -289,8 +299,9 @@ size_t carve(char* base, long nn, long ne, WS* w, bool pl) {
   t.y1pl = t.hidpl = t.a2pl = t.gmsgpl = t.ghgpl = t.gradpl = nullptr;
   if (pl) {
     t.gmsg = b.take<float>(ne * 3 * C);                      // only the edge-degree backward uses fp32 g_msg (E x 384)
-    t.y1pl = b.take<unsigned short>(ne * XROT * 3); t.hidpl = b.take<unsigned short>(ne * ROW * 3);
-    t.a2pl = b.take<unsigned short>(ne * RH * 3); t.gmsgpl = b.take<unsigned short>(ne * ROW * 2);
+    const long ne4 = (ne + 3) / 4 * 4;          // the quad-row (Q3) layout stores rows in groups of four
+    t.y1pl = b.take<unsigned short>(ne4 * XROT * 3); t.hidpl = b.take<unsigned short>(ne4 * ROW * 3);
+    t.a2pl = b.take<unsigned short>(ne4 * RH * 3); t.gmsgpl = b.take<unsigned short>(ne * ROW * 2);
     t.ghgpl = b.take<unsigned short>(ne * HG * 2); t.gradpl = b.take<unsigned short>(ne * RAD * 2);
   } else {
     t.xrot = b.take<float>(ne * XROT); t.gmsg = b.take<float>(ne * ROW);
@@ -321,7 +332,8 @@ int radial_fwd(umx_engine* eng, const WS& w, const RadialW& r, int slot, long ne
   hipLaunchKernelGGL(k_ln_silu_fwd, dim3(nblk(ne, 4)), dim3(256), 0, s, w.h1pre[slot], r.ln1w, r.ln1b, w.ra, ne);
   CHK(gemm_plain(eng, w.ra, RH, 0, r.w2, RH, r.b2, w.h2pre[slot], RH, 0, ne, RH, RH));
   if (eng->pl && eng->planes.count(r.w3)) {
-    hipLaunchKernelGGL(k_ln_silu_fwd_pl<3>, dim3(nblk(ne, 4)), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne);
+    if (eng->q3) hipLaunchKernelGGL((k_ln_silu_fwd_pl<3, true>), dim3(nblk(ne, 4)), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne);
+    else hipLaunchKernelGGL((k_ln_silu_fwd_pl<3, false>), dim3(nblk(ne, 4)), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne);
     CHK(gemm_pl(eng, 0, 3, w.a2pl, RH, 0, 0, r.w3, 0, r.b3, rad_out, r.out, 0, 0, ne, r.out, RH, 1.0f));
   } else {
     hipLaunchKernelGGL(k_ln_silu_fwd, dim3(nblk(ne, 4)), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.ra, ne);
@@ -392,12 +404,14 @@ int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, cons
     hipLaunchKernelGGL(k_norm_fwd, dim3(nblk(nn, 4)), B256, 0, s, xin, L.n1w, L.n1b, eng->d_sysemb, w.xn[i], nn);
     if (ne > 0 && eng->pl) {
       CHK(radial_fwd(eng, w, L.rad, i, ne, w.rad[i]));
-      hipLaunchKernelGGL(k_gather_rotate_mod_pl<3>, dim3((nblk(ne, 4) + 7) / 8 * 8), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne);
+      if (eng->q3) hipLaunchKernelGGL(k_gather_rotate_mod_q3, dim3((nblk(ne, 4) + 7) / 8 * 8), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne);
+      else hipLaunchKernelGGL((k_gather_rotate_mod_pl<3, false>), dim3((nblk(ne, 4) + 7) / 8 * 8), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne);
       // SO(2) conv 1 on the pre-modulated planes -> hg = [gate | hpre]
       CHK(gemm_pl(eng, 0, 3, w.y1pl, XROT, 0, 0, L.c1m0, 0, L.c1m0b, w.hg[i], HG, 0, 0, ne, 640, 768, 1.0f));
       CHK(gemm_pl(eng, 1, 3, w.y1pl, XROT, 768, 1280, L.c1m1, 256, nullptr, w.hg[i], HG, 640, 896, ne, 256, 512, 1.0f));
       CHK(gemm_pl(eng, 1, 3, w.y1pl, XROT, 1792, 2048, L.c1m2, 128, nullptr, w.hg[i], HG, 1152, 1280, ne, 128, 256, 1.0f));
-      hipLaunchKernelGGL(k_gate_edge_fwd_pl<3>, dim3(nblk(ne * (H / 4), 256)), B256, 0, s, w.hg[i], w.hidpl, ne);
+      if (eng->q3) hipLaunchKernelGGL((k_gate_edge_fwd_pl<3, true>), dim3(nblk(ne * (H / 4), 256)), B256, 0, s, w.hg[i], w.hidpl, ne);
+      else hipLaunchKernelGGL((k_gate_edge_fwd_pl<3, false>), dim3(nblk(ne * (H / 4), 256)), B256, 0, s, w.hg[i], w.hidpl, ne);
       CHK(gemm_pl(eng, 0, 3, w.hidpl, ROW, 0, 0, L.c2m0, 0, L.c2m0b, w.msg[i], ROW, 0, 0, ne, 384, 384, 1.0f));
       CHK(gemm_pl(eng, 1, 3, w.hidpl, ROW, 384, 640, L.c2m1, 256, nullptr, w.msg[i], ROW, 384, 640, ne, 256, 256, 1.0f));
       CHK(gemm_pl(eng, 1, 3, w.hidpl, ROW, 896, 1024, L.c2m2, 128, nullptr, w.msg[i], ROW, 896, 1024, ne, 128, 128, 1.0f));
@@ -575,6 +589,7 @@ int umx_create(umx_engine** out, int device_ordinal) {
   e->dev = device_ordinal;
   if (const char* ev = std::getenv("UMX_MFMA16")) e->mfma16 = std::atoi(ev);
   if (const char* ev = std::getenv("UMX_WIDE")) e->wide_tiles = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("UMX_Q3")) e->q3 = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_FUSE_MODROT")) e->fuse_modrot = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_STREAMS")) e->n_lanes = std::atoi(ev) >= 2 ? 2 : 1;
   if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -763,7 +778,10 @@ int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes) {
           uint32_t u; std::memcpy(&u, &x, 4);
           const uint32_t rnd = u + 0x7FFFu + ((u >> 16) & 1u);
           const unsigned short hb = (unsigned short)(rnd >> 16);
-          bw[r.off + (size_t)rr * K * P + (size_t)(k / 32) * 32 * P + (size_t)q * 32 + (k % 32)] = hb;
+          if (P == 3 && eng->q3)     // quad-row layout (umx_gemm_q.h), index in bf16 units; rows are multiples of 4 here
+            bw[r.off + (((size_t)(rr / 4) * (K / 16) + k / 16) * 384 + (size_t)(rr % 4) * 96 + (size_t)q * 32 + (size_t)(k % 16) * 2) / 2] = hb;
+          else
+            bw[r.off + (size_t)rr * K * P + (size_t)(k / 32) * 32 * P + (size_t)q * 32 + (k % 32)] = hb;
           const uint32_t back = (uint32_t)hb << 16; float fb; std::memcpy(&fb, &back, 4);
           x -= fb;
         }

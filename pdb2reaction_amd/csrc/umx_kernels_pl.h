@@ -36,6 +36,32 @@ template <int P> __device__ __forceinline__ void pl_store4(unsigned short* row, 
   }
 }
 
+// Q3 "quad-row" layout of the FORWARD (3-plane) operands (umx_gemm_q.h): element (row, k, plane q) of a matrix with `cols` columns
+// -> byte ((row/4) * (cols/16) + k/16) * 384 + (row%4) * 96 + q * 32 + (k%16) * 2.   base = start of the matrix.
+__device__ __forceinline__ unsigned short* q3_ptr(unsigned short* base, long row, int cols, int k) {
+  return reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(base) + ((row >> 2) * (cols >> 4) + (k >> 4)) * 384 + (row & 3) * 96 + (k & 15) * 2);
+}
+__device__ __forceinline__ void q3_store2(unsigned short* base, long row, int cols, int k, float x0, float x1) {
+  unsigned short* d = q3_ptr(base, row, cols, k);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
+    *reinterpret_cast<unsigned int*>(d + q * 16) = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
+    x0 -= (float)h0; x1 -= (float)h1;
+  }
+}
+__device__ __forceinline__ void q3_store4(unsigned short* base, long row, int cols, int k, float4 v) {
+  unsigned short* d = q3_ptr(base, row, cols, k);
+  float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    unsigned short hb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { const __bf16 h = (__bf16)x[c]; hb[c] = __builtin_bit_cast(unsigned short, h); x[c] -= (float)h; }
+    *reinterpret_cast<uint2*>(d + q * 16) = make_uint2((unsigned int)hb[0] | ((unsigned int)hb[1] << 16), (unsigned int)hb[2] | ((unsigned int)hb[3] << 16));
+  }
+}
+
 #define UMX_WAVE_ITEM_PL(idx, count)                                                  \
   const int lane = threadIdx.x & 63;                                                  \
   const long idx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))); \
@@ -52,7 +78,7 @@ template <int P> __device__ __forceinline__ void pl_store4(unsigned short* row, 
   if (idx >= (count)) return;
 
 // LayerNorm(128)+SiLU of the radial MLP, output as PL planes (A operand of the fc3 GEMM)
-template <int P>
+template <int P, bool Q = false>
 __global__ __launch_bounds__(256) void k_ln_silu_fwd_pl(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, unsigned short* __restrict__ y, long rows) {
   UMX_WAVE_ITEM_PL(row, rows)
@@ -63,11 +89,13 @@ __global__ __launch_bounds__(256) void k_ln_silu_fwd_pl(const float* __restrict_
   const float var = wave_sum(v.x * v.x + v.y * v.y) * (1.0f / RH);
   const float rstd = rsqrt_f(var + LN_EPS);
   const float2 ww = *reinterpret_cast<const float2*>(w + c0), bb = *reinterpret_cast<const float2*>(b + c0);
-  pl_store2<P>(y + row * (RH * P), c0, silu_f(v.x * rstd * ww.x + bb.x), silu_f(v.y * rstd * ww.y + bb.y));
+  const float o0 = silu_f(v.x * rstd * ww.x + bb.x), o1 = silu_f(v.y * rstd * ww.y + bb.y);
+  if (Q) q3_store2(y, row, RH, c0, o0, o1);
+  else pl_store2<P>(y + row * (RH * P), c0, o0, o1);
 }
 
 // K7a fused: y1[e] = (W_e [xn[src] | xn[dst]]) .* rad[e]  as PL planes (9 m-primary rows x 256 columns)
-template <int P>
+template <int P, bool Q = false>
 __global__ __launch_bounds__(256) void k_gather_rotate_mod_pl(const float* __restrict__ xn, const int* __restrict__ esrc,
                                                               const int* __restrict__ edst, const float* __restrict__ frame,
                                                               const float* __restrict__ rad, unsigned short* __restrict__ y1, long ne) {
@@ -90,18 +118,78 @@ __global__ __launch_bounds__(256) void k_gather_rotate_mod_pl(const float* __res
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
     const float2 m = *reinterpret_cast<const float2*>(rd + ridx[r] * 2 * C + c0);
-    pl_store2<P>(out, r * 2 * C + c0, p[r] * m.x, q[r] * m.y);
+    if (Q) q3_store2(y1, e, XROT, r * 2 * C + c0, p[r] * m.x, q[r] * m.y);
+    else pl_store2<P>(out, r * 2 * C + c0, p[r] * m.x, q[r] * m.y);
   }
   rot_fwd(f, dx, p); rot_fwd(f, dy, q);
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
     const float2 m = *reinterpret_cast<const float2*>(rd + ridx[r] * 2 * C + C + c0);
-    pl_store2<P>(out, r * 2 * C + C + c0, p[r] * m.x, q[r] * m.y);
+    if (Q) q3_store2(y1, e, XROT, r * 2 * C + C + c0, p[r] * m.x, q[r] * m.y);
+    else pl_store2<P>(out, r * 2 * C + C + c0, p[r] * m.x, q[r] * m.y);
+  }
+}
+
+// K7a for the Q3 operand layout (umx_gemm_q.h).  A workgroup = the four edges of one Q3 row group.  Per m-primary row r the
+// four waves put their 256 modulated columns x 3 planes into LDS in exactly the byte order of the 16 consecutive 384-B blocks that
+// hold (row group, columns r*256 ... r*256+255), and the whole workgroup then writes those 6 KB with coalesced 16-B stores
+// (direct stores from the compute layout would be 32-B pieces at a 384-B stride: measured 60 ms instead of 42 ms per iteration).
+__global__ __launch_bounds__(256) void k_gather_rotate_mod_q3(const float* __restrict__ xn, const int* __restrict__ esrc,
+                                                              const int* __restrict__ edst, const float* __restrict__ frame,
+                                                              const float* __restrict__ rad, unsigned short* __restrict__ y1, long ne) {
+  __shared__ __attribute__((aligned(16))) unsigned int stage[2][16][4][24];      // [buffer][16-column block][row in group][q*8 + pair]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long per = gridDim.x >> 3;                                               // XCD-contiguous groups (see UMX_WAVE_ITEM_PL_XCD)
+  const long grp = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const long e0 = grp * 4;
+  if (e0 >= ne) return;                                                          // block-uniform
+  const long e = e0 + wave;
+  const bool valid = e < ne;
+  const int c0 = lane * 2;
+  float ps[9], qs[9], pd[9], qd[9];
+  const float* rd = rad + (valid ? e : e0) * RAD;
+  {
+    const long ee = valid ? e : e0;
+    const float* f = frame + ee * FRAME;
+    const long js = esrc[ee], jd = edst[ee];
+    float sx[9], sy[9], dx[9], dy[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      const float2 a = *reinterpret_cast<const float2*>(xn + js * ROW + r * C + c0);
+      const float2 b = *reinterpret_cast<const float2*>(xn + jd * ROW + r * C + c0);
+      sx[r] = a.x; sy[r] = a.y; dx[r] = b.x; dy[r] = b.y;
+    }
+    rot_fwd(f, sx, ps); rot_fwd(f, sy, qs); rot_fwd(f, dx, pd); rot_fwd(f, dy, qd);
+  }
+  const int ridx[9] = {0, 1, 2, 3, 4, 3, 4, 5, 5};   // radial row of each m-primary row
+  unsigned char* gbase = reinterpret_cast<unsigned char*>(y1) + grp * (long)(XROT / 16) * 384;
+  auto put = [&](int buf, int col, float x0, float x1) {
+    unsigned int* d = &stage[buf][col >> 4][wave][(col & 15) >> 1];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
+      d[q * 8] = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
+      x0 -= (float)h0; x1 -= (float)h1;
+    }
+  };
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const int buf = r & 1;
+    const float2 ms = *reinterpret_cast<const float2*>(rd + ridx[r] * 2 * C + c0);
+    const float2 md = *reinterpret_cast<const float2*>(rd + ridx[r] * 2 * C + C + c0);
+    put(buf, c0, ps[r] * ms.x, qs[r] * ms.y);
+    put(buf, C + c0, pd[r] * md.x, qd[r] * md.y);
+    __syncthreads();
+    // 16 blocks x 384 B = 6144 B = 384 chunks of 16 B: thread t copies chunk t and, for t < 128, chunk 256 + t
+    const uint4* src = reinterpret_cast<const uint4*>(&stage[buf][0][0][0]);
+    uint4* dst = reinterpret_cast<uint4*>(gbase + (long)r * 16 * 384);
+    dst[threadIdx.x] = src[threadIdx.x];
+    if (threadIdx.x < 128) dst[256 + threadIdx.x] = src[256 + threadIdx.x];
   }
 }
 
 // SO(2) gate: hg = [gate(256) | hpre(9x128)] (fp32) -> hid (9x128) as PL planes
-template <int P>
+template <int P, bool Q = false>
 __global__ void k_gate_edge_fwd_pl(const float* __restrict__ hg, unsigned short* __restrict__ hid, long ne) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ne * (H / 4)) return;
@@ -122,7 +210,8 @@ __global__ void k_gate_edge_fwd_pl(const float* __restrict__ hg, unsigned short*
       const float4 s = l1 ? s1 : s2;
       w = make_float4(v.x * s.x, v.y * s.y, v.z * s.z, v.w * s.w);
     }
-    pl_store4<P>(o, r * H + c, w);
+    if (Q) q3_store4(hid, e, ROW, r * H + c, w);
+    else pl_store4<P>(o, r * H + c, w);
   }
 }
 

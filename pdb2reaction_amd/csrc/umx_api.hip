@@ -410,7 +410,7 @@ int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, cons
       CHK(gemm_pl(eng, 0, 3, w.y1pl, XROT, 0, 0, L.c1m0, 0, L.c1m0b, w.hg[i], HG, 0, 0, ne, 640, 768, 1.0f));
       CHK(gemm_pl(eng, 1, 3, w.y1pl, XROT, 768, 1280, L.c1m1, 256, nullptr, w.hg[i], HG, 640, 896, ne, 256, 512, 1.0f));
       CHK(gemm_pl(eng, 1, 3, w.y1pl, XROT, 1792, 2048, L.c1m2, 128, nullptr, w.hg[i], HG, 1152, 1280, ne, 128, 256, 1.0f));
-      if (eng->q3) hipLaunchKernelGGL((k_gate_edge_fwd_pl<3, true>), dim3(nblk(ne * (H / 4), 256)), B256, 0, s, w.hg[i], w.hidpl, ne);
+      if (eng->q3) hipLaunchKernelGGL(k_gate_edge_fwd_q3, dim3(nblk(ne, 8)), B256, 0, s, w.hg[i], w.hidpl, ne);
       else hipLaunchKernelGGL((k_gate_edge_fwd_pl<3, false>), dim3(nblk(ne * (H / 4), 256)), B256, 0, s, w.hg[i], w.hidpl, ne);
       CHK(gemm_pl(eng, 0, 3, w.hidpl, ROW, 0, 0, L.c2m0, 0, L.c2m0b, w.msg[i], ROW, 0, 0, ne, 384, 384, 1.0f));
       CHK(gemm_pl(eng, 1, 3, w.hidpl, ROW, 384, 640, L.c2m1, 256, nullptr, w.msg[i], ROW, 384, 640, ne, 256, 256, 1.0f));

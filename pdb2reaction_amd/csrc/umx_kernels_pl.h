@@ -215,6 +215,54 @@ __global__ void k_gate_edge_fwd_pl(const float* __restrict__ hg, unsigned short*
   }
 }
 
+// SO(2) gate for the Q3 operand layout: a workgroup = 8 edges = two Q3 row groups; per m-primary row the gated 128 columns x 3
+// planes of the 8 edges are staged in LDS in the byte order of their 2 x 8 consecutive 384-B blocks and written with coalesced
+// 16-B stores (same reason as k_gather_rotate_mod_q3).
+__global__ __launch_bounds__(256) void k_gate_edge_fwd_q3(const float* __restrict__ hg, unsigned short* __restrict__ hid, long ne) {
+  __shared__ __attribute__((aligned(16))) unsigned int stage[2][2][8][4][24];    // [buffer][row group][16-column block][row][q*8 + pair]
+  const long e0 = (long)blockIdx.x * 8;
+  if (e0 >= ne) return;                                                          // block-uniform
+  const int le = threadIdx.x >> 5;                                               // edge within the workgroup
+  const int c = (threadIdx.x & 31) * 4;
+  const long e = (e0 + le < ne) ? e0 + le : e0;                                  // tail lanes recompute edge e0 (their rows are padding)
+  const float* p = hg + e * HG;
+  const float4 g1 = *reinterpret_cast<const float4*>(p + c), g2 = *reinterpret_cast<const float4*>(p + H + c);
+  const float4 s1 = make_float4(sigmoid_f(g1.x), sigmoid_f(g1.y), sigmoid_f(g1.z), sigmoid_f(g1.w));
+  const float4 s2 = make_float4(sigmoid_f(g2.x), sigmoid_f(g2.y), sigmoid_f(g2.z), sigmoid_f(g2.w));
+  unsigned char* gbase = reinterpret_cast<unsigned char*>(hid) + (e0 >> 2) * (long)(ROW / 16) * 384;
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const int buf = r & 1;
+    const float4 v = *reinterpret_cast<const float4*>(p + 2 * H + r * H + c);
+    float x[4];
+    if (r == 0) { x[0] = silu_f(v.x); x[1] = silu_f(v.y); x[2] = silu_f(v.z); x[3] = silu_f(v.w); }
+    else {
+      const bool l1 = (r == 1 || r == 3 || r == 5);
+      const float4 sg = l1 ? s1 : s2;
+      x[0] = v.x * sg.x; x[1] = v.y * sg.y; x[2] = v.z * sg.z; x[3] = v.w * sg.w;
+    }
+    unsigned int* d = &stage[buf][le >> 2][c >> 4][le & 3][(c & 15) >> 1];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      unsigned short hb[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const __bf16 hh = (__bf16)x[k]; hb[k] = __builtin_bit_cast(unsigned short, hh); x[k] -= (float)hh; }
+      *reinterpret_cast<uint2*>(d + q * 8) = make_uint2((unsigned int)hb[0] | ((unsigned int)hb[1] << 16), (unsigned int)hb[2] | ((unsigned int)hb[3] << 16));
+    }
+    __syncthreads();
+    // per row group: 8 blocks x 384 B = 3072 B = 192 chunks of 16 B; 384 chunks in all
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int ch = threadIdx.x + 256 * it;
+      const int g = ch / 192, o = ch % 192;
+      if (ch < 384 && e0 + 4 * g < ne) {          // the second row group may lie entirely beyond the (4-row padded) buffer
+        const uint4 val = reinterpret_cast<const uint4*>(&stage[buf][g][0][0][0])[o];
+        reinterpret_cast<uint4*>(gbase + (long)g * (ROW / 16) * 384 + (long)r * 8 * 384)[o] = val;
+      }
+    }
+  }
+}
+
 // backward of K7b for the SO(2) messages: g_msg[e] = env_e (W_e g[dst e]) as PL planes; dedd/tau as the fp32 kernel
 template <int P>
 __global__ __launch_bounds__(256) void k_rotate_back_bwd_pl(const float* __restrict__ gnode, const float* __restrict__ msg,

@@ -213,7 +213,7 @@ def main():
                        "parallelism": f"images sharded {k}/{world} per GPU, 1 all-gather/iteration" if world > 1 else "single GPU, all images batched"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": pmc_traffic_per_launch(split) if (n == 2000 and k == 16 and world == 1) else None,
-                         "kernel": ("umx_gemm_pl_kernel<*> / umx_gemm_pl16_kernel<*> (split-bf16 LDS-DMA GEMM: SO(2)/radial linears + transposes, rank 0)" if split
+                         "kernel": ("umx_gemm_q_kernel<*> / umx_gemm_pl16_kernel<*> / umx_gemm_pl_kernel<*> (split-bf16 LDS-DMA GEMM family: SO(2)/radial linears + transposes, rank 0)" if split
                                     else "umx_gemm_kernel<*> (fp32-MFMA GEMM, rank 0)"),
                          "launches": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
                          "flops_per_launch": dom["mfma_flops"] / max(dom["launches"], 1),

@@ -53,6 +53,7 @@ struct umx_engine {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // second lane: half-chunks alternate streams so HBM-bound producers overlap the other lane's GEMMs
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool q3_wide = true;             // UMX_Q3WIDE=0 (dev): 256x128 tiles for every forward GEMM
   bool q3 = true;                  // UMX_Q3=0: forward operands in the 32-column PL layout + 256x128 tiles (set before umx_load_weights)
   bool wide_tiles = true;          // UMX_WIDE=0: 256x128 tiles for every GEMM
   int mfma16 = 1;                  // UMX_MFMA16: 0 = v_mfma_f32_32x32x16_bf16 everywhere, 1 = 16x16x32 where it measured faster, 2 = everywhere
@@ -206,7 +207,7 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
   const bool use16 = eng->mfma16 >= 2 || (eng->mfma16 == 1 && (cplx || K >= 512));
   if (P == 3 && eng->q3) {
     // forward operands in the quad-row layout: 256x256 tiles where N fills them, else 256x128 (umx_gemm_q.h)
-    const bool wq = N % (cplx ? 128 : 256) == 0;
+    const bool wq = eng->q3_wide && N % (cplx ? 128 : 256) == 0;
     const int bnq = wq ? (cplx ? 128 : 256) : (cplx ? 64 : 128);
     const long nNq = (N + bnq - 1) / bnq;
     dim3 gq((unsigned)(((nM + 7) / 8) * 8 * nNq));
@@ -590,6 +591,7 @@ int umx_create(umx_engine** out, int device_ordinal) {
   if (const char* ev = std::getenv("UMX_MFMA16")) e->mfma16 = std::atoi(ev);
   if (const char* ev = std::getenv("UMX_WIDE")) e->wide_tiles = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_Q3")) e->q3 = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("UMX_Q3WIDE")) e->q3_wide = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_FUSE_MODROT")) e->fuse_modrot = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_STREAMS")) e->n_lanes = std::atoi(ev) >= 2 ? 2 : 1;
   if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||

@@ -30,13 +30,14 @@ __global__ void k_split(const float* __restrict__ src, long rows, long ld, int K
 }
 
 // fp32 [rows][ld] columns [0,K) -> Q3 layout (umx_gemm_q.h)
+template <int P>
 __global__ void k_split_q(const float* __restrict__ src, long rows, long ld, int K, unsigned char* __restrict__ dst) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * K) return;
   const long r = i / K; const int k = (int)(i % K);
   float x = src[r * ld + k];
-  unsigned short* d = reinterpret_cast<unsigned short*>(dst + ((r / 4) * (K / 16) + k / 16) * 384 + (r % 4) * 96 + (k % 16) * 2);
-  for (int q = 0; q < 3; ++q) { const __bf16 hh = (__bf16)x; d[q * 16] = __builtin_bit_cast(unsigned short, hh); x -= (float)hh; }
+  unsigned short* d = reinterpret_cast<unsigned short*>(dst + ((r / 4) * (K / 16) + k / 16) * (128 * P) + (r % 4) * (32 * P) + (k % 16) * 2);
+  for (int q = 0; q < P; ++q) { const __bf16 hh = (__bf16)x; d[q * 16] = __builtin_bit_cast(unsigned short, hh); x -= (float)hh; }
 }
 
 int main(int argc, char** argv) {
@@ -97,13 +98,32 @@ int main(int argc, char** argv) {
     rep("PL32 4w 128x128 P=2 S=2 (2 blocks/CU)", timeit([&] { launch_pl(&umx_gemm_pl_kernel<0, 2, 2, 2, 2, 2, 2>, grid128(128), q2, 256); }));
     check("PL32 4w 128x128 P=2 vs fp32");
   }
+  if (N % 256 == 0) {      // Q2: two-plane quad-row layout (experiment)
+    unsigned char *Aq2, *Bq2;
+    const long Mp2 = (M + 3) / 4 * 4;
+    CK(hipMalloc(&Aq2, (size_t)Mp2 * K * 4)); CK(hipMalloc(&Bq2, (size_t)N * K * 4));
+    CK(hipMemset(Aq2, 0, (size_t)Mp2 * K * 4));
+    hipLaunchKernelGGL(k_split_q<2>, dim3((unsigned)((M * K + 255) / 256)), dim3(256), 0, 0, A, M, lda, K, Aq2);
+    hipLaunchKernelGGL(k_split_q<2>, dim3((unsigned)(((long)N * K + 255) / 256)), dim3(256), 0, 0, B, (long)N, (long)K, K, Bq2);
+    CK(hipDeviceSynchronize());
+    GemmPL g2; std::memset(&g2, 0, sizeof(g2)); g2.conj = 1.f;
+    g2.Apl = reinterpret_cast<const unsigned short*>(Aq2); g2.lda = 2L * K; g2.Bpl = reinterpret_cast<const unsigned short*>(Bq2); g2.ldb = 2L * K;
+    g2.Cp = C2; g2.ldc = N; g2.M = (int)M; g2.N = N; g2.K = K;
+    CK(hipMemset(C2, 0, M * (long)N * 4));
+    rep("Q2 256x256 P=2 (quad-row, BK=16)", timeit([&] { hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 2>), gridpl(256), dim3(512), 0, 0, g2); }));
+    check("Q2 256x256 P=2 vs fp32");
+    CK(hipMemset(C2, 0, M * (long)N * 4));
+    rep("Q2 256x128 P=2 (quad-row, BK=16)", timeit([&] { hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0, 2>), gridpl(128), dim3(512), 0, 0, g2); }));
+    check("Q2 256x128 P=2 vs fp32");
+    CK(hipFree(Aq2)); CK(hipFree(Bq2));
+  }
   if (N % 256 == 0) {
     unsigned char *Aq, *Bq;
     const long Mp = (M + 3) / 4 * 4;
     CK(hipMalloc(&Aq, (size_t)Mp * K * 6)); CK(hipMalloc(&Bq, (size_t)N * K * 6));
     CK(hipMemset(Aq, 0, (size_t)Mp * K * 6));
-    hipLaunchKernelGGL(k_split_q, dim3((unsigned)((M * K + 255) / 256)), dim3(256), 0, 0, A, M, lda, K, Aq);
-    hipLaunchKernelGGL(k_split_q, dim3((unsigned)(((long)N * K + 255) / 256)), dim3(256), 0, 0, B, (long)N, (long)K, K, Bq);
+    hipLaunchKernelGGL(k_split_q<3>, dim3((unsigned)((M * K + 255) / 256)), dim3(256), 0, 0, A, M, lda, K, Aq);
+    hipLaunchKernelGGL(k_split_q<3>, dim3((unsigned)(((long)N * K + 255) / 256)), dim3(256), 0, 0, B, (long)N, (long)K, K, Bq);
     CK(hipDeviceSynchronize());
     GemmPL gq; std::memset(&gq, 0, sizeof(gq)); gq.conj = 1.f;
     gq.Apl = reinterpret_cast<const unsigned short*>(Aq); gq.lda = 3L * K; gq.Bpl = reinterpret_cast<const unsigned short*>(Bq); gq.ldb = 3L * K;

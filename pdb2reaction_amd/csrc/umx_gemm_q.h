@@ -19,7 +19,7 @@
 
 namespace umx {
 
-__device__ __forceinline__ int q3_row_off(int row) { return (row >> 2) * 384 + (row & 3) * 96; }
+template <int P> __device__ __forceinline__ int q_row_off(int row) { return (row >> 2) * (128 * P) + (row & 3) * (32 * P); }
 
 template <int JA, int JBF, int BHALF_ROUND, int A_BYTES, int TAG>
 __device__ __forceinline__ void q3_issue(const unsigned char* A, const unsigned char* B, unsigned char* sbase, const long (&a_off)[JA],
@@ -35,15 +35,18 @@ __device__ __forceinline__ void q3_issue(const unsigned char* A, const unsigned 
       __builtin_amdgcn_global_load_lds(B + b_off[JBF] + kofs, (__attribute__((address_space(3))) void*)(sbase + A_BYTES + piece + JBF * 8192), 16, 0, 0);
 }
 
-template <int CPLX, int WIDE>
+// P = 3: the forward layout Q3 described above.  P = 2 ("Q2", 256-B blocks of 4 rows x 16 columns x 2 planes) exists for gemm_bench only.
+template <int CPLX, int WIDE, int P = 3>
 __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
   constexpr int BM = 256, BN = WIDE ? 256 : 128;
   constexpr int BMR = CPLX ? BM / 2 : BM, BNC = CPLX ? BN / 2 : BN;
-  constexpr int A_BYTES = BM * 96, B_BYTES = BN * 96, STAGE = A_BYTES + B_BYTES;
+  constexpr int RB = 32 * P, BLK = 128 * P, CPB = 8 * P;      // bytes per row per block, bytes per block, 16-B chunks per block
+  constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB, STAGE = A_BYTES + B_BYTES;
   constexpr int TNW = WIDE ? 4 : 2;                       // 32-column MFMA tiles per wave
   constexpr int JA = A_BYTES / 8192;                      // DMA rounds of the whole block (512 lanes x 16 B)
   constexpr int JBF = B_BYTES / 8192, BHR = (B_BYTES % 8192) ? 1 : 0;
   static_assert(2 * STAGE <= 160 * 1024 && A_BYTES % 8192 == 0 && (B_BYTES % 8192 == 0 || B_BYTES % 8192 == 4096), "tile geometry");
+  static_assert(P == 2 || P == 3, "two or three planes");
   __shared__ __attribute__((aligned(1024))) unsigned char ring[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -56,27 +59,27 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
 
   const unsigned char* Ab = reinterpret_cast<const unsigned char*>(p.Apl);
   const unsigned char* Bb = reinterpret_cast<const unsigned char*>(p.Bpl);
-  const long a_blocks = p.lda / 48;                        // 16-column blocks per row of A (lda = columns * 3)
+  const long a_blocks = p.lda / (16 * P);                  // 16-column blocks per row of A (lda = columns * P)
   const long b_blocks = p.K / 16;
   const long gA = ((long)p.M + 3) / 4;                     // row groups that exist (rows are padded to 4)
   const int gN = p.N / 4;
   long a_off[JA], b_off[JBF + BHR];
 #pragma unroll
   for (int j = 0; j < JA; ++j) {
-    const int c = tid + 512 * j, g = c / 24, s = c % 24;
+    const int c = tid + 512 * j, g = c / CPB, s = c % CPB;
     long grp; int offA;
     if (CPLX) { grp = (long)mt * (BMR / 4) + (g % (BMR / 4)); offA = (g / (BMR / 4)) ? p.offA1 : p.offA0; }
     else      { grp = (long)mt * (BM / 4) + g;                offA = p.offA0; }
     if (grp >= gA) grp = gA - 1;
-    a_off[j] = (grp * a_blocks + offA / 16) * 384 + s * 16;
+    a_off[j] = (grp * a_blocks + offA / 16) * BLK + s * 16;
   }
 #pragma unroll
   for (int j = 0; j < JBF + BHR; ++j) {
-    const int c = tid + 512 * j, g = (c / 24) % (BN / 4), s = c % 24;     // (% keeps the unused lanes of a half round in range)
+    const int c = tid + 512 * j, g = (c / CPB) % (BN / 4), s = c % CPB;   // (% keeps the unused lanes of a half round in range)
     long grp;
     if (CPLX) { int cg = nt * (BNC / 4) + (g % (BNC / 4)); if (cg >= gN) cg = gN - 1; grp = (long)(g / (BNC / 4)) * (p.bHalf / 4) + cg; }
     else      { int cg = nt * (BN / 4) + g; if (cg >= gN) cg = gN - 1; grp = cg; }
-    b_off[j] = grp * b_blocks * 384 + s * 16;
+    b_off[j] = grp * b_blocks * BLK + s * 16;
   }
   const int piece = __builtin_amdgcn_readfirstlane(wave * 1024);
   const bool b_tail = __builtin_amdgcn_readfirstlane(wave < 4 ? 1 : 0) != 0;
@@ -93,32 +96,32 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int row = CPLX ? (t * BMR + wm * 32 + l31) : (wm * 64 + t * 32 + l31);
-    a_ad[t] = q3_row_off(row) + h * 16;
+    a_ad[t] = q_row_off<P>(row) + h * 16;
   }
 #pragma unroll
   for (int t = 0; t < TNW; ++t) {
     const int row = CPLX ? ((t / (TNW / 2)) * BNC + wn * (16 * TNW) + (t % (TNW / 2)) * 32 + l31) : (wn * (32 * TNW) + t * 32 + l31);
-    b_ad[t] = A_BYTES + q3_row_off(row) + h * 16;
+    b_ad[t] = A_BYTES + q_row_off<P>(row) + h * 16;
   }
 
   const int nk = p.K / 16;
-  constexpr int TAG = 9000 + CPLX * 2 + WIDE;
+  constexpr int TAG = 9000 + P * 10 + CPLX * 2 + WIDE;
   q3_issue<JA, JBF, BHR, A_BYTES, TAG>(Ab, Bb, ring, a_off, b_off, 0, piece, b_tail);
   for (int kt = 0; kt < nk; ++kt) {
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // tile kt landed everywhere; everyone finished reading tile kt-1
-    if (kt + 1 < nk) q3_issue<JA, JBF, BHR, A_BYTES, TAG>(Ab, Bb, ring + ((kt + 1) & 1) * STAGE, a_off, b_off, (long)(kt + 1) * 384, piece, b_tail);
+    if (kt + 1 < nk) q3_issue<JA, JBF, BHR, A_BYTES, TAG>(Ab, Bb, ring + ((kt + 1) & 1) * STAGE, a_off, b_off, (long)(kt + 1) * BLK, piece, b_tail);
     const unsigned char* sb = ring + (kt & 1) * STAGE;
-    bf16x8_t a[2][3], b[TNW][3];
+    bf16x8_t a[2][P], b[TNW][P];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < P; ++q) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) a[t][q] = *reinterpret_cast<const bf16x8_t*>(sb + a_ad[t] + q * 32);
 #pragma unroll
       for (int t = 0; t < TNW; ++t) b[t][q] = *reinterpret_cast<const bf16x8_t*>(sb + b_ad[t] + q * 32);
     }
 #pragma unroll
-    for (int ord = 2; ord >= 0; --ord)         // smallest terms first
+    for (int ord = P - 1; ord >= 0; --ord)     // smallest terms first
 #pragma unroll
       for (int qa = 0; qa <= ord; ++qa) {
         const int qb = ord - qa;

@@ -70,13 +70,18 @@ int umx_set_workspace_limit(umx_engine* eng, size_t bytes);
 int umx_energy_forces(umx_engine* eng, int n_images, const float* pos_ang, double* energy_ev,
                       float* forces_ev_ang);
 
-/* Same, with DEVICE pointers; work is enqueued on `hip_stream` (a hipStream_t, NULL = the
- * engine's own stream) and the call returns after enqueueing the final kernels (one small
- * device-to-host read of per-image edge counts happens inside for workspace planning).         */
+/* Same, with DEVICE pointers; work is enqueued on `hip_stream` (a hipStream_t; NULL = the legacy
+ * default stream 0, i.e. what torch.cuda.current_stream().cuda_stream returns for torch's default
+ * stream).  Stream ordering is the only synchronisation the caller needs: the kernels run after
+ * everything already enqueued on that stream (the producer of d_pos_ang) and before anything
+ * enqueued on it afterwards (the consumer of d_energy_ev / d_forces_ev_ang).  The call returns
+ * after enqueueing the final kernels (one small device-to-host read of per-image edge counts
+ * happens inside for workspace planning, so the host does wait for the caller's earlier work).  */
 int umx_energy_forces_dev(umx_engine* eng, int n_images, const float* d_pos_ang,
                           double* d_energy_ev, float* d_forces_ev_ang, void* hip_stream);
 
-/* Block until all work enqueued by this engine has finished.                                   */
+/* Block until all work enqueued by this engine has finished (including work it put on a
+ * caller's stream through umx_energy_forces_dev).                                              */
 int umx_synchronize(umx_engine* eng);
 
 /* Graph statistics of the most recent evaluation: total directed edges over all images, and

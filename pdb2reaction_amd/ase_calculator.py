@@ -62,16 +62,20 @@ class UMXCalculator(_AseBase):
     # ---- engine / system binding ------------------------------------------------------------------
     def _ensure(self, atoms):
         from .engine import Engine
+        from . import weights as W
         from .uma_pysis import _device_index, resolve_weights
 
         z = _numbers(atoms)
         info = getattr(atoms, "info", {}) or {}
         charge, spin = int(info.get("charge", self.default_charge)), int(info.get("spin", self.default_spin))
         if self._engine is None:
+            self._weights = resolve_weights(self.model)
             self._engine = Engine(_device_index(self.device))
-            self._engine.load_weights(resolve_weights(self.model))
+            self._engine.load_weights(self._weights)
         key = (z.tobytes(), charge, spin)
         if key != self._bound:
+            # merged-MoLE weights depend on (composition, charge, spin, task): refuse to re-bind them to another system
+            W.check_merged_for(self._weights, z, charge, spin, self.task_name)
             self._engine.set_system(z, charge=charge, spin=spin, task=self.task_name, radius=self.radius, max_neigh=self.max_neigh)
             self._bound = key
         return self._engine

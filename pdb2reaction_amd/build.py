@@ -1,6 +1,7 @@
 """Build libumx.so for gfx950 with hipcc (in-tree, so the .so travels with the repository snapshot)."""
 from __future__ import annotations
 
+import glob
 import os
 import shutil
 import subprocess
@@ -10,7 +11,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libumx.so")
 SOURCES = ["umx_api.hip"]
-HEADERS = ["umx_common.h", "umx_gemm.h", "umx_gemm_pl.h", "umx_kernels.h", "umx_kernels_pl.h", os.path.join("..", "..", "include", "umx.h")]
+ABI_HEADER = os.path.normpath(os.path.join(HERE, "..", "include", "umx.h"))
+
+
+def dependencies() -> list:
+    """Every file the library is compiled from: all of csrc/*.h and csrc/*.hip (umx_api.hip includes the headers; a
+    hand-kept list once missed the default forward GEMM, so the stale git-ignored .so shipped) plus the ABI header."""
+    deps = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip")))
+    deps = [d for d in deps if os.path.basename(d) != "gemm_bench.hip"]     # stand-alone benchmark, not part of the library
+    return deps + [ABI_HEADER]
 
 
 def find_hipcc() -> str:
@@ -24,8 +33,7 @@ def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in dependencies())
 
 
 def build_library(force: bool = False, verbose: bool = True) -> str:

@@ -85,6 +85,13 @@ def from_state_dict(state: Mapping[str, object], *, prefix: str = "backbone.", c
     return out
 
 
-def convert(state: Mapping[str, object], **kw) -> bytes:
-    """State dict -> UMXW0001 blob (``weights.pack_blob`` of ``from_state_dict``)."""
-    return W.pack_blob(from_state_dict(state, **kw))
+def convert(state: Mapping[str, object], *, merged_for: Optional[Mapping[str, object]] = None, **kw) -> bytes:
+    """State dict -> UMXW0001 blob (``weights.pack_blob`` of ``from_state_dict``).
+
+    ``merged_for`` = ``weights.system_record(atomic_numbers, charge, spin, task)`` of the system the MoLE coefficients were
+    computed for; it is stored in the blob trailer and checked whenever the blob is bound to a system.  It is REQUIRED when
+    ``coefficients`` are given: a merged parameter set is only valid for that one (composition, charge, spin, task)."""
+    if kw.get("coefficients") is not None and merged_for is None:
+        raise ValueError("convert(coefficients=...) needs merged_for=weights.system_record(...): a MoLE merge is valid for one system only")
+    meta = {"merged_for": dict(merged_for)} if merged_for is not None else None
+    return W.pack_blob(from_state_dict(state, **kw), meta=meta)

@@ -51,6 +51,8 @@ struct ProfRec { hipEvent_t a, b; double flops; int M, N, K, amode, cplx, prec, 
 struct umx_engine {
   int dev = 0;
   hipStream_t stream = nullptr;
+  hipStream_t last_run = nullptr;  // stream of the most recent evaluation (the caller's for the device-pointer entry)
+  bool ran_on_caller = false;
   hipStream_t stream2 = nullptr;   // second lane: half-chunks alternate streams so HBM-bound producers overlap the other lane's GEMMs
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool q3_wide = true;             // UMX_Q3WIDE=0 (dev): 256x128 tiles for every forward GEMM
@@ -911,18 +913,18 @@ int umx_set_system(umx_engine* eng, int n_atoms, const int32_t* z, int charge, i
 
 int umx_synchronize(umx_engine* eng) {
   if (!eng) return UMX_ERR_ARG;
+  HIPCHK(eng, hipSetDevice(eng->dev));
   HIPCHK(eng, hipStreamSynchronize(eng->stream));
+  if (eng->ran_on_caller) HIPCHK(eng, hipStreamSynchronize(eng->last_run));   // stream 0 included
   return UMX_OK;
 }
 
-int umx_energy_forces_dev(umx_engine* eng, int n_images, const float* d_pos, double* d_energy, float* d_forces, void* hip_stream) {
-  if (!eng) return UMX_ERR_ARG;
-  if (!eng->have_system) return fail(eng, UMX_ERR_ARG, "umx_energy_forces: bind a system first (umx_set_system)");
-  if (n_images <= 0 || !d_pos || !d_energy) return fail(eng, UMX_ERR_ARG, "umx_energy_forces: bad arguments");
-  HIPCHK(eng, hipSetDevice(eng->dev));
-  hipStream_t user = static_cast<hipStream_t>(hip_stream);
+// Evaluate on `run_stream` (may be the legacy default stream 0).  eng->stream is swapped for the duration so that every
+// helper launches there; it is restored on every exit path.
+static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_images, const float* d_pos, double* d_energy, float* d_forces) {
   hipStream_t own = eng->stream;
-  if (user) eng->stream = user;
+  eng->stream = run_stream;
+  eng->last_run = run_stream; eng->ran_on_caller = (run_stream != own);
   struct Restore { umx_engine* e; hipStream_t s; ~Restore() { e->stream = s; } } restore{eng, own};
   hipStream_t s = eng->stream;
   const int N = eng->natoms;
@@ -1023,6 +1025,17 @@ int umx_energy_forces_dev(umx_engine* eng, int n_images, const float* d_pos, dou
   return UMX_OK;
 }
 
+int umx_energy_forces_dev(umx_engine* eng, int n_images, const float* d_pos, double* d_energy, float* d_forces, void* hip_stream) {
+  if (!eng) return UMX_ERR_ARG;
+  if (!eng->have_system) return fail(eng, UMX_ERR_ARG, "umx_energy_forces: bind a system first (umx_set_system)");
+  if (n_images <= 0 || !d_pos || !d_energy) return fail(eng, UMX_ERR_ARG, "umx_energy_forces: bad arguments");
+  HIPCHK(eng, hipSetDevice(eng->dev));
+  // NULL = the legacy default stream (hipStream_t 0): the work is then ordered after everything the caller has enqueued on
+  // the default stream (the producer of d_pos) and before whatever it enqueues next (the consumer of d_energy / d_forces),
+  // exactly as with an explicit stream.  The engine's private non-blocking stream is never used for caller-owned buffers.
+  return energy_forces_on(eng, static_cast<hipStream_t>(hip_stream), n_images, d_pos, d_energy, d_forces);
+}
+
 int umx_energy_forces(umx_engine* eng, int n_images, const float* pos, double* energy, float* forces) {
   if (!eng) return UMX_ERR_ARG;
   if (!eng->have_system) return fail(eng, UMX_ERR_ARG, "umx_energy_forces: bind a system first (umx_set_system)");
@@ -1046,7 +1059,7 @@ int umx_energy_forces(umx_engine* eng, int n_images, const float* pos, double* e
     eng->io_img_cap = n_images;
   }
   HIPCHK(eng, hipMemcpyAsync(eng->d_io_pos, pos, nt * 3 * sizeof(float), hipMemcpyHostToDevice, eng->stream));
-  CHK(umx_energy_forces_dev(eng, n_images, eng->d_io_pos, eng->d_io_e, forces ? eng->d_io_f : nullptr, nullptr));
+  CHK(energy_forces_on(eng, eng->stream, n_images, eng->d_io_pos, eng->d_io_e, forces ? eng->d_io_f : nullptr));
   HIPCHK(eng, hipMemcpyAsync(energy, eng->d_io_e, (size_t)n_images * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
   if (forces) HIPCHK(eng, hipMemcpyAsync(forces, eng->d_io_f, nt * 3 * sizeof(float), hipMemcpyDeviceToHost, eng->stream));
   HIPCHK(eng, hipStreamSynchronize(eng->stream));
@@ -1071,6 +1084,7 @@ int umx_profile_read(umx_engine* eng, umx_profile_stats* out, int reset) {
   if (out) std::memset(out, 0, sizeof(*out));
   HIPCHK(eng, hipSetDevice(eng->dev));
   HIPCHK(eng, hipStreamSynchronize(eng->stream));
+  if (eng->prof_used) HIPCHK(eng, hipEventSynchronize(eng->prof[eng->prof_used - 1].b));   // events may sit on the caller's stream
   double ms = 0.0, fl = 0.0;
   FILE* dump = nullptr;
   if (const char* dp = std::getenv("UMX_PROFILE_DUMP")) dump = std::fopen(dp, "a");

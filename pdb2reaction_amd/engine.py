@@ -153,7 +153,9 @@ class Engine:
         return e, f
 
     def energy_forces_dev(self, n_images: int, d_pos: int, d_energy: int, d_forces: Optional[int], stream: int = 0):
-        """Device-pointer form (integers from e.g. ``tensor.data_ptr()``); enqueues on ``stream``."""
+        """Device-pointer form (integers from e.g. ``tensor.data_ptr()``); enqueues on ``stream``, a ``hipStream_t`` handle
+        as returned by ``torch.cuda.current_stream().cuda_stream``.  0 is the legacy default stream (torch's default
+        stream), NOT a private engine stream: consumers on the same stream need no further synchronisation."""
         self._chk(self.lib.umx_energy_forces_dev(self._h, int(n_images), C.c_void_p(d_pos), C.c_void_p(d_energy),
                                                  C.c_void_p(d_forces) if d_forces else None,
                                                  C.c_void_p(stream) if stream else None), "umx_energy_forces_dev")

@@ -1,6 +1,7 @@
 """Wire formats and config plumbing either side of the hot path.
 
-Restated from the reference (file:line relative to the reference root); pure Python/numpy, no third-party IO:
+Written from the behaviour of the reference (file:line relative to the reference root; exact-text tests in
+tests/test_formats.py pin it); pure Python/numpy, no third-party IO:
 
 * XYZ ``.trj``: concatenated XYZ frames whose comment line holds the energy in Hartree as ``f"{E:.12f}"`` and whose
   coordinates are ``"{sym} {x:.15f} {y:.15f} {z:.15f}"`` in Angstrom -- ``path_opt.py:276-290`` (ASE images),
@@ -46,92 +47,111 @@ def write_xyz(symbols: Sequence[str], coords_ang: np.ndarray, path: PathLike, en
         f.write(xyz_block(symbols, coords_ang, "" if energy_hartree is None else f"{energy_hartree:.12f}"))
 
 
+_FIRST_DECIMAL = re.compile(r"-?\d+(?:\.\d+)?")       # sign, digits, optional fraction; an exponent is NOT part of the match
+
+
+def _frames(lines: Sequence[str], strict_header: bool):
+    """Walk concatenated XYZ frames in a list of lines: yields (comment, atom_lines).
+
+    A header that is not an integer ends the walk (``strict_header=False``: what the reference's energy reader does with
+    trailing junk) or raises (``True``); blank lines between frames are skipped only in strict mode."""
+    i, n = 0, len(lines)
+    while i < n:
+        head = lines[i].strip()
+        if strict_header and not head:
+            i += 1
+            continue
+        try:
+            nat = int(head)
+        except ValueError:
+            if strict_header:
+                raise ValueError(f"line {i + 1}: expected an atom count, got {lines[i]!r}")
+            return
+        comment = lines[i + 1] if i + 1 < n else ""
+        yield comment, lines[i + 2: i + 2 + nat]
+        i += 2 + nat
+
+
 def read_energies_xyz(fname: PathLike) -> List[float]:
-    """Hartree energies from the comment line of each frame (reference ``trj2fig.py:86-109``)."""
-    energies: List[float] = []
-    with open(fname, encoding="utf-8") as fh:
-        while (hdr := fh.readline()):
-            try:
-                nat = int(hdr.strip())
-            except ValueError:
-                break
-            comment = fh.readline().strip()
-            m = re.search(r"(-?\d+(?:\.\d+)?)", comment)
-            if not m:
-                raise RuntimeError(f"Energy not found in comment: {comment}")
-            energies.append(float(m.group(1)))
-            for _ in range(nat):
-                fh.readline()
-    if not energies:
+    """One energy (Hartree) per frame of an XYZ/.trj file: the FIRST plain decimal number on the comment line -- so
+    ``-1.25e-3`` reads as ``-1.25`` exactly as in the reference's plotting reader (``trj2fig.py:86-109``).
+    RuntimeError when a comment holds no number or the file holds no frame."""
+    text = Path(fname).read_text(encoding="utf-8")
+    out: List[float] = []
+    for comment, _ in _frames(text.split("\n"), strict_header=False):
+        hit = _FIRST_DECIMAL.search(comment)
+        if hit is None:
+            raise RuntimeError(f"Energy not found in comment: {comment.strip()}")
+        out.append(float(hit.group(0)))
+    if not out:
         raise RuntimeError(f"No energy data in {fname}")
-    return energies
+    return out
 
 
 def read_trj(fname: PathLike) -> Tuple[List[str], np.ndarray, List[str]]:
     """All frames of an XYZ ``.trj``: (symbols, coords [K,N,3] Angstrom, comment lines)."""
-    symbols: List[str] = []
-    frames, comments = [], []
-    with open(fname, encoding="utf-8") as fh:
-        while (hdr := fh.readline()):
-            if not hdr.strip():
-                continue
-            nat = int(hdr.strip())
-            comments.append(fh.readline().rstrip("\n"))
-            syms, xyz = [], []
-            for _ in range(nat):
-                parts = fh.readline().split()
-                syms.append(parts[0])
-                xyz.append([float(v) for v in parts[1:4]])
-            if symbols and syms != symbols:
-                raise ValueError("atom order changes between frames")
-            symbols = syms
-            frames.append(xyz)
-    if not frames:
+    text = Path(fname).read_text(encoding="utf-8")
+    symbols: Optional[List[str]] = None
+    coords, comments = [], []
+    for comment, atoms in _frames(text.split("\n"), strict_header=True):
+        cols = [a.split() for a in atoms]
+        syms = [c[0] for c in cols]
+        if symbols is not None and syms != symbols:
+            raise ValueError("atom order changes between frames")
+        symbols = syms
+        coords.append([[float(v) for v in c[1:4]] for c in cols])
+        comments.append(comment.rstrip("\n"))
+    if symbols is None:
         raise RuntimeError(f"No frames in {fname}")
-    return symbols, np.asarray(frames, dtype=float), comments
+    return symbols, np.asarray(coords, dtype=float), comments
 
 
 # ---- YAML precedence (defaults <- CLI <- YAML) ---------------------------------------------------------
+# Behaviour of the reference's helpers (``utils.py:243-313``): a YAML section overrides what defaults and CLI flags have
+# put into a config dict; nested dicts merge key by key, everything else (lists included) is replaced wholesale; of
+# several candidate section paths only the first one that exists AND is a mapping is used.
 def deep_update(dst: Dict[str, Any], src: Optional[Mapping[str, Any]]) -> Dict[str, Any]:
-    """Recursively update mapping *dst* with *src*, returning *dst* (reference ``utils.py:243-252``)."""
-    for k, v in (src or {}).items():
-        if isinstance(v, dict) and isinstance(dst.get(k), dict):
-            deep_update(dst[k], v)
-        else:
-            dst[k] = v
+    """Merge *src* into *dst* in place and return *dst*; dict-into-dict merges recurse, any other value overwrites."""
+    todo = [(dst, src)] if src else []
+    while todo:
+        into, frm = todo.pop()
+        for key in frm:
+            val = frm[key]
+            if isinstance(val, dict) and isinstance(into.get(key), dict):
+                todo.append((into[key], val))
+            else:
+                into[key] = val
     return dst
 
 
-def _get_mapping_section(cfg: Mapping[str, Any], path: Sequence[str]) -> Optional[Dict[str, Any]]:
-    cur: Any = cfg
+def _section(cfg: Any, path: Sequence[str]) -> Optional[Dict[str, Any]]:
+    """The mapping found by walking *path* through nested mappings, else None (missing key, null, or a non-mapping)."""
+    node = cfg
     for key in path:
-        if not isinstance(cur, Mapping):
+        node = node.get(key) if isinstance(node, Mapping) else None
+        if node is None:
             return None
-        cur = cur.get(key)
-        if cur is None:
-            return None
-    return cur if isinstance(cur, dict) else None
+    return node if isinstance(node, dict) else None
 
 
 def apply_yaml_overrides(yaml_cfg: Mapping[str, Any],
                          overrides: Sequence[Tuple[Dict[str, Any], Sequence[Sequence[str]]]]) -> None:
-    """For every (target, candidate paths): deep-merge the FIRST existing YAML section (reference ``utils.py:266-297``)."""
-    for target, paths in overrides:
-        for path in paths:
-            section = _get_mapping_section(yaml_cfg, tuple(path))
-            if section is not None:
-                deep_update(target, section)
-                break
+    """``overrides`` = [(target dict, (path, path, ...)), ...]: each target receives the first of its candidate sections."""
+    for target, candidates in overrides:
+        found = next((sec for sec in (_section(yaml_cfg, tuple(c)) for c in candidates) if sec is not None), None)
+        if found is not None:
+            deep_update(target, found)
 
 
 def load_yaml_dict(path: Optional[PathLike]) -> Dict[str, Any]:
-    """YAML file whose root must be a mapping; ``{}`` when *path* is falsy (reference ``utils.py:300-313``)."""
+    """Parsed YAML file; no path -> ``{}``, empty file -> ``{}``, a root that is not a mapping -> ValueError."""
     if not path:
         return {}
     import yaml
 
-    with open(path, "r") as f:
-        data = yaml.safe_load(f) or {}
+    data = yaml.safe_load(Path(path).read_text())
+    if data is None:
+        return {}
     if not isinstance(data, dict):
         raise ValueError(f"YAML root must be a mapping, got: {type(data)}")
     return data

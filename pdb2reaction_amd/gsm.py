@@ -185,12 +185,14 @@ class GrowingStringDriver:
         need = None
         climbing = False
         cycle = 0
+        stale = False
         for cycle in range(1, int(opt["max_cycles"]) + 1):
             x = self.coords
             k = len(x)
             if need is None or len(need) != k:
                 need = np.ones(k, dtype=bool)
             self._eval(x, need)
+            stale = False                                       # energies/forces belong to the current coordinates
             moving = np.ones(k, dtype=bool)
             moving[0] = not gs["fix_first"]
             moving[-1] = not gs["fix_last"]
@@ -257,6 +259,7 @@ class GrowingStringDriver:
             # ---- reparametrise / grow
             every = gs["reparam_every_full"] if full else gs["reparam_every"]
             self._set_coords(xn)
+            stale = True
             changed = False
             if not full:
                 changed = self._grow(xn, rms_img)
@@ -276,5 +279,9 @@ class GrowingStringDriver:
         x = self.coords
         if self.energies is None or len(self.energies) != len(x):
             self._eval(x, np.ones(len(x), dtype=bool))
+        elif stale and need is not None and len(need) == len(x):
+            # max_cycles exhausted right after a step: the result must pair coordinates with THEIR energies,
+            # so the stepped images get one more evaluation instead of returning pre-step energies
+            self._eval(x, need)
         return GSMResult(coords=x, energies=self.energies.copy(), converged=converged, cycles=cycle, fully_grown=self.fully_grown,
                          hei_index=select_hei_index(self.energies), force_evaluations=self.n_eval, history=history)

@@ -38,24 +38,44 @@ def mask_frozen(forces: np.ndarray, frozen: Sequence[int]) -> np.ndarray:
 
 
 def fd_hessian(batch_forces: Callable[[np.ndarray], np.ndarray], coord_ang: np.ndarray, frozen: Sequence[int], *, device,
-               double: bool, partial: bool, batch: int = 64, step: float = FD_STEP_ANG, group=None):
+               double: bool, partial: bool, batch: int = 64, step: float = FD_STEP_ANG, shard: bool = False, group=None):
     """Central-difference Hessian in eV/A^2 as a torch tensor (n_out, 3, n_out, 3) on `device`.
 
     batch_forces(coords[K,N,3]) -> forces [K,N,3] float32.  Columns of frozen DOF stay zero (full output) or are
     dropped together with their rows (`partial`).
 
-    Multi-GPU: when torch.distributed is initialised with more than one rank, active columns are dealt
-    round-robin (column k of the active list -> rank k mod G), every rank evaluates only its own displaced geometries and
-    ONE all-reduce of the (3N x 3N) matrix at the end assembles the result on every rank (columns are disjoint, so the
-    sum is an exact gather).
+    Multi-GPU is OPT-IN: ``shard=True`` makes this call a COLLECTIVE over `group` (default: the world).
+    Every rank of the group must enter it with the same geometry and frozen set; active columns are dealt round-robin
+    (column k of the active list -> rank k mod G), every rank evaluates only its own displaced geometries and ONE
+    all-reduce of the (3N x 3N) matrix assembles the result on every rank (columns are disjoint, so the sum is an exact
+    gather).  The geometry is checked across ranks first (max |x - x_rank0| must be 0) so that ranks bound to different
+    structures fail loudly instead of summing inconsistent columns.  With ``shard=False`` (the default, and what
+    ``uma_pysis.get_hessian`` does unless sharding was enabled on the calculator) the call is purely local even inside an
+    initialised process group -- a rank-0-only frequency step neither hangs nor returns a 1/G-filled matrix.
     """
     import torch
     import torch.distributed as dist
 
-    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-    rank = dist.get_rank(group) if world > 1 else 0
-
+    world, rank = 1, 0
     x0 = np.asarray(coord_ang, dtype=np.float64)
+    if shard:
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("fd_hessian(shard=True) needs an initialised torch.distributed process group")
+        world = dist.get_world_size(group)
+        rank = dist.get_rank(group)
+        if world > 1:
+            host_coll = dist.get_backend(group) == "gloo"
+            ref = torch.as_tensor(x0, dtype=torch.float64, device="cpu" if host_coll else device).clone()
+            mine_x = ref.clone()
+            dist.broadcast(ref, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            bad = torch.tensor([float((ref - mine_x).abs().max()), float(len(frozen))], dtype=torch.float64, device=ref.device)
+            lo, hi = bad.clone(), bad.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+            if float(hi[0]) != 0.0 or float(lo[1]) != float(hi[1]):
+                raise RuntimeError("fd_hessian(shard=True): ranks entered with different geometries or frozen sets "
+                                   f"(max |x - x_rank0| = {float(hi[0]):.3e}, frozen counts {int(lo[1])}..{int(hi[1])})")
+
     n = x0.shape[0]
     dof = 3 * n
     active, _ = dof_partition(n, frozen)

@@ -66,22 +66,37 @@ CALC_KW: Dict[str, Any] = {
 FD_BATCH = int(os.environ.get("UMX_FD_BATCH", "64"))
 
 
-def resolve_weights(model: str) -> Dict[str, np.ndarray]:
+def resolve_weights(model: str) -> "W.WeightSet":
     """Map the reference's ``model`` keyword to a merged UMA-S parameter set.
 
     * a path to a ``.umxw`` blob -> loaded as is;
-    * a model name -> ``$UMX_WEIGHTS_DIR/<name>.umxw`` if present;
-    * otherwise the deterministic synthetic stand-in (``weights.make_synthetic_weights``), because the
-      real checkpoint is a gated download that does not exist in this environment.
+    * a model name -> ``$UMX_WEIGHTS_DIR/<name>.umxw``;
+    * ``"synthetic"`` / ``"synthetic:<seed>"`` -> the deterministic stand-in of ``weights.make_synthetic_weights``
+      (what tests and bench.py use: the real checkpoint is a gated download that does not exist here, SURVEY.md 8c);
+    * anything else raises ``FileNotFoundError`` -- like the reference, which raises when the checkpoint cannot be
+      obtained (``uma_pysis.py:246-250``).  A calculator must never hand out energies of random weights unasked;
+      ``UMX_ALLOW_SYNTHETIC=1`` turns the miss into the synthetic stand-in (with a warning) for plumbing runs.
     """
-    if os.path.isfile(model):
-        return W.load_weights(model)
+    m = str(model)
+    if m == "synthetic" or m.startswith("synthetic:"):
+        return W.make_synthetic_weights(int(m.split(":", 1)[1]) if ":" in m else int(os.environ.get("UMX_SYNTHETIC_SEED", "0")))
+    if os.path.isfile(m):
+        return W.load_weights(m)
     wdir = os.environ.get("UMX_WEIGHTS_DIR")
-    if wdir:
-        cand = os.path.join(wdir, f"{model}.umxw")
-        if os.path.isfile(cand):
-            return W.load_weights(cand)
-    return W.make_synthetic_weights(int(os.environ.get("UMX_SYNTHETIC_SEED", "0")))
+    cand = os.path.join(wdir, f"{m}.umxw") if wdir else None
+    if cand and os.path.isfile(cand):
+        return W.load_weights(cand)
+    if os.environ.get("UMX_ALLOW_SYNTHETIC", "0") == "1":
+        import warnings
+
+        warnings.warn(f"model {m!r}: no weight blob found, UMX_ALLOW_SYNTHETIC=1 -> RANDOM synthetic weights; energies and "
+                      "forces are physically meaningless", RuntimeWarning, stacklevel=2)
+        return W.make_synthetic_weights(int(os.environ.get("UMX_SYNTHETIC_SEED", "0")))
+    where = cand if cand else f"$UMX_WEIGHTS_DIR/{m}.umxw (UMX_WEIGHTS_DIR is not set)"
+    raise FileNotFoundError(
+        f"UMA weights for model {m!r} not found: expected {where}, or pass model=<path to a .umxw blob> "
+        "(convert a fairchem checkpoint with pdb2reaction_amd.checkpoint.convert). "
+        "Use model='synthetic' or UMX_ALLOW_SYNTHETIC=1 only for tests and benchmarks.")
 
 
 def _device_index(device: str) -> int:
@@ -135,9 +150,11 @@ class UMAcore:
         self._radius_user = radius
         self._r_edges_user = r_edges
 
-        self.engine = Engine(_device_index(device))
-        self.engine.load_weights(resolve_weights(model))
+        weights = resolve_weights(model)                    # raises FileNotFoundError before any GPU work
         self.z = synth.symbols_to_z(self.elem)
+        W.check_merged_for(weights, self.z, charge, spin, task_name)   # a MoLE merge is valid for one system only
+        self.engine = Engine(_device_index(device))
+        self.engine.load_weights(weights)
         self.engine.set_system(self.z, charge=charge, spin=spin, task=task_name, radius=radius, max_neigh=max_neigh)
 
     @property
@@ -201,6 +218,9 @@ class uma_pysis(Calculator):
         self.freeze_atoms: List[int] = sorted(set(int(i) for i in (freeze_atoms or [])))
         self.return_partial_hessian = bool(return_partial_hessian)
         self.hessian_double = bool(hessian_double)
+        # multi-GPU FD Hessian is opt-in (enable_hessian_sharding): a collective must never start implicitly
+        self._hess_shard = False
+        self._hess_group = None
 
     # ---------- internals -------------------------------------------
     def _ensure_core(self, elem: Sequence[str]):
@@ -209,12 +229,19 @@ class uma_pysis(Calculator):
             self._core = UMAcore(elem, **self._core_kw)
         return self._core
 
+    def enable_hessian_sharding(self, on: bool = True, group=None) -> None:
+        """Deal the FD-Hessian columns over the ranks of `group` (default: the world) -- c4's "freq Hessian (3N force
+        batches) on 8 GPUs".  From then on ``get_hessian`` is a COLLECTIVE: every rank of the group must call it with the
+        same geometry (checked).  Off by default, so a Hessian requested by one rank only stays a local computation."""
+        self._hess_shard, self._hess_group = bool(on), group
+
     def _fd_hessian_ev(self, elem: Sequence[str], coord_ang: np.ndarray) -> Dict[str, Any]:
         """Base-point E/F plus the finite-difference Hessian (eV/A^2, torch on the core's device); hessian.fd_hessian."""
         core = self._ensure_core(elem)
         base = core.compute(coord_ang, forces=True, hessian=False)
         hess = H.fd_hessian(lambda c: core.compute_batch(c, forces=True)["forces"], coord_ang, self.freeze_atoms, device=core.device,
-                            double=self.hessian_double, partial=self.return_partial_hessian, batch=FD_BATCH)
+                            double=self.hessian_double, partial=self.return_partial_hessian, batch=FD_BATCH,
+                            shard=self._hess_shard, group=self._hess_group)
         return {"energy": base["energy"], "forces": base["forces"], "hessian": hess}
 
     # ---------- PySisyphus API --------------------------------------

@@ -13,12 +13,17 @@ Blob layout (little endian), parsed by ``csrc/umx_api.hip``::
     u32   n_tensors, u32 reserved
     n_tensors x { char name[96]; u32 ndim; u32 dims[4]; u64 offset; u64 nbytes }
     f32 data section (each tensor 64-byte aligned, offsets relative to the data section)
+    optional trailer (ignored by the C parser): char "UMXMETA1", u32 nbytes, JSON -- e.g.
+    {"merged_for": {"composition": {"1": 12, "6": 4}, "charge": 0, "spin": 1, "task": "omol"}} for a
+    parameter set whose MoLE experts were merged for ONE system (checkpoint.py); consumers must refuse
+    to bind such a blob to any other system (:func:`check_merged_for`).
 """
 from __future__ import annotations
 
+import json
 import struct
 from collections import OrderedDict
-from typing import Dict, Tuple
+from typing import Any, Dict, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -51,6 +56,37 @@ L_OF_LP = (0, 1, 1, 1, 2, 2, 2, 2, 2)
 L_OF_MP = tuple(L_OF_LP[i] for i in TO_M)
 
 MAGIC = b"UMXW0001"
+META_MAGIC = b"UMXMETA1"
+
+
+class WeightSet(OrderedDict):
+    """name -> float32 array, plus ``meta`` (the blob trailer: provenance, the system a MoLE merge was made for)."""
+
+    meta: Dict[str, Any]
+
+    def __init__(self, *a, meta: Optional[Dict[str, Any]] = None, **kw):
+        super().__init__(*a, **kw)
+        self.meta = dict(meta or {})
+
+
+def system_record(atomic_numbers: Sequence[int], charge: int, spin: int, task: str) -> Dict[str, Any]:
+    """What MoLE routing depends on: the element multiset, total charge, spin multiplicity, task."""
+    zs, counts = np.unique(np.asarray(atomic_numbers, dtype=np.int64), return_counts=True)
+    return {"composition": {str(int(z)): int(c) for z, c in zip(zs, counts)}, "charge": int(charge), "spin": int(spin), "task": str(task)}
+
+
+def check_merged_for(weights: Dict[str, np.ndarray], atomic_numbers: Sequence[int], charge: int, spin: int, task: str) -> None:
+    """Raise ValueError when `weights` carries a ``merged_for`` record that does not match the system about to be bound.
+    Parameter sets without the record (synthetic weights, single-expert checkpoints) fit every system."""
+    want = (getattr(weights, "meta", None) or {}).get("merged_for")
+    if not want:
+        return
+    have = system_record(atomic_numbers, charge, spin, task)
+    if have != want:
+        diff = [k for k in ("composition", "charge", "spin", "task") if have.get(k) != want.get(k)]
+        raise ValueError(
+            f"these weights were MoLE-merged for another system (differs in {', '.join(diff)}: blob {{{', '.join(f'{k}={want.get(k)}' for k in diff)}}}, "
+            f"requested {{{', '.join(f'{k}={have.get(k)}' for k in diff)}}}); re-run checkpoint.convert for this system")
 
 
 def _radial_shapes(prefix: str, out_dim: int) -> "OrderedDict[str, Tuple[int, ...]]":
@@ -124,7 +160,7 @@ def make_synthetic_weights(seed: int = 0) -> "OrderedDict[str, np.ndarray]":
     participates non-trivially in parity tests.  SO(2) m>0 weights carry the 1/sqrt(2) factor.
     """
     rng = np.random.default_rng(seed)
-    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    out = WeightSet(meta={"source": f"synthetic(seed={int(seed)})"})
     for name, shape in param_shapes().items():
         leaf = name.split(".")[-1]
         if name == "normalizer.rmsd":
@@ -147,8 +183,9 @@ def make_synthetic_weights(seed: int = 0) -> "OrderedDict[str, np.ndarray]":
     return out
 
 
-def pack_blob(weights: Dict[str, np.ndarray]) -> bytes:
-    """Serialise a name->array dict into the UMXW0001 blob read by ``umx_load_weights``."""
+def pack_blob(weights: Dict[str, np.ndarray], meta: Optional[Dict[str, Any]] = None) -> bytes:
+    """Serialise a name->array dict into the UMXW0001 blob read by ``umx_load_weights`` (``meta`` or ``weights.meta``
+    goes into the JSON trailer)."""
     shapes = param_shapes()
     missing = [k for k in shapes if k not in weights]
     if missing:
@@ -169,10 +206,15 @@ def pack_blob(weights: Dict[str, np.ndarray]) -> bytes:
     head = MAGIC + struct.pack("<II", len(entries), 0)
     table = b"".join(entries)
     pad = (-(len(head) + len(table))) % 64
-    return head + table + b"\0" * pad + b"".join(chunks)
+    meta = meta if meta is not None else getattr(weights, "meta", None)
+    trailer = b""
+    if meta:
+        js = json.dumps(meta, sort_keys=True).encode()
+        trailer = META_MAGIC + struct.pack("<I", len(js)) + js
+    return head + table + b"\0" * pad + b"".join(chunks) + trailer
 
 
-def unpack_blob(blob: bytes) -> "OrderedDict[str, np.ndarray]":
+def unpack_blob(blob: bytes) -> "WeightSet":
     if blob[:8] != MAGIC:
         raise ValueError("not a UMXW0001 weight blob")
     n, _ = struct.unpack_from("<II", blob, 8)
@@ -184,9 +226,14 @@ def unpack_blob(blob: bytes) -> "OrderedDict[str, np.ndarray]":
         ents.append((name.rstrip(b"\0").decode(), (d0, d1, d2, d3)[:ndim], off, nb))
         pos += esz
     data0 = pos + ((-pos) % 64)
-    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    out = WeightSet()
+    end = data0
     for name, shape, off, nb in ents:
         out[name] = np.frombuffer(blob, dtype=np.float32, count=nb // 4, offset=data0 + off).reshape(shape).copy()
+        end = max(end, data0 + off + nb + ((-nb) % 64))
+    if blob[end:end + 8] == META_MAGIC:
+        (n_js,) = struct.unpack_from("<I", blob, end + 8)
+        out.meta = json.loads(blob[end + 12:end + 12 + n_js].decode())
     return out
 
 
@@ -195,6 +242,6 @@ def save_weights(path: str, weights: Dict[str, np.ndarray]) -> None:
         f.write(pack_blob(weights))
 
 
-def load_weights(path: str) -> "OrderedDict[str, np.ndarray]":
+def load_weights(path: str) -> "WeightSet":
     with open(path, "rb") as f:
         return unpack_blob(f.read())

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from pdb2reaction_amd import engine as E
+from pdb2reaction_amd import engine as E, weights as W
 import importlib
 
 U = importlib.import_module("pdb2reaction_amd.uma_pysis")   # the package attribute of that name is the class
@@ -42,7 +42,7 @@ def test_missing_library_is_loud(tmp_path):
 def test_engine_refuses_to_run_without_gpu():
     with pytest.raises(E.UmxError, match="no HIP device"):
         E.Engine(0)
-    calc = U.uma_pysis()
+    calc = U.uma_pysis(model="synthetic")
     with pytest.raises(E.UmxError):
         calc.get_energy(["H", "H"], [0, 0, 0, 0, 0, 1.4])
 
@@ -66,6 +66,33 @@ def test_calc_kw_and_ctor_mirror_reference():
     assert c._core is None                                     # lazy model load (reference :482,502-504)
     with pytest.raises(TypeError):
         U.uma_pysis(0, 1)                                       # keyword-only, like the reference
+
+
+def test_missing_weights_are_loud(tmp_path, monkeypatch):
+    """reference uma_pysis.py:246-250 raises when the checkpoint cannot be obtained; a drop-in must not hand out
+    energies of random weights (VERDICT r1 'silent garbage physics')."""
+    monkeypatch.delenv("UMX_ALLOW_SYNTHETIC", raising=False)
+    monkeypatch.delenv("UMX_WEIGHTS_DIR", raising=False)
+    with pytest.raises(FileNotFoundError, match=r"uma-s-1p1.*UMX_WEIGHTS_DIR"):
+        U.resolve_weights("uma-s-1p1")
+    monkeypatch.setenv("UMX_WEIGHTS_DIR", str(tmp_path))
+    with pytest.raises(FileNotFoundError, match=str(tmp_path / "uma-s-1p1.umxw").replace("\\", "/")):
+        U.resolve_weights("uma-s-1p1")
+    with pytest.raises(FileNotFoundError):                     # the calculator fails at first use, before touching the GPU
+        U.uma_pysis().get_energy(["H", "H"], [0, 0, 0, 0, 0, 1.4])
+    # explicit opt-ins
+    w0 = U.resolve_weights("synthetic")
+    assert np.array_equal(w0["mix_csd.bias"], W.make_synthetic_weights(0)["mix_csd.bias"])
+    assert not np.array_equal(U.resolve_weights("synthetic:3")["mix_csd.bias"], w0["mix_csd.bias"])
+    monkeypatch.setenv("UMX_ALLOW_SYNTHETIC", "1")
+    with pytest.warns(RuntimeWarning, match="RANDOM synthetic weights"):
+        U.resolve_weights("uma-s-1p1")
+    monkeypatch.delenv("UMX_ALLOW_SYNTHETIC")
+    # a blob in $UMX_WEIGHTS_DIR or given by path is loaded as is
+    W.save_weights(str(tmp_path / "uma-s-1p1.umxw"), W.make_synthetic_weights(5))
+    got = U.resolve_weights("uma-s-1p1")
+    assert np.array_equal(got["mix_csd.bias"], W.make_synthetic_weights(5)["mix_csd.bias"])
+    assert np.array_equal(U.resolve_weights(str(tmp_path / "uma-s-1p1.umxw"))["mix_csd.bias"], got["mix_csd.bias"])
 
 
 def test_device_mapping():
@@ -205,3 +232,23 @@ def test_string_update_properties():
     assert z.shape == x.shape and torch.isfinite(z).all()
     z2 = string_step(x, torch.zeros_like(f))
     assert torch.allclose(z2, reparametrize_equal(x))
+
+
+def test_build_dependency_list_covers_every_kernel_header(monkeypatch):
+    """a hand-kept header list missed umx_gemm_q.h, so the stale (git-ignored) libumx.so shipped."""
+    import glob
+
+    from pdb2reaction_amd import build as B
+
+    deps = B.dependencies()
+    names = {os.path.basename(d) for d in deps}
+    assert {"umx_gemm_q.h", "umx_generators.h", "umx_api.hip", "umx.h"} <= names
+    assert {os.path.basename(h) for h in glob.glob(os.path.join(B.CSRC, "*.h"))} <= names
+    assert all(os.path.exists(d) for d in deps)
+    real = os.path.getmtime
+    t_lib = real(B.OUT)
+    for touched in ("umx_gemm_q.h", "umx_generators.h", "umx_kernels_pl.h", "umx.h"):
+        monkeypatch.setattr(os.path, "getmtime", lambda p, t=touched: t_lib + 5.0 if os.path.basename(p) == t else min(real(p), t_lib))
+        assert B.needs_build(), touched
+    monkeypatch.setattr(os.path, "getmtime", lambda p: min(real(p), t_lib))
+    assert not B.needs_build()

@@ -36,9 +36,20 @@ def test_merge_and_roundtrip():
     for k in w:
         assert got[k].dtype == np.float32
         np.testing.assert_allclose(got[k], w[k], rtol=0, atol=2e-6 * max(1.0, np.abs(w[k]).max()))
-    blob = CK.convert(state, coefficients=alpha, extra=extra)
+    with pytest.raises(ValueError, match="merged_for"):
+        CK.convert(state, coefficients=alpha, extra=extra)                  # a merge without its system record is refused
+    rec = W.system_record([1, 1, 6, 8, 1], 0, 1, "omol")
+    blob = CK.convert(state, coefficients=alpha, extra=extra, merged_for=rec)
     back = W.unpack_blob(blob)
     assert all(np.array_equal(back[k], got[k]) for k in got)
+    # the blob remembers the system the experts were merged for and refuses any other
+    assert back.meta["merged_for"] == {"composition": {"1": 3, "6": 1, "8": 1}, "charge": 0, "spin": 1, "task": "omol"}
+    W.check_merged_for(back, [8, 1, 1, 1, 6], 0, 1, "omol")                 # same multiset, other order: fine
+    for z, q, s, t, what in [([1, 1, 6, 8], 0, 1, "omol", "composition"), ([1, 1, 6, 8, 1], 1, 1, "omol", "charge"),
+                             ([1, 1, 6, 8, 1], 0, 3, "omol", "spin"), ([1, 1, 6, 8, 1], 0, 1, "omat", "task")]:
+        with pytest.raises(ValueError, match=what):
+            W.check_merged_for(back, z, q, s, t)
+    W.check_merged_for(w, [1, 2, 3], 5, 2, "oc20")                          # synthetic weights carry no record: any system
     m = CK.merge_mole(np.arange(12.0).reshape(3, 2, 2), [0.5, 0.25, 0.25])
     np.testing.assert_allclose(m, [[2.5 + 0.5, 3.5 + 0.5], [4.5 + 0.5, 5.5 + 0.5]])
 

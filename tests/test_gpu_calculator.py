@@ -22,7 +22,7 @@ def setup(oracle):
 
 def test_get_forces_matches_oracle_in_atomic_units(oracle, setup):
     z, elem, imgs = setup
-    calc = U.uma_pysis(freeze_atoms=[0, 5])
+    calc = U.uma_pysis(model="synthetic", freeze_atoms=[0, 5])
     x_bohr = (imgs[0] * U.ANG2BOHR).reshape(-1)
     r = calc.get_forces(elem, x_bohr)
     p32 = (x_bohr.reshape(-1, 3) * U.BOHR2ANG).astype(np.float32)
@@ -37,7 +37,7 @@ def test_get_forces_matches_oracle_in_atomic_units(oracle, setup):
 
 def test_batch_equals_serial_calls(setup):
     z, elem, imgs = setup
-    calc = U.uma_pysis()
+    calc = U.uma_pysis(model="synthetic")
     xb = imgs.reshape(4, -1) * U.ANG2BOHR
     rb = calc.get_forces_batch(elem, xb)
     for k in range(4):
@@ -47,7 +47,7 @@ def test_batch_equals_serial_calls(setup):
 
 def test_fd_hessian_against_oracle_fd(oracle, setup):
     z, elem, imgs = setup
-    calc = U.uma_pysis(freeze_atoms=[3], out_hess_torch=True)
+    calc = U.uma_pysis(model="synthetic", freeze_atoms=[3], out_hess_torch=True)
     x_bohr = (imgs[1] * U.ANG2BOHR).reshape(-1)
     r = calc.get_hessian(elem, x_bohr)
     h = r["hessian"]
@@ -70,7 +70,7 @@ def test_fd_hessian_against_oracle_fd(oracle, setup):
     sub = np.ix_(cols, cols)
     ref = 0.5 * (full[sub] + full[sub].T) * U.H_EVAA_2_AU
     assert np.abs(h[sub] - ref).max() <= 5e-3 * U.H_EVAA_2_AU          # fp32 forces / 2e-3 A ~ 1e-3 eV/A^2 noise floor
-    calc2 = U.uma_pysis(freeze_atoms=[3], return_partial_hessian=True, out_hess_torch=False, hessian_double=False)
+    calc2 = U.uma_pysis(model="synthetic", freeze_atoms=[3], return_partial_hessian=True, out_hess_torch=False, hessian_double=False)
     h2 = calc2.get_hessian(elem, x_bohr)["hessian"]
     assert h2.shape == (39, 39) and h2.dtype == np.float32
 
@@ -78,10 +78,10 @@ def test_fd_hessian_against_oracle_fd(oracle, setup):
 def test_error_behaviour(setup):
     z, elem, imgs = setup
     with pytest.raises(RuntimeError, match="no CPU path"):
-        U.uma_pysis(device="cpu").get_energy(elem, imgs[0].reshape(-1))
+        U.uma_pysis(model="synthetic", device="cpu").get_energy(elem, imgs[0].reshape(-1))
     with pytest.raises(ValueError):
-        U.uma_pysis().get_energy(["Xx"] * 14, imgs[0].reshape(-1))
-    c = U.uma_pysis()
+        U.uma_pysis(model="synthetic").get_energy(["Xx"] * 14, imgs[0].reshape(-1))
+    c = U.uma_pysis(model="synthetic")
     c.get_energy(elem, imgs[0].reshape(-1))
     with pytest.raises(RuntimeError, match="Analytical Hessian is not available"):
         c._core.compute(imgs[0], forces=True, hessian=True)
@@ -110,7 +110,7 @@ def test_ase_style_calculator(oracle, setup):
     from pdb2reaction_amd.ase_calculator import UMXCalculator
 
     z, elem, imgs = setup
-    calc = UMXCalculator(task_name="omol")
+    calc = UMXCalculator(model="synthetic", task_name="omol")
     images = [FakeAtoms(z, imgs[k].astype(np.float32)) for k in range(3)]
     for im in images:
         im.calc = calc
@@ -133,7 +133,7 @@ def test_gsm_driver_on_the_engine(tmp_path, setup):
     from pdb2reaction_amd.gsm import GrowingStringDriver
 
     z, elem, imgs = setup
-    calc = U.uma_pysis(freeze_atoms=[0])
+    calc = U.uma_pysis(model="synthetic", freeze_atoms=[0])
     r, p = (imgs[0] * U.ANG2BOHR).reshape(-1), (imgs[3] * U.ANG2BOHR).reshape(-1)
     drv = GrowingStringDriver(elem, r, p, calc, gs_kw={"max_nodes": 4, "perp_thresh": 1e3, "climb": False}, stopt_kw={"max_cycles": 4, "max_step": 0.05})
     res = drv.run()
@@ -154,7 +154,7 @@ def test_staged_scan_with_batched_lbfgs_on_the_engine(setup):
     from pdb2reaction_amd import prestep as PS
 
     z, elem, imgs = setup
-    calc = U.uma_pysis()
+    calc = U.uma_pysis(model="synthetic")
     ref = imgs[0] * U.ANG2BOHR
     anchors = [0, 5, 9]
     rot = PS._rodrigues(np.array([0.3, -1.0, 0.5]), 0.7)

@@ -175,6 +175,36 @@ def test_device_pointer_entry(engine):
     assert np.array_equal(ed.cpu().numpy(), e) and np.array_equal(fd.cpu().numpy(), f)
 
 
+def test_device_pointer_entry_is_stream_ordered(engine):
+    """The dev entry must be ordered with the CALLER's stream and nothing else (the work used to run on a private
+    non-blocking stream when the handle was 0, so torch consumers read the output while it was still being computed).
+    No device-wide synchronisation here: results are consumed by torch ops on the same stream, positions are overwritten
+    right after the call, and the only host wait is the .cpu() of the CONSUMER's output (which waits for that stream only)."""
+    n, k = 400, 4                      # large enough that the evaluation takes several ms
+    z, imgs, _ = synth.make_images(n, k, seed=3)
+    engine.set_system(z)
+    e_ref, f_ref = engine.energy_forces(imgs)
+    imgs2 = imgs[::-1] + np.random.default_rng(9).normal(0.0, 0.05, imgs.shape)   # same atoms, other geometries
+    e_ref2, f_ref2 = engine.energy_forces(imgs2)
+    dev = torch.device("cuda", 0)
+    host_a = torch.as_tensor(imgs, dtype=torch.float32).pin_memory()
+    host_b = torch.as_tensor(imgs2, dtype=torch.float32).pin_memory()
+    for stream in (torch.cuda.current_stream(), torch.cuda.Stream()):
+        with torch.cuda.stream(stream):
+            pos = torch.empty(k, n, 3, dtype=torch.float32, device=dev)
+            ed = torch.full((k,), float("nan"), dtype=torch.float64, device=dev)
+            fd = torch.full((k, n, 3), float("nan"), dtype=torch.float32, device=dev)
+            pos.copy_(host_a, non_blocking=True)                                  # producer on the caller's stream
+            engine.energy_forces_dev(k, pos.data_ptr(), ed.data_ptr(), fd.data_ptr(), stream=stream.cuda_stream)
+            e1, f1 = ed.clone(), fd.to(torch.float64)                             # consumers on the caller's stream
+            pos.copy_(host_b, non_blocking=True)                                  # overwrite the input right away
+            engine.energy_forces_dev(k, pos.data_ptr(), ed.data_ptr(), fd.data_ptr(), stream=stream.cuda_stream)
+            e2, f2 = ed.clone(), fd.to(torch.float64)
+            out = [t.cpu().numpy() for t in (e1, f1, e2, f2)]
+        assert np.array_equal(out[0], e_ref) and np.array_equal(out[1], f_ref.astype(np.float64))
+        assert np.array_equal(out[2], e_ref2) and np.array_equal(out[3], f_ref2.astype(np.float64))
+
+
 @pytest.mark.parametrize("mode", ["fp32", "split"])
 def test_stage_by_stage_against_staged_oracle(weights, mode, monkeypatch):
     """Every intermediate of the forward AND of the analytic reverse pass vs oracle/staged.py, in both precision modes

@@ -91,3 +91,13 @@ def test_custom_evaluator_is_used():
     drv = GrowingStringDriver(["X"], MIN_A, MIN_B, calc=None, evaluate=evaluate, gs_kw={"max_nodes": 3}, stopt_kw={"max_cycles": 4})
     drv.run()
     assert seen and seen[0] == 4
+
+
+def test_unconverged_exit_returns_energies_of_the_returned_coordinates():
+    """max_cycles exhausted right after a step: energies must belong to the returned geometries."""
+    calc = MuellerBrown()
+    drv = GrowingStringDriver(["X"], MIN_A, MIN_B, calc, gs_kw={"max_nodes": 3, "climb": False}, stopt_kw={"max_cycles": 5})
+    res = drv.run()
+    assert not res.converged and res.cycles == 5
+    e_now = calc.get_forces_batch(["X"], res.coords)["energy"]
+    np.testing.assert_allclose(res.energies, e_now, rtol=0, atol=1e-12)

@@ -92,8 +92,20 @@ def _hess_worker(rank, world, port, out):
             return (-(c.reshape(len(c), -1) @ a)).reshape(c.shape).astype(np.float32)
 
         x0 = rng.standard_normal((n, 3))
-        h = fd_hessian(forces, x0, [1], device=torch.device("cpu"), double=True, partial=False, batch=4)
-        out[rank] = (h.reshape(3 * n, 3 * n).numpy(), sum(calls))
+        h = fd_hessian(forces, x0, [1], device=torch.device("cpu"), double=True, partial=False, batch=4, shard=True)
+        n_sharded = sum(calls)
+        # default (shard=False): purely local even inside an initialised group -- only rank 0 calls it here, and it must
+        # neither hang nor return a partly filled matrix
+        h_local = None
+        if rank == 0:
+            h_local = fd_hessian(forces, x0, [1], device=torch.device("cpu"), double=True, partial=False, batch=4).reshape(3 * n, 3 * n).numpy()
+        # ranks that enter the collective with different geometries fail loudly on every rank
+        try:
+            fd_hessian(forces, x0 + 1e-9 * rank, [1], device=torch.device("cpu"), double=True, partial=False, batch=4, shard=True)
+            mismatch = "no error"
+        except RuntimeError as exc:
+            mismatch = str(exc)
+        out[rank] = (h.reshape(3 * n, 3 * n).numpy(), n_sharded, h_local, mismatch)
     finally:
         dist.destroy_process_group()
 
@@ -107,8 +119,10 @@ def test_fd_hessian_columns_are_sharded_over_ranks():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_hess_worker, args=(2, port, out), nprocs=2, join=True)
-    h0, n0 = out[0]
-    h1, n1 = out[1]
+    h0, n0, h_local, msg0 = out[0]
+    h1, n1, _, msg1 = out[1]
+    assert np.array_equal(h_local, h0)                              # single-rank call == sharded result, bit for bit
+    assert "different geometries" in msg0 and "different geometries" in msg1
     assert np.array_equal(h0, h1)                                   # every rank holds the full matrix
     assert n0 == n1 == 12                                           # 12 active DOF / 2 ranks * 2 displacements each
     rng = np.random.default_rng(0)

@@ -16,7 +16,7 @@ z, pos = synth.make_cluster(n)
 elem = [synth.SYMBOLS[int(a)] for a in z]
 order = np.argsort(np.linalg.norm(pos, axis=1))
 freeze = sorted(int(i) for i in order[act:])
-calc = U.uma_pysis(freeze_atoms=freeze, out_hess_torch=False, return_partial_hessian=True)
+calc = U.uma_pysis(model="synthetic", freeze_atoms=freeze, out_hess_torch=False, return_partial_hessian=True)
 x = (pos * U.ANG2BOHR).reshape(-1)
 calc.get_forces(elem, x)                      # load weights
 t0 = time.perf_counter()

@@ -17,7 +17,7 @@ nodes = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 cycles = int(sys.argv[3]) if len(sys.argv) > 3 else 25
 z, imgs, frozen = synth.make_images(n, 2)
 elem = [synth.SYMBOLS[int(a)] for a in z]
-calc = U.uma_pysis(freeze_atoms=list(frozen))
+calc = U.uma_pysis(model="synthetic", freeze_atoms=list(frozen))
 r, p = (imgs[0] * U.ANG2BOHR).reshape(-1), (imgs[1] * U.ANG2BOHR).reshape(-1)
 free0 = torch.cuda.mem_get_info()[0]
 t0 = time.perf_counter()

@@ -34,7 +34,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
-from pdb2reaction_amd import weights as W
+from . import tables as W    # literal constants of the oracle (NOT the product's tables: see tables.py)
 
 C = W.SPHERE_CHANNELS
 H = W.HIDDEN_CHANNELS

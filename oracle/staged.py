@@ -18,7 +18,7 @@ from typing import Dict
 import numpy as np
 import torch
 
-from pdb2reaction_amd import weights as W
+from . import tables as W    # literal constants of the oracle (NOT the product's tables: see tables.py)
 from . import escn_md_oracle as O
 
 C, H, S = O.C, O.H, O.S

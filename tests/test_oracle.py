@@ -14,6 +14,30 @@ def system():
     return z, pos
 
 
+def test_oracle_tables_equal_product_tables():
+    """The oracle keeps its OWN literal constants (oracle/tables.py, each citing SURVEY.md App. A); product and checker
+    must agree on every one of them -- a wrong table in either place fails here instead of cancelling silently."""
+    from oracle import tables as T
+    import oracle.escn_md_oracle as O
+    import oracle.staged as ST
+
+    assert O.W is T and ST.W is T                                      # the oracle really uses its own tables
+    for name in ("LMAX", "MMAX", "NUM_SPH", "SPHERE_CHANNELS", "HIDDEN_CHANNELS", "EDGE_CHANNELS", "NUM_LAYERS",
+                 "NUM_DISTANCE_BASIS", "CUTOFF", "MAX_NEIGHBORS", "EDGE_FEAT", "RADIAL_HIDDEN", "MAX_NUM_ELEMENTS", "DEG_RESCALE",
+                 "CHARGE_OFFSET", "NUM_CHARGE", "NUM_SPIN", "DATASET_LIST", "NORM_EPS", "LN_EPS", "TO_M", "L_OF_LP", "L_OF_MP"):
+        assert getattr(T, name) == getattr(W, name), name
+    # tables that must be self-consistent on their own: TO_M is a permutation grouping m = 0 | +-1 | +-2
+    assert sorted(T.TO_M) == list(range(9))
+    m_of_lp = [m for l in range(3) for m in range(-l, l + 1)]
+    assert [abs(m_of_lp[i]) for i in T.TO_M] == [0, 0, 0, 1, 1, 1, 1, 2, 2]
+    assert [T.L_OF_LP[i] for i in T.TO_M] == list(T.L_OF_MP)
+    assert list(T.L_OF_LP) == [l for l in range(3) for _ in range(2 * l + 1)]
+    shapes = W.param_shapes()
+    for key, shp in T.SHAPES.items():
+        hits = [v for k, v in shapes.items() if k.endswith(key)]
+        assert hits and all(tuple(h) == tuple(shp) for h in hits), key
+
+
 def test_param_inventory():
     shapes = W.param_shapes()
     n = sum(int(np.prod(s)) for s in shapes.values())

@@ -1,0 +1,115 @@
+"""Host-side restatements pinned to the REFERENCE's own functions.
+
+tests/golden/ref_host_functions.json holds input -> output vectors produced by executing the reference's pure helper
+functions in the build container (tools/make_reference_fixtures.py; the fixture is data, no reference source).  Each test
+feeds the recorded inputs to this repo's counterpart and compares with the recorded outputs: exact for integer / text /
+structural results, 1e-13 relative for float64 arithmetic whose operation order differs (vectorised bias, SVD sign
+conventions are identical because both use numpy.linalg.svd on the same matrix)."""
+import copy
+import json
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from pdb2reaction_amd import bond_changes as BC, formats as F, prestep as PS
+from pdb2reaction_amd._calculator_base import ANG2BOHR, BOHR2ANG
+from pdb2reaction_amd.hessian import EV_PER_ANG2_TO_AU
+from pdb2reaction_amd.string import select_hei_index
+
+
+@pytest.fixture(scope="module")
+def fx():
+    with open(os.path.join(GOLDEN, "ref_host_functions.json")) as f:
+        return json.load(f)
+
+
+def test_constants_are_the_ones_the_fixture_was_made_with(fx):
+    c = fx["constants"]
+    assert c["ANG2BOHR"] == ANG2BOHR and c["BOHR2ANG"] == BOHR2ANG and c["H_EVAA_2_AU"] == EV_PER_ANG2_TO_AU
+
+
+def test_select_hei_index_matches_reference(fx):
+    assert len(fx["select_hei_index"]) >= 40
+    for case in fx["select_hei_index"]:
+        assert select_hei_index(case["energies"]) == case["index"], case["energies"]
+
+
+def test_kabsch_matches_reference(fx):
+    for case in fx["kabsch_R_t"]:
+        R, t = PS.kabsch_R_t(np.array(case["P"]), np.array(case["Q"]))
+        np.testing.assert_allclose(R, case["R"], rtol=0, atol=1e-14)
+        np.testing.assert_allclose(t, case["t"], rtol=0, atol=1e-13)
+        assert np.linalg.det(R) > 0.999                                     # proper rotation, reflection case included
+
+
+def test_rotation_helpers_match_reference(fx):
+    for case in fx["rodrigues"]:
+        np.testing.assert_allclose(PS._rodrigues(np.array(case["axis"]), case["theta"]), case["R"], rtol=0, atol=1e-15)
+    for case in fx["rotation_align_vectors"]:
+        np.testing.assert_allclose(PS._rotation_a_to_b(np.array(case["a"]), np.array(case["b"])), case["R"], rtol=0, atol=1e-15)
+    for case in fx["rmsd"]:
+        assert PS.rmsd_ang(np.array(case["A"]), np.array(case["B"])) == pytest.approx(case["rmsd_ang"], rel=1e-15)
+
+
+def test_harmonic_bias_matches_reference(fx):
+    for case in fx["harmonic_bias"]:
+        hb = PS.HarmonicBias(base_calc=None, k=case["k_ev_ang2"], pairs=[tuple(p) for p in case["pairs"]])
+        x = np.array(case["coords_bohr"])
+        e, f = hb._bias(x[None])
+        assert float(e[0]) == pytest.approx(case["energy"], rel=1e-13)
+        np.testing.assert_allclose(f[0].reshape(-1), case["forces"], rtol=1e-13, atol=1e-16)
+        # and through the calculator protocol on top of a base calculator that returns zeros
+        base = SimpleNamespace(get_forces=lambda elem, c: {"energy": 0.0, "forces": np.zeros(x.size)},
+                               get_energy=lambda elem, c: {"energy": 0.0})
+        hb2 = PS.HarmonicBias(base, k=case["k_ev_ang2"], pairs=[tuple(p) for p in case["pairs"]])
+        r = hb2.get_forces(["X"] * len(x), x.reshape(-1))
+        assert r["energy"] == pytest.approx(case["energy"], rel=1e-13)
+        np.testing.assert_allclose(r["forces"], case["forces"], rtol=1e-13, atol=1e-16)
+
+
+def test_bond_change_report_text_matches_reference(fx):
+    for case in fx["summarize_changes"]:
+        res = BC.BondChangeResult(formed_covalent={tuple(p) for p in case["formed"]}, broken_covalent={tuple(p) for p in case["broken"]},
+                                  distances_1=None if case["d1"] is None else np.array(case["d1"]),
+                                  distances_2=None if case["d2"] is None else np.array(case["d2"]))
+        assert BC.summarize_changes(SimpleNamespace(atoms=case["atoms"]), res, case["one_based"]) == case["text"]
+
+
+def test_energy_reader_matches_reference(fx, tmp_path):
+    p = tmp_path / "a.trj"
+    for case in fx["read_energies_xyz"]:
+        p.write_text(case["text"])
+        if "raises" in case:
+            with pytest.raises(RuntimeError) as ei:
+                F.read_energies_xyz(p)
+            assert case["raises"] == "RuntimeError"
+            assert str(ei.value).replace(str(p), "<path>") == case["message"]
+        else:
+            assert F.read_energies_xyz(p) == case["energies"]
+
+
+def test_yaml_helpers_match_reference(fx, tmp_path):
+    for case in fx["deep_update"]:
+        dst = copy.deepcopy(case["dst"])
+        out = F.deep_update(dst, copy.deepcopy(case["src"]))
+        assert out is dst and dst == case["result"]
+    for case in fx["apply_yaml_overrides"]:
+        targets = [(copy.deepcopy(t["before"]), tuple(tuple(p) for p in t["paths"])) for t in case["targets"]]
+        F.apply_yaml_overrides(case["yaml"], targets)
+        for (got, _), t in zip(targets, case["targets"]):
+            assert got == t["after"], t
+    p = tmp_path / "c.yaml"
+    for case in fx["load_yaml_dict"]:
+        if case["text"] is None:
+            assert F.load_yaml_dict(None) == case["data"]
+            continue
+        p.write_text(case["text"])
+        if "raises" in case:
+            with pytest.raises(ValueError) as ei:
+                F.load_yaml_dict(p)
+            assert case["raises"] == "ValueError" and str(ei.value) == case["message"]
+        else:
+            assert F.load_yaml_dict(p) == case["data"]

@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ref_host_functions.json: input -> output vectors of the REFERENCE's own pure helper functions.
+
+BUILD-CONTAINER ONLY (needs /root/reference; the GPU box never has it and never runs this).  The reference package cannot
+be imported here (pysisyphus / ase / fairchem are absent), but a handful of its host-side helpers are self-contained
+numpy / stdlib code.  This script parses the reference files with ``ast``, compiles ONLY the named function definitions
+(nothing else of the module is executed, no module of the reference is imported, no third-party stand-ins are written)
+and records what they return on seeded inputs.  The fixture is DATA (inputs and outputs); no reference source text is
+stored.  tests/test_reference_fixtures.py then holds this repo's restatements to those outputs:
+
+  pdb2reaction/path_opt.py            _select_hei_index                         -> pdb2reaction_amd.string.select_hei_index
+  pdb2reaction/align_freeze_atoms.py  kabsch_R_t, _rodrigues,
+                                      _rotation_align_vectors, _rmsd            -> pdb2reaction_amd.prestep.*
+  pdb2reaction/opt.py                 HarmonicBiasCalculator._bias_energy_forces_bohr -> prestep.HarmonicBias._bias
+  pdb2reaction/bond_changes.py        _bond_str, summarize_changes              -> pdb2reaction_amd.bond_changes.*
+  pdb2reaction/trj2fig.py             read_energies_xyz                         -> pdb2reaction_amd.formats.read_energies_xyz
+  pdb2reaction/utils.py               deep_update, apply_yaml_overrides,
+                                      load_yaml_dict                            -> pdb2reaction_amd.formats.*
+
+Unit constants the reference takes from pysisyphus.constants are passed in from scipy and recorded
+in the fixture.
+"""
+from __future__ import annotations
+
+import ast
+import copy
+import json
+import os
+import re
+import sys
+import tempfile
+import types
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Any, Dict, Iterable, List, Mapping, Optional, Sequence, Set, Tuple
+
+import numpy as np
+
+REF = Path(os.environ.get("REFERENCE_ROOT", "/root/reference")) / "pdb2reaction"
+ROOT = Path(__file__).resolve().parent.parent
+OUT = ROOT / "tests" / "golden" / "ref_host_functions.json"
+sys.path.insert(0, str(ROOT))
+from pdb2reaction_amd._calculator_base import ANG2BOHR, AU2EV, BOHR2ANG  # noqa: E402  (scipy CODATA, as pysisyphus)
+
+H_EVAA_2_AU = 1.0 / AU2EV / ANG2BOHR / ANG2BOHR
+
+
+def grab(path: Path, names: Sequence[str], cls: Optional[str] = None, extra: Optional[Dict[str, Any]] = None) -> Dict[str, Any]:
+    """Compile the named module-level functions / dataclasses (or methods of class `cls`) of one reference file."""
+    src = path.read_text()
+    tree = ast.parse(src)
+    body = tree.body
+    if cls is not None:
+        body = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls).body
+    ns: Dict[str, Any] = {"np": np, "re": re, "Any": Any, "Dict": Dict, "List": List, "Tuple": Tuple, "Optional": Optional,
+                          "Sequence": Sequence, "_Sequence": Sequence, "Mapping": Mapping, "Set": Set, "Iterable": Iterable,
+                          "Path": Path, "dataclass": dataclass, "ANG2BOHR": ANG2BOHR, "BOHR2ANG": BOHR2ANG,
+                          "H_EVAA_2_AU": H_EVAA_2_AU}
+    ns.update(extra or {})
+    for node in body:
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)) and node.name in names:
+            mod = ast.Module(body=[node], type_ignores=[])
+            exec(compile(mod, f"<{path.name}:{node.name}>", "exec"), ns)
+    missing = [n for n in names if n not in ns]
+    if missing:
+        raise RuntimeError(f"{path}: {missing} not found")
+    return ns
+
+
+def main():
+    rng = np.random.default_rng(20261004)
+    fx: Dict[str, Any] = {"constants": {"ANG2BOHR": ANG2BOHR, "BOHR2ANG": BOHR2ANG, "H_EVAA_2_AU": H_EVAA_2_AU},
+                          "generated_by": "tools/make_reference_fixtures.py", "reference": "t-0hmura/pdb2reaction (local checkout)"}
+
+    # ---- HEI rule (path_opt.py:259-273)
+    hei = grab(REF / "path_opt.py", ["_select_hei_index"])["_select_hei_index"]
+    cases = [[0.0, 1.0], [3.0], [0.0, 2.0, 1.0], [0.0, 1.0, 3.0, 2.0, 5.0, 4.0, 0.5], [5.0, 1.0, 2.0, 3.0, 9.0],
+             [9.0, 1.0, 0.5, 0.2, 0.1], [1.0, 1.0, 1.0, 1.0], [0.0, 2.0, 2.0, 1.0], [0.0, 3.0, 1.0, 3.0, 0.0]]
+    cases += [list(rng.normal(size=int(n))) for n in rng.integers(2, 30, size=40)]
+    fx["select_hei_index"] = [{"energies": c, "index": int(hei(c))} for c in cases]
+
+    # ---- alignment maths (align_freeze_atoms.py:128-225)
+    al = grab(REF / "align_freeze_atoms.py", ["kabsch_R_t", "_rodrigues", "_rotation_align_vectors", "_orth_proj_perp", "_rmsd"])
+    kab = []
+    for n in (3, 4, 7, 25):
+        P = rng.normal(size=(n, 3)) * 3.0
+        Q = rng.normal(size=(n, 3)) * 3.0
+        if n == 7:                                # mobile = rotated + reflected copy: exercises the det < 0 branch
+            Q = P @ np.diag([1.0, 1.0, -1.0]) + 0.01 * rng.normal(size=(n, 3))
+        R, t = al["kabsch_R_t"](P.copy(), Q.copy())
+        kab.append({"P": P.tolist(), "Q": Q.tolist(), "R": R.tolist(), "t": t.tolist()})
+    fx["kabsch_R_t"] = kab
+    rod = []
+    for _ in range(6):
+        ax, th = rng.normal(size=3), float(rng.uniform(-np.pi, np.pi))
+        rod.append({"axis": ax.tolist(), "theta": th, "R": al["_rodrigues"](ax.copy(), th).tolist()})
+    rod.append({"axis": [0.0, 0.0, 0.0], "theta": 1.0, "R": al["_rodrigues"](np.zeros(3), 1.0).tolist()})
+    fx["rodrigues"] = rod
+    rav = []
+    pairs = [(rng.normal(size=3), rng.normal(size=3)) for _ in range(6)]
+    pairs += [(np.array([1.0, 2.0, 3.0]), np.array([2.0, 4.0, 6.0])), (np.array([1.0, 0.0, 0.0]), np.array([-2.0, 0.0, 0.0])),
+              (np.array([0.0, 1.0, 0.0]), np.array([0.0, -1.0, 0.0])), (np.zeros(3), np.array([1.0, 0.0, 0.0]))]
+    for a, b in pairs:
+        rav.append({"a": a.tolist(), "b": b.tolist(), "R": al["_rotation_align_vectors"](a.copy(), b.copy()).tolist()})
+    fx["rotation_align_vectors"] = rav
+    fx["rmsd"] = []
+    for n in (1, 5, 40):
+        A, B = rng.normal(size=(n, 3)), rng.normal(size=(n, 3))
+        fx["rmsd"].append({"A": A.tolist(), "B": B.tolist(), "rmsd_ang": al["_rmsd"](A, B)})
+
+    # ---- harmonic bias (opt.py:298-322): the method compiled on its own, `self` = a plain namespace with the two attributes it reads
+    bias_fn = grab(REF / "opt.py", ["_bias_energy_forces_bohr"], cls="HarmonicBiasCalculator")["_bias_energy_forces_bohr"]
+    fx["harmonic_bias"] = []
+    for n, k_ev in ((4, 10.0), (9, 3.5), (3, 100.0)):
+        x = rng.normal(size=(n, 3)) * 2.5
+        prs = [(int(i), int(j), float(t)) for i, j, t in zip(rng.integers(0, n, 6), rng.integers(0, n, 6), rng.uniform(0.8, 3.0, 6))]
+        prs += [(0, n + 3, 1.0), (-1, 0, 1.0), (1, 1, 1.5)]                 # out of range / self pair: skipped by the reference
+        me = types.SimpleNamespace(k_au_bohr2=float(k_ev) * H_EVAA_2_AU, _pairs=list(prs))
+        e, f = bias_fn(me, x.reshape(-1).copy())
+        fx["harmonic_bias"].append({"k_ev_ang2": k_ev, "coords_bohr": x.tolist(), "pairs": [list(p) for p in prs],
+                                    "energy": float(e), "forces": np.asarray(f).tolist()})
+
+    # ---- bond-change report text (bond_changes.py:96-232)
+    bc = grab(REF / "bond_changes.py", ["BondChangeResult", "_bond_str", "summarize_changes"], extra={"Pair": Tuple[int, int]})
+    fx["summarize_changes"] = []
+    for formed, broken, with_d in (({(0, 2), (1, 3)}, {(2, 4)}, True), (set(), {(0, 1)}, True), (set(), set(), True), ({(3, 4)}, set(), False)):
+        n = 5
+        d1, d2 = np.abs(rng.normal(size=(n, n))) * 4 + 1, np.abs(rng.normal(size=(n, n))) * 4 + 1
+        res = bc["BondChangeResult"](formed_covalent=formed, broken_covalent=broken, distances_1=d1 if with_d else None,
+                                     distances_2=d2 if with_d else None)
+        geom = types.SimpleNamespace(atoms=["c", "H", "o", "N", "cl"])
+        for one_based in (True, False):
+            fx["summarize_changes"].append({"atoms": geom.atoms, "formed": sorted(map(list, formed)), "broken": sorted(map(list, broken)),
+                                            "d1": d1.tolist() if with_d else None, "d2": d2.tolist() if with_d else None,
+                                            "one_based": one_based, "text": bc["summarize_changes"](geom, res, one_based)})
+
+    # ---- energy reader (trj2fig.py:86-109)
+    rd = grab(REF / "trj2fig.py", ["read_energies_xyz"])["read_energies_xyz"]
+    fx["read_energies_xyz"] = []
+    texts = ["2\n-1.5\nH 0 0 0\nH 0 0 1\n2\n   3.25 extra 7\nH 0 0 0\nH 0 0 1\n",
+             "1\nE = -1.25e-3 Hartree step 7\nH 0 0 0\n1\nenergy: 42\nH 0 0 1\n",
+             "1\n-0.000000000001\nH 0 0 0\nnot a header\n1\n5.0\nH 0 0 0\n",
+             "1\nno number here\nH 0 0 0\n", "not an xyz\n", "", "1\n.5\nH 0 0 0\n", "1\n-228.123456789012\nC 1 2 3"]
+    with tempfile.TemporaryDirectory() as td:
+        for t in texts:
+            p = Path(td) / "a.trj"
+            p.write_text(t)
+            try:
+                fx["read_energies_xyz"].append({"text": t, "energies": rd(p)})
+            except Exception as exc:
+                fx["read_energies_xyz"].append({"text": t, "raises": type(exc).__name__, "message": str(exc).replace(str(p), "<path>")})
+
+        # ---- YAML precedence (utils.py:243-313)
+        import yaml
+        ut = grab(REF / "utils.py", ["deep_update", "_get_mapping_section", "apply_yaml_overrides", "load_yaml_dict"], extra={"yaml": yaml})
+        fx["deep_update"] = []
+        for dst, src in (({"a": 1, "n": {"x": 1, "y": {"z": 2}}}, {"n": {"y": {"w": 3}, "x": [1, 2]}, "b": None}),
+                         ({"a": {"b": 1}}, {"a": 5}), ({"a": 5}, {"a": {"b": 1}}), ({"k": {"l": [1]}}, None), ({}, {"q": {"r": {}}})):
+            d = copy.deepcopy(dst)
+            fx["deep_update"].append({"dst": dst, "src": src, "result": ut["deep_update"](d, copy.deepcopy(src))})
+        fx["apply_yaml_overrides"] = []
+        ycfg = {"calc": {"charge": 2, "spin": 3}, "gs": {"max_nodes": 14, "nested": {"b": 5}}, "sopt": {"lbfgs": {"thresh": "gau"}},
+                "lbfgs": {"thresh": "baker"}, "opt": None, "scalar": 7, "deep": {"x": {"y": 4}}}
+        targets = [({"charge": -1, "model": "uma-s-1p1"}, [["calc"]]), ({"max_nodes": 10, "nested": {"a": 1, "b": 2}}, [["gs"]]),
+                   ({"thresh": "gau_loose", "max_cycles": 100}, [["sopt", "lbfgs"], ["lbfgs"]]), ({"thresh": "x"}, [["missing"], ["lbfgs"]]),
+                   ({"a": 1}, [["opt"], ["scalar"], ["deep", "x"]]), ({"keep": True}, [["nope"], ["scalar", "deeper"]])]
+        tg = [(copy.deepcopy(t), tuple(tuple(p) for p in ps)) for t, ps in targets]
+        ut["apply_yaml_overrides"](ycfg, tg)
+        fx["apply_yaml_overrides"].append({"yaml": ycfg, "targets": [{"before": t, "paths": ps, "after": a[0]} for (t, ps), a in zip(targets, tg)]})
+        fx["load_yaml_dict"] = []
+        for t in ("calc:\n  charge: 2\n", "", "- 1\n- 2\n", "a: {b: [1, 2], c: null}\n", "42\n"):
+            p = Path(td) / "c.yaml"
+            p.write_text(t)
+            try:
+                fx["load_yaml_dict"].append({"text": t, "data": ut["load_yaml_dict"](p)})
+            except Exception as exc:
+                fx["load_yaml_dict"].append({"text": t, "raises": type(exc).__name__, "message": str(exc)})
+        fx["load_yaml_dict"].append({"text": None, "data": ut["load_yaml_dict"](None)})
+
+    OUT.parent.mkdir(parents=True, exist_ok=True)
+    OUT.write_text(json.dumps(fx, indent=1, sort_keys=True) + "\n")
+    print(f"wrote {OUT} ({OUT.stat().st_size} bytes): " + ", ".join(f"{k}={len(v)}" for k, v in fx.items() if isinstance(v, list)))
+
+
+if __name__ == "__main__":
+    main()

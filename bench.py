@@ -10,9 +10,17 @@ is fixed by BASELINE.json's workload, N=1 evaluates all 16 images on one GPU).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 3 --warmup 1
 
-Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (fp32-MFMA GEMM
-family, timed live with HIP events on the launch stream) and `cpu_baseline` (the repo's own CPU
-restatement -- the reference's fairchem path cannot run here -- on a bounded sample, N=1 only).
+Rank 0 prints ONE JSON line (contract in the task statement) carrying
+
+* `roofline`: the dominant kernel family = the split-bf16 LDS-DMA GEMMs (SO(2) / radial linears and their transposes),
+  timed live with HIP events on the launch stream.  `achieved` / `frac` are ALGORITHMIC: 2*M*N*K per product (SURVEY.md
+  8d / Appendix D) over the measured kernel time, against the dense bf16 MFMA peak.  The 6x / 3x redundant bf16 products of
+  the 3-plane / 2-plane split are emulation overhead, reported separately as `mfma_pipe_util` (executed FLOPs / peak).
+  `traffic` (HBM bytes per launch from rocprofv3 PMC passes) is only emitted when the committed summary under profiles/
+  was measured on EXACTLY this build (source digest compiled into libumx.so), else null + `traffic_source` says why;
+* `fp32_mode`: the same workload on the all-fp32-MFMA build of the engine (`UMX_PRECISION=fp32`, the strict
+  same-arithmetic-as-the-reference number), a few steps timed the same way (N=1 only);
+* `cpu_baseline`: the repo's own CPU restatement (the reference's fairchem path cannot run here) on a bounded sample.
 """
 from __future__ import annotations
 
@@ -40,26 +48,23 @@ PEAK_FP32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparse headline)
 
 
-def pmc_traffic_per_launch(split: bool):
-    """HBM bytes per launch of the dominant GEMM family from the committed rocprofv3 PMC passes (profiles/), or None.
-    bench.py cannot collect PMC counters itself; the figure is for exactly this workload and build."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")
-    try:
-        d = json.load(open(path))
-        return float(d["dominant_family"]["hbm_bytes_per_launch_avg"]) if split else None
-    except Exception:
-        return None
+PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_hbm_traffic.json")
 
 
-def pmc_non_gemm_bytes_per_step(split: bool):
-    """HBM bytes per iteration moved by everything EXCEPT the two GEMM families (same committed PMC passes), or None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")
+def pmc_summary(build_digest: str):
+    """(summary dict | None, source note).  bench.py cannot collect PMC counters itself (rocprofv3 wraps the process), so HBM
+    traffic comes from the committed summary of two PMC passes over this very command -- but ONLY when that summary was
+    measured on the build that is running now (`csrc_sha256` == the digest compiled into libumx.so).  A kernel edit makes
+    the figure vanish from the line instead of going stale."""
     try:
-        d = json.load(open(path))
-        return (float(d["hbm_bytes_per_iteration"]) - float(d["dominant_family"]["hbm_bytes_per_iteration"])
-                - float(d.get("fp32_gemm_family_hbm_bytes_per_iteration", 0.0))) if split else None
-    except Exception:
-        return None
+        with open(PMC_SUMMARY) as f:
+            d = json.load(f)
+    except Exception as exc:
+        return None, f"no PMC summary ({type(exc).__name__})"
+    rel = os.path.relpath(PMC_SUMMARY, os.path.dirname(os.path.abspath(__file__)))
+    if d.get("csrc_sha256") != build_digest:
+        return None, f"{rel} is stale: measured on build {str(d.get('csrc_sha256'))[:12]}, running {build_digest[:12]}"
+    return d, f"{rel} @ build {build_digest[:12]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 FETCH correction)"
 
 
 PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak (about 6.3 TB/s is achievable by a float4 copy)
@@ -77,16 +82,22 @@ def usable_cores() -> int:
     return max(1, min(n, int(os.environ.get("UMX_CPU_BASELINE_THREADS", "16"))))
 
 
-def cpu_baseline(n_atoms_sample: int, edges_per_iter: float):
-    """Time the CPU oracle (float32, all host threads) on ONE image of `n_atoms_sample` atoms and scale
-    by directed edges to the benchmark's string iteration."""
+def cpu_baseline(edges_per_iter: float, c2_atoms: int = 500):
+    """The CPU oracle (float32, all usable host threads) on a BOUNDED sample: configuration c1 in full (50 atoms x 8
+    images) and ONE image of the c2 size (500 atoms; a full c3 iteration would take ~10 minutes of CPU), the latter scaled
+    by directed edges to the benchmark's string iteration (the work is linear in edges: SURVEY.md Appendix D)."""
     from oracle.escn_md_oracle import Oracle, radius_graph
 
     cores = usable_cores()
     torch.set_num_threads(cores)
     w = W.make_synthetic_weights(0)
     orc = Oracle(w, dtype=torch.float32)
-    z, pos = synth.make_cluster(n_atoms_sample)
+    z1, imgs1, _ = synth.make_images(50, 8)
+    t0 = time.perf_counter()
+    for k in range(len(imgs1)):
+        orc.energy_forces(z1, imgs1[k].astype(np.float32))
+    t_c1 = time.perf_counter() - t0
+    z, pos = synth.make_cluster(c2_atoms)
     src, _ = radius_graph(torch.as_tensor(pos), W.CUTOFF)
     t0 = time.perf_counter()
     orc.energy_forces(z, pos.astype(np.float32))
@@ -95,8 +106,10 @@ def cpu_baseline(n_atoms_sample: int, edges_per_iter: float):
     it_s = 1.0 / (dt * edges_per_iter / ne)
     return {
         "value": it_s, "unit": "iterations/s", "cores": cores, "kind": "port",
-        "sample": f"own CPU restatement (oracle/, torch float32, {cores} threads), 1 image x {n_atoms_sample} atoms "
-                  f"({ne} directed edges) E+F in {dt:.2f} s, scaled by edges to the {int(edges_per_iter)}-edge iteration",
+        "sample": f"own CPU restatement (oracle/, torch float32 autograd, {cores} threads), NOT fairchem: c1 in full (50 atoms x 8 images) "
+                  f"{t_c1:.2f} s = {1.0 / t_c1:.3f} iterations/s; one c2-size image ({c2_atoms} atoms, {ne} directed edges) E+F in {dt:.2f} s, "
+                  f"scaled by edges to the {int(edges_per_iter)}-edge c3 iteration",
+        "c1_iterations_per_s": 1.0 / t_c1,
     }
 
 
@@ -107,8 +120,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--atoms", type=int, default=2000)
     ap.add_argument("--images", type=int, default=16)
-    ap.add_argument("--cpu-sample-atoms", type=int, default=700)
+    ap.add_argument("--cpu-sample-atoms", type=int, default=500, help="size of the single timed CPU-oracle image (c2 size by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-mode", action="store_true")
+    ap.add_argument("--fp32-steps", type=int, default=2)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,53 +148,64 @@ def main():
 
     n, k = args.atoms, args.images
     z, imgs, frozen = synth.make_images(n, k)
-    eng = Engine(local_rank)
-    eng.load_weights(W.make_synthetic_weights(0))
-    eng.set_system(z, charge=0, spin=1, task="omol")
+    weights = W.make_synthetic_weights(0)
     frozen_t = torch.as_tensor(frozen, dtype=torch.long, device=dev)
-
-    # string state: coordinates in Bohr, float64, resident on the device
-    x = torch.as_tensor(imgs * ANG2BOHR, dtype=torch.float64, device=dev)       # (K,N,3)
-
     kl_max = -(-k // world)
-    pos32 = torch.empty(kl_max, n, 3, dtype=torch.float32, device=dev)
-    e_loc = torch.empty(kl_max, dtype=torch.float64, device=dev)
-    f_loc = torch.empty(kl_max, n, 3, dtype=torch.float32, device=dev)
-
-    def evaluate_local(c_bohr):
-        kl = c_bohr.shape[0]
-        pos32[:kl].copy_(c_bohr * BOHR2ANG)                                        # AtomicData.pos is float32 Angstrom
-        eng.energy_forces_dev(kl, pos32.data_ptr(), e_loc.data_ptr(), f_loc.data_ptr(),
-                              stream=torch.cuda.current_stream().cuda_stream)
-        f = f_loc[:kl].to(torch.float64) * F_EVAA_2_AU
-        f[:, frozen_t, :] = 0.0                                                    # uma_pysis.py:561-567
-        return e_loc[:kl] * EV2AU, f
-
-    ev = ShardedImageEvaluator(evaluate_local, k, n, dev)
-
-    def step(xc):
-        e, f = ev(xc)
-        xn = string_step(xc.reshape(k, -1), f.reshape(k, -1), max_step=0.1, alpha=0.5, fix_ends=False)
-        return xn.reshape(k, n, 3), e
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        x, e = step(x)
-    fence()
-    eng.profile_enable(True)
-    eng.profile_read(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        x, e = step(x)
-    fence()
-    dt = time.perf_counter() - t0
-    prof = eng.profile_read(True)
-    eng.profile_enable(False)
-    ne_local, maxdeg = eng.graph_stats()            # edges of this rank's images in the last step
+    def run(precision: str, steps: int, warmup: int):
+        """W untimed + K timed string iterations on a fresh engine in `precision` mode; returns (dt, profile, edges, maxdeg)."""
+        os.environ["UMX_PRECISION"] = precision              # read by umx_load_weights
+        eng = Engine(local_rank)
+        eng.load_weights(weights)
+        eng.set_system(z, charge=0, spin=1, task="omol")
+        x = torch.as_tensor(imgs * ANG2BOHR, dtype=torch.float64, device=dev)       # string state: Bohr, float64, in HBM
+        pos32 = torch.empty(kl_max, n, 3, dtype=torch.float32, device=dev)
+        e_loc = torch.empty(kl_max, dtype=torch.float64, device=dev)
+        f_loc = torch.empty(kl_max, n, 3, dtype=torch.float32, device=dev)
+
+        def evaluate_local(c_bohr):
+            kl = c_bohr.shape[0]
+            pos32[:kl].copy_(c_bohr * BOHR2ANG)                                    # AtomicData.pos is float32 Angstrom
+            # the engine enqueues on torch's current stream (handle 0 = the legacy default stream): producer (copy above) and
+            # consumers (conversion below, the all-gather) are ordered with it by the stream alone
+            eng.energy_forces_dev(kl, pos32.data_ptr(), e_loc.data_ptr(), f_loc.data_ptr(),
+                                  stream=torch.cuda.current_stream().cuda_stream)
+            f = f_loc[:kl].to(torch.float64) * F_EVAA_2_AU
+            f[:, frozen_t, :] = 0.0                                                # uma_pysis.py:561-567
+            return e_loc[:kl] * EV2AU, f
+
+        ev = ShardedImageEvaluator(evaluate_local, k, n, dev)
+
+        def step(xc):
+            e, f = ev(xc)
+            xn = string_step(xc.reshape(k, -1), f.reshape(k, -1), max_step=0.1, alpha=0.5, fix_ends=False)
+            return xn.reshape(k, n, 3), e
+
+        for _ in range(warmup):
+            x, e = step(x)
+        fence()
+        eng.profile_enable(True)
+        eng.profile_read(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            x, e = step(x)
+        fence()
+        dt = time.perf_counter() - t0
+        prof = eng.profile_read(True)
+        eng.profile_enable(False)
+        ne_local, maxdeg = eng.graph_stats()            # edges of this rank's images in the last step
+        if not bool(torch.isfinite(e).all()):
+            raise SystemExit("bench.py: non-finite energies in the timed region")
+        eng.close()
+        return dt, prof, ne_local, maxdeg
+
+    mode = os.environ.get("UMX_PRECISION", "split")
+    dt, prof, ne_local, maxdeg = run(mode, args.steps, args.warmup)
     tt = torch.tensor([dt, float(ne_local)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         tmax = tt.clone()
@@ -191,14 +217,16 @@ def main():
     it_s = args.steps / dt
 
     if rank == 0:
+        from pdb2reaction_amd.engine import load_library
+
+        digest = load_library().umx_build_digest().decode()
         pl, f32 = prof["split_bf16"], prof["fp32"]
         split = pl["launches"] > 0
         dom = pl if split else f32
-        # dominant kernel family: in the default (split) mode the plane-interleaved bf16 LDS-DMA GEMM.  `achieved` counts the
-        # FLOPs the matrix cores executed (6 bf16 MFMA products per fp32-equivalent product in the forward pass, 3 in the
-        # reverse pass) against the dense bf16 peak; `achieved_algorithmic` is the fp32-equivalent rate (2*M*N*K per product).
-        ach = dom["mfma_flops"] / max(dom["ms"], 1e-9) / 1e9
         peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
+        alg = dom["alg_flops"] / max(dom["ms"], 1e-9) / 1e9          # algorithmic TFLOP/s of the dominant family (2*M*N*K per product)
+        executed = dom["mfma_flops"] / max(dom["ms"], 1e-9) / 1e9    # what the matrix cores executed (x6 forward / x3 reverse split products)
+        pmc, pmc_note = pmc_summary(digest) if (n == 2000 and k == 16 and world == 1 and split) else (None, "PMC summary exists for c3 / 1 GPU / split mode only")
         out = {
             "metric": "path_opt_string_iterations_per_s", "value": it_s, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -207,35 +235,55 @@ def main():
             "data": "synthetic",
             "image_atom_steps_per_s": k * n * it_s,
             "algorithmic_tflops": FLOP_PER_EDGE * edges_iter * it_s / 1e12,
+            "build_digest": digest,
             "config": {"workload": f"c3: {n}-atom synthetic active-site cluster x {k} images, GSM-style string iteration "
                                    f"(batched UMA-S E+F of all images + string update), UMA-S shapes, synthetic weights",
                        "atoms": n, "images": k, "directed_edges_per_iteration": int(edges_iter), "max_degree": maxdeg,
                        "parallelism": f"images sharded {k}/{world} per GPU, 1 all-gather/iteration" if world > 1 else "single GPU, all images batched"},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                         "traffic": pmc_traffic_per_launch(split) if (n == 2000 and k == 16 and world == 1) else None,
+            "roofline": {"bound": "mfma", "achieved": alg, "peak": peak, "unit": "TFLOP/s", "frac": alg / peak,
+                         "definition": "achieved = algorithmic FLOPs (2*M*N*K per product, SURVEY.md 8d) of the family / its HIP-event time; "
+                                       "mfma_pipe_util counts the bf16 products actually executed (x6 fwd, x3 reverse)",
+                         "mfma_pipe_util": executed / peak, "executed_tflops": executed,
+                         "traffic": float(pmc["dominant_family"]["hbm_bytes_per_launch_avg"]) if pmc else None, "traffic_source": pmc_note,
                          "kernel": ("umx_gemm_q_kernel<*> / umx_gemm_pl16_kernel<*> / umx_gemm_pl_kernel<*> (split-bf16 LDS-DMA GEMM family: SO(2)/radial linears + transposes, rank 0)" if split
                                     else "umx_gemm_kernel<*> (fp32-MFMA GEMM, rank 0)"),
                          "launches": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
-                         "flops_per_launch": dom["mfma_flops"] / max(dom["launches"], 1),
-                         "achieved_algorithmic": dom["alg_flops"] / max(dom["ms"], 1e-9) / 1e9,
                          "algorithmic_flops_per_launch": dom["alg_flops"] / max(dom["launches"], 1),
-                         "share_of_step": dom["ms"] / (ms * args.steps),
+                         "executed_flops_per_launch": dom["mfma_flops"] / max(dom["launches"], 1),
+                         "ms_per_step": dom["ms"] / args.steps, "share_of_step": dom["ms"] / (ms * args.steps),
+                         "vs_fp32_mfma_peak": alg / PEAK_FP32_MFMA_TFLOPS,
                          "other_gemm_family": {"kernel": "umx_gemm_kernel<*> (fp32 MFMA)" if split else None,
                                                "ms_per_step": f32["ms"] / args.steps if split else 0.0,
                                                "achieved": f32["alg_flops"] / max(f32["ms"], 1e-9) / 1e9 if split else 0.0,
                                                "peak": PEAK_FP32_MFMA_TFLOPS}},
         }
         # second regime: the HBM-bound gather / rotate / gate / segmented-reduce kernels = everything outside the
-        # two GEMM families; bytes from the committed PMC passes of this exact workload, time measured live
-        nb = pmc_non_gemm_bytes_per_step(split) if (n == 2000 and k == 16 and world == 1) else None
-        if nb is not None:
-            rest_ms = ms - (dom["ms"] + f32["ms"]) / args.steps
-            out["roofline"]["hbm_regime"] = {"bound": "hbm", "kernels": "all non-GEMM kernels (k_gather_rotate_mod_pl, k_modrot_bwd_pl, k_gate_edge_*, k_rotate_back_*, ...)",
-                                             "ms_per_step": rest_ms, "traffic_per_step": nb, "achieved": nb / max(rest_ms, 1e-9) / 1e6,
-                                             "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": nb / max(rest_ms, 1e-9) / 1e6 / PEAK_HBM_GBPS}
+        # two GEMM families; time measured live, bytes from the PMC summary of this exact build (or omitted)
+        rest_ms = ms - (dom["ms"] + (f32["ms"] if split else 0.0)) / args.steps
+        hb = {"bound": "hbm", "kernels": "all non-GEMM kernels (k_gather_rotate_mod_q3, k_modrot_bwd_pl, k_gate_edge_*, k_rotate_back_*, ...)",
+              "ms_per_step": rest_ms, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "traffic_per_step": None, "achieved": None, "frac": None,
+              "traffic_source": pmc_note}
+        if pmc:
+            nb = (float(pmc["hbm_bytes_per_iteration"]) - float(pmc["dominant_family"]["hbm_bytes_per_iteration"])
+                  - float(pmc.get("fp32_gemm_family_hbm_bytes_per_iteration", 0.0)))
+            hb.update(traffic_per_step=nb, achieved=nb / max(rest_ms, 1e-9) / 1e6, frac=nb / max(rest_ms, 1e-9) / 1e6 / PEAK_HBM_GBPS,
+                      total_traffic_per_step=float(pmc["hbm_bytes_per_iteration"]))
+        out["roofline"]["hbm_regime"] = hb
+        if world == 1 and split and not args.no_fp32_mode:
+            # the strict same-arithmetic-as-the-reference figure: every GEMM on v_mfma_f32_32x32x2_f32, timed by the same clock
+            try:
+                dt32, prof32, _, _ = run("fp32", args.fp32_steps, 1)
+                g32 = prof32["fp32"]
+                out["fp32_mode"] = {"value": args.fp32_steps / dt32, "unit": "iterations/s", "ms_per_step": dt32 / args.fp32_steps * 1e3,
+                                    "steps": args.fp32_steps, "warmup": 1, "dtype": "f32 (all GEMMs on v_mfma_f32_32x32x2_f32)",
+                                    "gemm_tflops": g32["alg_flops"] / max(g32["ms"], 1e-9) / 1e9, "gemm_peak": PEAK_FP32_MFMA_TFLOPS,
+                                    "gemm_frac": g32["alg_flops"] / max(g32["ms"], 1e-9) / 1e9 / PEAK_FP32_MFMA_TFLOPS}
+            except Exception as exc:
+                out["fp32_mode"] = {"value": None, "error": f"{type(exc).__name__}: {exc}"}
+            os.environ["UMX_PRECISION"] = mode
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_sample_atoms, edges_iter)
+                out["cpu_baseline"] = cpu_baseline(edges_iter, args.cpu_sample_atoms)
             except Exception as exc:  # the baseline is informative; never lose the GPU numbers to it
                 out["cpu_baseline"] = {"value": None, "unit": "iterations/s", "cores": usable_cores(), "kind": "port",
                                        "sample": f"failed: {type(exc).__name__}: {exc}"}

@@ -37,6 +37,11 @@ enum umx_status {
 /* Version of this ABI (bumped on any signature change). */
 int umx_abi_version(void);
 
+/* sha256 (hex) over the kernel/host sources this library was compiled from (pdb2reaction_amd/build.py::source_digest),
+ * "unknown" for a hand-made build.  Lets the host side refuse a stale prebuilt library and lets committed profiler
+ * summaries name the exact build they were measured on.  No reference counterpart (the reference is pure Python).  */
+const char* umx_build_digest(void);
+
 /* Create / destroy an engine bound to HIP device `device_ordinal`.
  * Replaces: UMAcore.__init__ device selection, uma_pysis.py:200-203.                           */
 int umx_create(umx_engine** out, int device_ordinal);

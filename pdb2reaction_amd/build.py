@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -22,6 +23,19 @@ def dependencies() -> list:
     return deps + [ABI_HEADER]
 
 
+def source_digest() -> str:
+    """sha256 over names and contents of every file the library is compiled from.  It is compiled INTO the library
+    (``umx_build_digest()``), written next to it (``libumx.so.digest``) and recorded with every committed PMC summary, so a
+    stale prebuilt .so or a stale traffic figure is detected by content rather than by mtime."""
+    h = hashlib.sha256()
+    for d in dependencies():
+        h.update(os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
 def find_hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -33,17 +47,26 @@ def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(d) > t for d in dependencies())
+    if any(os.path.getmtime(d) > t for d in dependencies()):
+        return True
+    try:                                   # content check: a checkout can reset mtimes without changing the prebuilt .so
+        with open(OUT + ".digest") as f:
+            return f.read().strip() != source_digest()
+    except OSError:
+        return True
 
 
 def build_library(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return OUT
+    digest = source_digest()
     cmd = [find_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", CSRC,
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", OUT]
+           f'-DUMX_SRC_DIGEST="{digest}"', *[os.path.join(CSRC, s) for s in SOURCES], "-o", OUT]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    with open(OUT + ".digest", "w") as f:
+        f.write(digest + "\n")
     return OUT
 
 

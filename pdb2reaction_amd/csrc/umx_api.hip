@@ -572,7 +572,12 @@ std::vector<float> transpose(const float* src, int rows, int cols) {
 // ================================================================================================
 extern "C" {
 
-int umx_abi_version(void) { return 3; }
+int umx_abi_version(void) { return 4; }
+
+#ifndef UMX_SRC_DIGEST
+#define UMX_SRC_DIGEST "unknown"
+#endif
+const char* umx_build_digest(void) { return UMX_SRC_DIGEST; }
 
 const char* umx_last_error(const umx_engine* eng) { return eng ? eng->err.c_str() : g_create_err.c_str(); }
 

@@ -59,6 +59,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     vp, i32, i64p, dp, fp = C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_float)
     sigs = {
         "umx_abi_version": ([], i32),
+        "umx_build_digest": ([], C.c_char_p),
         "umx_create": ([C.POINTER(vp), i32], i32),
         "umx_destroy": ([vp], i32),
         "umx_last_error": ([vp], C.c_char_p),
@@ -79,12 +80,20 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.argtypes, fn.restype = args, res
     if path is None:
+        # content check against the sources in this tree: the .so is git-ignored and travels prebuilt, so an edit without a
+        # rebuild would silently run old kernels (VERDICT r1 "stale-.so hazard")
+        from .build import source_digest
+
+        have, want = lib.umx_build_digest().decode(), source_digest()
+        if have != want and os.environ.get("UMX_ALLOW_STALE", "0") != "1":
+            raise ImportError(f"{p} was built from other sources (digest {have[:12]}..., tree {want[:12]}...): rebuild with "
+                              "`python -m pdb2reaction_amd.build` (UMX_ALLOW_STALE=1 overrides)")
         _lib = lib
     return lib
 
 
 EXPORTED_SYMBOLS = (
-    "umx_abi_version", "umx_create", "umx_destroy", "umx_last_error", "umx_load_weights", "umx_set_system",
+    "umx_abi_version", "umx_build_digest", "umx_create", "umx_destroy", "umx_last_error", "umx_load_weights", "umx_set_system",
     "umx_set_workspace_limit", "umx_energy_forces", "umx_energy_forces_dev", "umx_synchronize",
     "umx_last_graph_stats", "umx_profile_enable", "umx_profile_read", "umx_bond_changes", "umx_debug_fetch", "umx_debug_keep",
 )

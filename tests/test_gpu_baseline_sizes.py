@@ -1,0 +1,145 @@
+"""GPU parity at the BASELINE sizes the headline is quoted on.
+
+tests/golden/c3c4_n2000.npz (tools/make_golden_c3.py) holds float64 oracle ENERGIES AND FORCES of 2000-atom images:
+two images of the c3 string (16 images) and two of the c4 string (24 images), plus two oracle finite-difference Hessian
+columns at c4 image 0.  The large-M code paths only exist at this size (2.3 M edges per iteration, 256 x 256 tiles, XCD
+mapping, index products above 2^31), and in split mode the reverse pass uses 16-bit-significand products -- so the
+forces are held to the north-star tolerance here, in BOTH precision modes, through the C ABI.
+
+  c3: ~2000-atom cluster, GSM 16 images                      (BASELINE.json configs[2])
+  c4: ~2000-atom cluster, DMF path_opt 24 images + freq Hessian (configs[3]; reference path_opt.py:399-426,
+      uma_pysis.py:595-686)
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from pdb2reaction_amd import synth
+
+U = importlib.import_module("pdb2reaction_amd.uma_pysis")
+
+pytestmark = pytest.mark.gpu
+
+TOL_E = 1e-4   # eV      (BASELINE.json north_star)
+TOL_F = 1e-3   # eV/A
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return load_golden("c3c4_n2000")
+
+
+@pytest.mark.parametrize("mode", ["split", "fp32"])
+def test_c3_energy_and_forces_against_f64_oracle(weights, gold, mode, monkeypatch):
+    """The headline configuration: E and F of 2000-atom images vs the float64 oracle, both precision modes."""
+    from pdb2reaction_amd.engine import Engine
+
+    monkeypatch.setenv("UMX_PRECISION", mode)
+    eng = Engine(0)
+    try:
+        eng.load_weights(weights)
+        eng.set_system(gold["z"])
+        e, f = eng.energy_forces(gold["c3_pos"])
+        ne, maxdeg = eng.graph_stats()
+        assert ne > 2 * 140_000 and maxdeg <= 300
+        de = np.abs(e - gold["c3_energy"])
+        df = np.abs(f.astype(np.float64) - gold["c3_forces"])
+        print(f"[c3 {mode}] |dE| = {de.max():.2e} eV, max|dF| = {df.max():.2e} eV/A, rms dF = {np.sqrt((df ** 2).mean()):.2e}")
+        assert de.max() <= TOL_E, (mode, de)
+        assert df.max() <= TOL_F, (mode, df.max())
+        # the reverse pass is systematic-error free too: the net force error over 2000 atoms stays at round-off level
+        assert np.abs((f.astype(np.float64) - gold["c3_forces"]).sum(axis=1)).max() <= 5e-4
+    finally:
+        eng.close()
+
+
+class FakeAtoms:
+    """The slice of ase.Atoms that torch_dmf / the reference's DMF path touches (path_opt.py:351-363,418-423)."""
+
+    def __init__(self, z, pos, charge=0, spin=1):
+        self.numbers = np.asarray(z)
+        self._p = np.asarray(pos, dtype=np.float64)
+        self.info = {"charge": charge, "spin": spin}
+        self.calc = None
+
+    def get_positions(self):
+        return self._p
+
+    def get_atomic_numbers(self):
+        return self.numbers
+
+
+def test_c4_dmf_24_images_one_batched_call(gold):
+    """c4's string: ONE calculate_images call for the 24 DMF images of a 2000-atom cluster (ASE protocol, eV and eV/A)."""
+    from pdb2reaction_amd.ase_calculator import UMXCalculator
+
+    z, imgs, _ = synth.make_images(2000, 24)
+    p32 = imgs.astype(np.float32)
+    i0, i1 = (int(i) for i in gold["c4_index"])
+    assert np.array_equal(p32[[i0, i1]], gold["c4_pos"]) and np.array_equal(z, gold["z"])
+    calc = UMXCalculator(model="synthetic", task_name="omol")
+    images = [FakeAtoms(z, p32[k]) for k in range(24)]
+    for im in images:
+        im.calc = calc
+    e, f = calc.calculate_images(images)
+    assert e.shape == (24,) and f.shape == (24, 2000, 3) and f.dtype == np.float64
+    assert np.isfinite(e).all() and np.isfinite(f).all()
+    for j, k in enumerate((i0, i1)):
+        assert abs(e[k] - gold["c4_energy"][j]) <= TOL_E
+        assert np.abs(f[k] - gold["c4_forces"][j]).max() <= TOL_F
+    # the image-by-image protocol torch_dmf uses gives bit-identical numbers (batch size / chunking never changes a result)
+    for k in (i1, 23):
+        assert calc.get_potential_energy(images[k]) == e[k]
+        assert np.array_equal(calc.get_forces(images[k]), f[k])
+    assert np.abs(f.sum(axis=1)).max() <= 5e-4                                   # Newton's third law, every image
+
+
+def test_c4_fd_hessian_2000_atoms(gold):
+    """c4's 'freq Hessian (3N force batches)': get_hessian on a 2000-atom image with 66 active DOF (the rest frozen),
+    compared with central differences of the float64 oracle forces on the two golden columns -- full 6000-long columns,
+    frozen rows included -- plus the return_partial_hessian / dtype / container variants (uma_pysis.py:515-551,595-686)."""
+    z = gold["z"]
+    i0 = int(gold["c4_index"][0])
+    assert i0 == 0
+    p64 = gold["c4_pos"][0].astype(np.float64)
+    order = np.argsort(np.einsum("ij,ij->i", p64, p64))
+    k_gold = [int(k) for k in gold["hess_dof"]]
+    active_atoms = sorted(set(int(a) for a in order[0:41:2]) | {int(order[1])} | {k // 3 for k in k_gold})
+    assert len(active_atoms) == 22
+    frozen = [a for a in range(2000) if a not in set(active_atoms)]
+    elem = [synth.SYMBOLS[int(q)] for q in z]
+    x_bohr = (p64 * U.ANG2BOHR).reshape(-1)
+
+    calc = U.uma_pysis(model="synthetic", freeze_atoms=frozen, out_hess_torch=False)
+    r = calc.get_hessian(elem, x_bohr)
+    h = r["hessian"]
+    assert isinstance(h, np.ndarray) and h.dtype == np.float64 and h.shape == (6000, 6000)
+    assert np.array_equal(h, h.T)
+    assert abs(r["energy"] / U.EV2AU - gold["c4_energy"][0]) <= TOL_E
+    fz = r["forces"].reshape(2000, 3)
+    assert np.all(fz[frozen] == 0.0)                                              # uma_pysis.py:561-567
+    assert np.abs(fz[active_atoms] / U.F_EVAA_2_AU - gold["c4_forces"][0][active_atoms]).max() <= TOL_F
+    act_dof = np.array([3 * a + c for a in active_atoms for c in range(3)])
+    frz_dof = np.array([3 * a + c for a in frozen for c in range(3)])
+    assert np.all(h[np.ix_(frz_dof, frz_dof)] == 0.0)                             # columns of frozen DOF are never built
+    tol_h = 1.5e-2          # eV/A^2: float32 forces (round-off ~1e-5 eV/A) / (2 * 1e-3 A); entries reach 0.68 eV/A^2
+    cols = gold["hess_cols"]                                                      # (2, 6000) eV/A^2, oracle FD
+    for j, k in enumerate(k_gold):
+        # frozen rows: H_sym[i,k] = (H[i,k] + 0) / 2 -- the whole column against the oracle
+        got = h[frz_dof, k] / U.H_EVAA_2_AU
+        assert np.abs(got - 0.5 * cols[j][frz_dof]).max() <= tol_h
+        assert np.abs(cols[j][frz_dof]).max() > 0.05                              # ... and it is not a comparison of zeros
+    sub = np.ix_(k_gold, k_gold)
+    ref = 0.5 * (cols[:, k_gold] + cols[:, k_gold].T)                             # symmetrised 2x2 block of the golden columns
+    assert np.abs(h[sub] / U.H_EVAA_2_AU - ref.T).max() <= tol_h
+    assert np.abs(np.diag(ref)).min() > 0.03                                      # (synthetic weights: curvatures are O(0.1) eV/A^2)
+
+    # partial Hessian: active block only, float32, torch on the device
+    calc2 = U.uma_pysis(model="synthetic", freeze_atoms=frozen, return_partial_hessian=True, hessian_double=False, out_hess_torch=True)
+    h2 = calc2.get_hessian(elem, x_bohr)["hessian"]
+    assert isinstance(h2, torch.Tensor) and h2.is_cuda and h2.dtype == torch.float32 and tuple(h2.shape) == (66, 66)
+    h2 = h2.cpu().numpy().astype(np.float64)
+    assert np.abs(h2 - h[np.ix_(act_dof, act_dof)]).max() <= 1e-6 * np.abs(h2).max() + 1e-7

@@ -24,9 +24,16 @@ def test_bench_json_line_contract():
     assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-6
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "mfma_pipe_util"):
         assert key in r, key
     assert r["bound"] in ("hbm", "mfma") and 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # frac is ALGORITHMIC (2*M*N*K per product / time / peak); the executed split products are the separate, larger figure
+    assert abs(r["achieved"] * 1e12 - r["algorithmic_flops_per_launch"] / (r["avg_launch_ms"] * 1e-3)) <= 1e-6 * r["achieved"] * 1e12
+    assert r["mfma_pipe_util"] >= 3.0 * r["frac"] * 0.999 and r["peak"] == 2500.0
+    assert r["traffic"] is None and r["hbm_regime"]["traffic_per_step"] is None       # no PMC summary exists for this tiny workload
+    f = d["fp32_mode"]                                                               # strict same-arithmetic figure, same clock
+    assert f["value"] > 0 and f["dtype"].startswith("f32") and 0.0 < f["gemm_frac"] < 1.0
+    assert len(d["build_digest"]) == 64
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key

@@ -60,10 +60,10 @@ def test_c3_energy_golden(engine):
     """2000-atom images (BASELINE c3 size) against float64 oracle energies (tools/make_golden_c3.py).
     Guards the systematic part of the error: anything shared by all atoms (e.g. the system embedding)
     must be exact, or the bias grows linearly with N (it was -2e-4 eV before sys_emb moved to float64)."""
-    g = load_golden("c3_n2000_energy")
+    g = load_golden("c3c4_n2000")                       # forces at this size: tests/test_gpu_baseline_sizes.py
     engine.set_system(g["z"])
-    e, _ = engine.energy_forces(g["pos"], forces=False)
-    assert np.abs(e - g["energy"]).max() <= TOL_E
+    e, _ = engine.energy_forces(g["c3_pos"], forces=False)
+    assert np.abs(e - g["c3_energy"]).max() <= TOL_E
 
 
 @pytest.mark.parametrize("mode", ["fp32", "split"])

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -55,12 +56,16 @@ struct umx_engine {
   bool ran_on_caller = false;
   hipStream_t stream2 = nullptr;   // second lane: half-chunks alternate streams so HBM-bound producers overlap the other lane's GEMMs
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_tok[2] = {nullptr, nullptr};   // matrix-pipe token of the two lanes (run_plans_alternating)
   bool q3_wide = true;             // UMX_Q3WIDE=0 (dev): 256x128 tiles for every forward GEMM
   bool q3 = true;                  // UMX_Q3=0: forward operands in the 32-column PL layout + 256x128 tiles (set before umx_load_weights)
   bool wide_tiles = true;          // UMX_WIDE=0: 256x128 tiles for every GEMM
   int mfma16 = 1;                  // UMX_MFMA16: 0 = v_mfma_f32_32x32x16_bf16 everywhere, 1 = 16x16x32 where it measured faster, 2 = everywhere
   bool fuse_modrot = true;         // UMX_FUSE_MODROT=0: separate k_modulate_bwd_pl + k_gather_rotate_bwd (debug: exposes g_xrot)
-  int n_lanes = 1;                 // UMX_STREAMS (1 or 2); 2 gives ~2.5 % on c3 but inflates event-bracketed kernel timings
+  int n_lanes = 1;                 // UMX_STREAMS (1 or 2): two chunks in flight, matrix segments alternating between the lanes
+  int stream_cap = 0;              // UMX_STREAM_BLOCKS: two-lane mode caps the grids of the grid-stride streaming kernels at this many
+                                   // workgroups (multiple of 8; default 512 = two per CU) so they run BESIDE the other lane's GEMM
+  bool throttle = false;           // set while a two-lane evaluation is being issued
   std::string err;
   // weights
   bool have_weights = false;
@@ -121,6 +126,10 @@ namespace {
 int fail(umx_engine* e, int code, const std::string& msg) { e->err = msg; return code; }
 
 inline unsigned nblk(long n, int per) { return (unsigned)((n + per - 1) / per); }
+// grid of a grid-stride ("virtual block") kernel: all blocks normally, capped in throttled two-lane mode
+inline unsigned vgrid(const umx_engine* eng, unsigned blocks) {
+  return (eng->throttle && eng->stream_cap > 0 && blocks > (unsigned)eng->stream_cap) ? (unsigned)eng->stream_cap : blocks;
+}
 
 // ---- GEMM launcher -----------------------------------------------------------------------------
 GemmP gp_zero() { GemmP p; std::memset(&p, 0, sizeof(p)); p.conj = 1.0f; return p; }
@@ -325,38 +334,52 @@ int dbg_capture(umx_engine* eng, const std::string& name, const void* dptr, size
 #define DBG(name, ptr, count) CHK(dbg_capture(eng, name, ptr, (size_t)(count) * sizeof(*(ptr))))
 
 // ---- radial MLP forward / backward -------------------------------------------------------------
-int radial_fwd(umx_engine* eng, const WS& w, const RadialW& r, int slot, long ne, float* rad_out) {
+// Each is split into its small layers (fp32 GEMMs + LayerNorm/SiLU kernels: "streaming" work) and the one large fc3 GEMM, so that
+// the two-lane executor can treat the large GEMM as a matrix-pipe segment (see Plan below).
+int radial_fwd_head(umx_engine* eng, const WS& w, const RadialW& r, int slot, long ne) {
   hipStream_t s = eng->stream;
   GemmP p = gp_zero();
   p.evec = w.evec; p.gcoef = eng->gcoef; p.gmu = eng->d_gmu; p.B = r.w1g; p.ldb = NG; p.Cp = w.h1pre[slot]; p.ldc = RH;
   p.TS = r.ts; p.TT = r.tt; p.ez = w.ez;
   p.M = (int)ne; p.N = RH; p.K = NG;
   CHK(launch_gemm(eng, p, A_GAUSS, 0, E_TABLES));
-  hipLaunchKernelGGL(k_ln_silu_fwd, dim3(nblk(ne, 4)), dim3(256), 0, s, w.h1pre[slot], r.ln1w, r.ln1b, w.ra, ne);
+  hipLaunchKernelGGL(k_ln_silu_fwd, dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h1pre[slot], r.ln1w, r.ln1b, w.ra, ne);
   CHK(gemm_plain(eng, w.ra, RH, 0, r.w2, RH, r.b2, w.h2pre[slot], RH, 0, ne, RH, RH));
   if (eng->pl && eng->planes.count(r.w3)) {
-    if (eng->q3) hipLaunchKernelGGL((k_ln_silu_fwd_pl<3, true>), dim3(nblk(ne, 4)), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne);
-    else hipLaunchKernelGGL((k_ln_silu_fwd_pl<3, false>), dim3(nblk(ne, 4)), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne);
-    CHK(gemm_pl(eng, 0, 3, w.a2pl, RH, 0, 0, r.w3, 0, r.b3, rad_out, r.out, 0, 0, ne, r.out, RH, 1.0f));
+    if (eng->q3) hipLaunchKernelGGL((k_ln_silu_fwd_pl<3, true>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne);
+    else hipLaunchKernelGGL((k_ln_silu_fwd_pl<3, false>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne);
   } else {
-    hipLaunchKernelGGL(k_ln_silu_fwd, dim3(nblk(ne, 4)), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.ra, ne);
-    CHK(gemm_plain(eng, w.ra, RH, 0, r.w3, RH, r.b3, rad_out, r.out, 0, ne, r.out, RH));
+    hipLaunchKernelGGL(k_ln_silu_fwd, dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.ra, ne);
   }
   HIPCHK(eng, hipGetLastError());
   return UMX_OK;
 }
+int radial_fwd_fc3(umx_engine* eng, const WS& w, const RadialW& r, long ne, float* rad_out) {
+  if (eng->pl && eng->planes.count(r.w3)) return gemm_pl(eng, 0, 3, w.a2pl, RH, 0, 0, r.w3, 0, r.b3, rad_out, r.out, 0, 0, ne, r.out, RH, 1.0f);
+  return gemm_plain(eng, w.ra, RH, 0, r.w3, RH, r.b3, rad_out, r.out, 0, ne, r.out, RH);
+}
+int radial_fwd(umx_engine* eng, const WS& w, const RadialW& r, int slot, long ne, float* rad_out) {
+  CHK(radial_fwd_head(eng, w, r, slot, ne));
+  return radial_fwd_fc3(eng, w, r, ne, rad_out);
+}
 
-int radial_bwd(umx_engine* eng, const WS& w, const RadialW& r, int slot, long ne, const float* grad, const unsigned short* gradpl = nullptr) {
+int radial_bwd_fc3(umx_engine* eng, const WS& w, const RadialW& r, long ne, const float* grad, const unsigned short* gradpl) {
+  if (gradpl) return gemm_pl(eng, 0, 2, gradpl, r.out, 0, 0, r.w3T, 0, nullptr, w.e128a, RH, 0, 0, ne, RH, r.out, 1.0f);
+  return gemm_plain(eng, grad, r.out, 0, r.w3T, r.out, nullptr, w.e128a, RH, 0, ne, RH, r.out);
+}
+int radial_bwd_tail(umx_engine* eng, const WS& w, const RadialW& r, int slot, long ne) {
   hipStream_t s = eng->stream;
-  if (gradpl) CHK(gemm_pl(eng, 0, 2, gradpl, r.out, 0, 0, r.w3T, 0, nullptr, w.e128a, RH, 0, 0, ne, RH, r.out, 1.0f));
-  else CHK(gemm_plain(eng, grad, r.out, 0, r.w3T, r.out, nullptr, w.e128a, RH, 0, ne, RH, r.out));
-  hipLaunchKernelGGL(k_ln_silu_bwd, dim3(nblk(ne, 4)), dim3(256), 0, s, w.e128a, w.h2pre[slot], r.ln2w, r.ln2b, w.e128b, ne);
+  hipLaunchKernelGGL(k_ln_silu_bwd, dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.e128a, w.h2pre[slot], r.ln2w, r.ln2b, w.e128b, ne);
   CHK(gemm_plain(eng, w.e128b, RH, 0, r.w2T, RH, nullptr, w.e128a, RH, 0, ne, RH, RH));
-  hipLaunchKernelGGL(k_ln_silu_bwd, dim3(nblk(ne, 4)), dim3(256), 0, s, w.e128a, w.h1pre[slot], r.ln1w, r.ln1b, w.e128b, ne);
+  hipLaunchKernelGGL(k_ln_silu_bwd, dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.e128a, w.h1pre[slot], r.ln1w, r.ln1b, w.e128b, ne);
   CHK(gemm_plain(eng, w.e128b, RH, 0, r.w1gT, RH, nullptr, w.ggauss, NG, 0, ne, NG, RH));
-  hipLaunchKernelGGL(k_radial_dd, dim3(nblk(ne, 4)), dim3(256), 0, s, w.ggauss, w.evec, eng->gcoef, eng->d_gmu, w.dedd, ne);
+  hipLaunchKernelGGL(k_radial_dd, dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.ggauss, w.evec, eng->gcoef, eng->d_gmu, w.dedd, ne);
   HIPCHK(eng, hipGetLastError());
   return UMX_OK;
+}
+int radial_bwd(umx_engine* eng, const WS& w, const RadialW& r, int slot, long ne, const float* grad, const unsigned short* gradpl = nullptr) {
+  CHK(radial_bwd_fc3(eng, w, r, ne, grad, gradpl));
+  return radial_bwd_tail(eng, w, r, slot, ne);
 }
 
 // SO(3) linear on l-primary node rows: per degree l one GEMM with gridDim.z = 2l+1
@@ -368,177 +391,310 @@ int so3_linear(umx_engine* eng, const float* A, const float* Wl, const float* bi
 }
 
 // ---- one chunk: nn nodes (= images * natoms), edges counted on the fly --------------------------
-int run_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, const int* d_cand, long nimg, long ne, double* d_energy, float* d_forces) {
-  hipStream_t s = eng->stream;
+// The chunk's launch sequence is recorded as a PLAN of segments instead of being issued directly.  A segment is either
+// "matrix" (a group of the large split-bf16 GEMMs: MFMA-bound, one LDS-filling workgroup per CU) or "stream" (everything
+// else: the HBM-bound gather / rotate / gate / reduce kernels and the small fp32 GEMMs).  With one lane the executor simply
+// issues the segments in order.  With two lanes (UMX_STREAMS=2) it issues the plans of two chunks alternately and hands a
+// TOKEN from matrix segment to matrix segment across the lanes (events), so that at any time at most one lane occupies the
+// matrix pipe while the other lane's stream segments run beside it on the same CUs -- the two bounds (MFMA and HBM)
+// overlap instead of adding up.
+struct Seg { bool matrix; std::function<int()> fn; };
+struct Plan {
+  std::vector<Seg> segs;
+  void stream(std::function<int()> f) { segs.push_back({false, std::move(f)}); }
+  void matrix(std::function<int()> f) { segs.push_back({true, std::move(f)}); }
+};
+
+void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, const int* d_cand, long nimg, long ne, double* d_energy,
+                float* d_forces, Plan& P) {
   const int N = eng->natoms;
   const long nn = nimg * N;
   const float rc2 = eng->cutoff * eng->cutoff;
   const dim3 B256(256);
-  // K1 graph
-  hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, d_deg, nn, w.row_ptr, w.stats);
-  hipLaunchKernelGGL(k_graph_fill, dim3(nblk(nn, 4)), B256, 0, s, d_pos, N, nn, rc2, eng->max_neigh, d_cand, w.row_ptr, w.esrc, w.edst, w.evec);
-  HIPCHK(eng, hipMemsetAsync(w.out_cur, 0, (nn + 1) * sizeof(int), s));
-  if (ne > 0) hipLaunchKernelGGL(k_out_count, dim3(nblk(ne, 256)), B256, 0, s, w.esrc, ne, w.out_cur);
-  hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, w.out_cur, nn, w.out_ptr, w.stats + 2);
-  HIPCHK(eng, hipMemsetAsync(w.out_cur, 0, (nn + 1) * sizeof(int), s));
-  if (ne > 0) {
-    hipLaunchKernelGGL(k_out_fill, dim3(nblk(ne, 256)), B256, 0, s, w.esrc, ne, w.out_ptr, w.out_cur, w.out_edge);
-    hipLaunchKernelGGL(k_out_sort, dim3(nblk(nn, 4)), B256, 0, s, w.out_ptr, nn, w.out_edge);
-    hipLaunchKernelGGL(k_edge_geom, dim3(nblk(ne, 256)), B256, 0, s, w.evec, ne, eng->cutoff, w.frame);
-    hipLaunchKernelGGL(k_edge_z, dim3(nblk(ne, 256)), B256, 0, s, w.esrc, w.edst, eng->d_z, N, w.ez, ne);
-  }
-  HIPCHK(eng, hipGetLastError());
-  DBG("row_ptr", w.row_ptr, nn + 1); DBG("src", w.esrc, ne); DBG("dst", w.edst, ne); DBG("out_ptr", w.out_ptr, nn + 1); DBG("out_edge", w.out_edge, ne);
-  DBG("evec", w.evec, ne * 4); DBG("frame", w.frame, ne * FRAME);
-  // K4 + K5
-  hipLaunchKernelGGL(k_node_init, dim3(nblk(nn * ROW, 256)), B256, 0, s, eng->d_z, N, nn, eng->emb_sphere, eng->d_sysemb, w.xs[0]);
-  if (ne > 0) CHK(radial_fwd(eng, w, eng->rdeg, NL, ne, w.rad_deg));
-  hipLaunchKernelGGL(k_rotate_back_reduce<3>, dim3(nblk(nn, 4)), B256, 0, s, w.rad_deg, w.frame, w.row_ptr, w.xs[0], w.xs[0], nn,
-                     1.0f / DEG_RESCALE);
-  HIPCHK(eng, hipGetLastError());
-  DBG("rad.deg", w.rad_deg, ne * 3 * C); DBG("x0", w.xs[0], nn * ROW);
+  const bool pl = eng->pl;
+  // every closure reads eng->stream when it RUNS (the executor points it at the lane's stream)
+  // K1 graph, K4 + K5
+  P.stream([=, &w]() -> int {
+    hipStream_t s = eng->stream;
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, d_deg, nn, w.row_ptr, w.stats);
+    hipLaunchKernelGGL(k_graph_fill, dim3(nblk(nn, 4)), B256, 0, s, d_pos, N, nn, rc2, eng->max_neigh, d_cand, w.row_ptr, w.esrc, w.edst, w.evec);
+    HIPCHK(eng, hipMemsetAsync(w.out_cur, 0, (nn + 1) * sizeof(int), s));
+    if (ne > 0) hipLaunchKernelGGL(k_out_count, dim3(nblk(ne, 256)), B256, 0, s, w.esrc, ne, w.out_cur);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, w.out_cur, nn, w.out_ptr, w.stats + 2);
+    HIPCHK(eng, hipMemsetAsync(w.out_cur, 0, (nn + 1) * sizeof(int), s));
+    if (ne > 0) {
+      hipLaunchKernelGGL(k_out_fill, dim3(nblk(ne, 256)), B256, 0, s, w.esrc, ne, w.out_ptr, w.out_cur, w.out_edge);
+      hipLaunchKernelGGL(k_out_sort, dim3(nblk(nn, 4)), B256, 0, s, w.out_ptr, nn, w.out_edge);
+      hipLaunchKernelGGL(k_edge_geom, dim3(nblk(ne, 256)), B256, 0, s, w.evec, ne, eng->cutoff, w.frame);
+      hipLaunchKernelGGL(k_edge_z, dim3(nblk(ne, 256)), B256, 0, s, w.esrc, w.edst, eng->d_z, N, w.ez, ne);
+    }
+    HIPCHK(eng, hipGetLastError());
+    DBG("row_ptr", w.row_ptr, nn + 1); DBG("src", w.esrc, ne); DBG("dst", w.edst, ne); DBG("out_ptr", w.out_ptr, nn + 1); DBG("out_edge", w.out_edge, ne);
+    DBG("evec", w.evec, ne * 4); DBG("frame", w.frame, ne * FRAME);
+    hipLaunchKernelGGL(k_node_init, dim3(nblk(nn * ROW, 256)), B256, 0, s, eng->d_z, N, nn, eng->emb_sphere, eng->d_sysemb, w.xs[0]);
+    if (ne > 0) CHK(radial_fwd(eng, w, eng->rdeg, NL, ne, w.rad_deg));
+    hipLaunchKernelGGL(k_rotate_back_reduce<3>, dim3(nblk(nn, 4)), B256, 0, s, w.rad_deg, w.frame, w.row_ptr, w.xs[0], w.xs[0], nn,
+                       1.0f / DEG_RESCALE);
+    HIPCHK(eng, hipGetLastError());
+    DBG("rad.deg", w.rad_deg, ne * 3 * C); DBG("x0", w.xs[0], nn * ROW);
+    return UMX_OK;
+  });
 
   for (int i = 0; i < NL; ++i) {
-    const LayerW& L = eng->lw[i];
-    const std::string t = "." + std::to_string(i);
+    const LayerW* Lp = &eng->lw[i];
     float* xin = w.xs[2 * i];
     float* xmid = w.xs[2 * i + 1];
     float* xout = w.xs[2 * i + 2];
-    hipLaunchKernelGGL(k_norm_fwd, dim3(nblk(nn, 4)), B256, 0, s, xin, L.n1w, L.n1b, eng->d_sysemb, w.xn[i], nn);
-    if (ne > 0 && eng->pl) {
-      CHK(radial_fwd(eng, w, L.rad, i, ne, w.rad[i]));
-      if (eng->q3) hipLaunchKernelGGL(k_gather_rotate_mod_q3, dim3((nblk(ne, 4) + 7) / 8 * 8), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne);
-      else hipLaunchKernelGGL((k_gather_rotate_mod_pl<3, false>), dim3((nblk(ne, 4) + 7) / 8 * 8), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne);
+    if (ne > 0 && pl) {
+      P.stream([=, &w]() -> int {
+        hipStream_t s = eng->stream;
+        hipLaunchKernelGGL(k_norm_fwd, dim3(nblk(nn, 4)), B256, 0, s, xin, Lp->n1w, Lp->n1b, eng->d_sysemb, w.xn[i], nn);
+        return radial_fwd_head(eng, w, Lp->rad, i, ne);
+      });
+      P.matrix([=, &w]() -> int { return radial_fwd_fc3(eng, w, Lp->rad, ne, w.rad[i]); });
+      P.stream([=, &w]() -> int {
+        hipStream_t s = eng->stream;
+        if (eng->q3) hipLaunchKernelGGL(k_gather_rotate_mod_q3, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne);
+        else hipLaunchKernelGGL((k_gather_rotate_mod_pl<3, false>), dim3((nblk(ne, 4) + 7) / 8 * 8), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne);
+        HIPCHK(eng, hipGetLastError());
+        return UMX_OK;
+      });
       // SO(2) conv 1 on the pre-modulated planes -> hg = [gate | hpre]
-      CHK(gemm_pl(eng, 0, 3, w.y1pl, XROT, 0, 0, L.c1m0, 0, L.c1m0b, w.hg[i], HG, 0, 0, ne, 640, 768, 1.0f));
-      CHK(gemm_pl(eng, 1, 3, w.y1pl, XROT, 768, 1280, L.c1m1, 256, nullptr, w.hg[i], HG, 640, 896, ne, 256, 512, 1.0f));
-      CHK(gemm_pl(eng, 1, 3, w.y1pl, XROT, 1792, 2048, L.c1m2, 128, nullptr, w.hg[i], HG, 1152, 1280, ne, 128, 256, 1.0f));
-      if (eng->q3) hipLaunchKernelGGL(k_gate_edge_fwd_q3, dim3(nblk(ne, 8)), B256, 0, s, w.hg[i], w.hidpl, ne);
-      else hipLaunchKernelGGL((k_gate_edge_fwd_pl<3, false>), dim3(nblk(ne * (H / 4), 256)), B256, 0, s, w.hg[i], w.hidpl, ne);
-      CHK(gemm_pl(eng, 0, 3, w.hidpl, ROW, 0, 0, L.c2m0, 0, L.c2m0b, w.msg[i], ROW, 0, 0, ne, 384, 384, 1.0f));
-      CHK(gemm_pl(eng, 1, 3, w.hidpl, ROW, 384, 640, L.c2m1, 256, nullptr, w.msg[i], ROW, 384, 640, ne, 256, 256, 1.0f));
-      CHK(gemm_pl(eng, 1, 3, w.hidpl, ROW, 896, 1024, L.c2m2, 128, nullptr, w.msg[i], ROW, 896, 1024, ne, 128, 128, 1.0f));
-    } else if (ne > 0) {
-      hipLaunchKernelGGL(k_gather_rotate, dim3(nblk(ne, 4)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.xrot, ne);
-      CHK(radial_fwd(eng, w, L.rad, i, ne, w.rad[i]));
-      // SO(2) conv 1 (radially modulated) -> hg = [gate | hpre]
-      {
-        GemmP p = gp_zero();
-        p.A = w.xrot; p.lda = XROT; p.R = w.rad[i]; p.ldr = RAD; p.B = L.c1m0; p.ldb = 3 * 2 * C; p.bias = L.c1m0b;
-        p.Cp = w.hg[i]; p.ldc = HG; p.M = (int)ne; p.N = 2 * H + 3 * H; p.K = 3 * 2 * C;
-        CHK(launch_gemm(eng, p, A_MODUL, 0, E_BIAS));
-      }
-      CHK(gemm_cplx(eng, w.xrot, XROT, 768, 1280, w.rad[i], RAD, 768, L.c1m1, 512, 256, w.hg[i], HG, 640, 896, ne, 256, 512, 1.0f));
-      CHK(gemm_cplx(eng, w.xrot, XROT, 1792, 2048, w.rad[i], RAD, 1280, L.c1m2, 256, 128, w.hg[i], HG, 1152, 1280, ne, 128, 256, 1.0f));
-      hipLaunchKernelGGL(k_gate_edge_fwd, dim3(nblk(ne * (H / 4), 256)), B256, 0, s, w.hg[i], w.hid, ne);
-      // SO(2) conv 2 -> msg
-      CHK(gemm_plain(eng, w.hid, ROW, 0, L.c2m0, 3 * H, L.c2m0b, w.msg[i], ROW, 0, ne, 3 * C, 3 * H));
-      CHK(gemm_cplx(eng, w.hid, ROW, 384, 640, nullptr, 0, 0, L.c2m1, 256, 256, w.msg[i], ROW, 384, 640, ne, 256, 256, 1.0f));
-      CHK(gemm_cplx(eng, w.hid, ROW, 896, 1024, nullptr, 0, 0, L.c2m2, 128, 128, w.msg[i], ROW, 896, 1024, ne, 128, 128, 1.0f));
+      P.matrix([=, &w]() -> int {
+        CHK(gemm_pl(eng, 0, 3, w.y1pl, XROT, 0, 0, Lp->c1m0, 0, Lp->c1m0b, w.hg[i], HG, 0, 0, ne, 640, 768, 1.0f));
+        CHK(gemm_pl(eng, 1, 3, w.y1pl, XROT, 768, 1280, Lp->c1m1, 256, nullptr, w.hg[i], HG, 640, 896, ne, 256, 512, 1.0f));
+        return gemm_pl(eng, 1, 3, w.y1pl, XROT, 1792, 2048, Lp->c1m2, 128, nullptr, w.hg[i], HG, 1152, 1280, ne, 128, 256, 1.0f);
+      });
+      P.stream([=, &w]() -> int {
+        hipStream_t s = eng->stream;
+        if (eng->q3) hipLaunchKernelGGL(k_gate_edge_fwd_q3, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hg[i], w.hidpl, ne);
+        else hipLaunchKernelGGL((k_gate_edge_fwd_pl<3, false>), dim3(nblk(ne * (H / 4), 256)), B256, 0, s, w.hg[i], w.hidpl, ne);
+        HIPCHK(eng, hipGetLastError());
+        return UMX_OK;
+      });
+      P.matrix([=, &w]() -> int {
+        CHK(gemm_pl(eng, 0, 3, w.hidpl, ROW, 0, 0, Lp->c2m0, 0, Lp->c2m0b, w.msg[i], ROW, 0, 0, ne, 384, 384, 1.0f));
+        CHK(gemm_pl(eng, 1, 3, w.hidpl, ROW, 384, 640, Lp->c2m1, 256, nullptr, w.msg[i], ROW, 384, 640, ne, 256, 256, 1.0f));
+        return gemm_pl(eng, 1, 3, w.hidpl, ROW, 896, 1024, Lp->c2m2, 128, nullptr, w.msg[i], ROW, 896, 1024, ne, 128, 128, 1.0f);
+      });
+    } else {
+      P.stream([=, &w]() -> int {
+        hipStream_t s = eng->stream;
+        const LayerW& L = *Lp;
+        hipLaunchKernelGGL(k_norm_fwd, dim3(nblk(nn, 4)), B256, 0, s, xin, L.n1w, L.n1b, eng->d_sysemb, w.xn[i], nn);
+        if (ne > 0) {
+          hipLaunchKernelGGL(k_gather_rotate, dim3(nblk(ne, 4)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.xrot, ne);
+          CHK(radial_fwd(eng, w, L.rad, i, ne, w.rad[i]));
+          // SO(2) conv 1 (radially modulated) -> hg = [gate | hpre]
+          {
+            GemmP p = gp_zero();
+            p.A = w.xrot; p.lda = XROT; p.R = w.rad[i]; p.ldr = RAD; p.B = L.c1m0; p.ldb = 3 * 2 * C; p.bias = L.c1m0b;
+            p.Cp = w.hg[i]; p.ldc = HG; p.M = (int)ne; p.N = 2 * H + 3 * H; p.K = 3 * 2 * C;
+            CHK(launch_gemm(eng, p, A_MODUL, 0, E_BIAS));
+          }
+          CHK(gemm_cplx(eng, w.xrot, XROT, 768, 1280, w.rad[i], RAD, 768, L.c1m1, 512, 256, w.hg[i], HG, 640, 896, ne, 256, 512, 1.0f));
+          CHK(gemm_cplx(eng, w.xrot, XROT, 1792, 2048, w.rad[i], RAD, 1280, L.c1m2, 256, 128, w.hg[i], HG, 1152, 1280, ne, 128, 256, 1.0f));
+          hipLaunchKernelGGL(k_gate_edge_fwd, dim3(nblk(ne * (H / 4), 256)), B256, 0, s, w.hg[i], w.hid, ne);
+          // SO(2) conv 2 -> msg
+          CHK(gemm_plain(eng, w.hid, ROW, 0, L.c2m0, 3 * H, L.c2m0b, w.msg[i], ROW, 0, ne, 3 * C, 3 * H));
+          CHK(gemm_cplx(eng, w.hid, ROW, 384, 640, nullptr, 0, 0, L.c2m1, 256, 256, w.msg[i], ROW, 384, 640, ne, 256, 256, 1.0f));
+          CHK(gemm_cplx(eng, w.hid, ROW, 896, 1024, nullptr, 0, 0, L.c2m2, 128, 128, w.msg[i], ROW, 896, 1024, ne, 128, 128, 1.0f));
+        }
+        HIPCHK(eng, hipGetLastError());
+        return UMX_OK;
+      });
     }
-    hipLaunchKernelGGL(k_rotate_back_reduce<9>, dim3(nblk(nn, 4)), B256, 0, s, w.msg[i], w.frame, w.row_ptr, xin, xmid, nn, 1.0f);
-    HIPCHK(eng, hipGetLastError());
-    DBG("xn" + t, w.xn[i], nn * ROW); DBG("rad" + t, w.rad[i], ne * RAD);
-    if (!eng->pl) { DBG("xrot" + t, w.xrot, ne * XROT); DBG("hid" + t, w.hid, ne * ROW); }
-    DBG("hg" + t, w.hg[i], ne * HG); DBG("msg" + t, w.msg[i], ne * ROW); DBG("xmid" + t, xmid, nn * ROW);
-    // K8 atom-wise
-    hipLaunchKernelGGL(k_norm_fwd, dim3(nblk(nn, 4)), B256, 0, s, xmid, L.n2w, L.n2b, (const float*)nullptr, w.xn2, nn);
-    CHK(gemm_plain(eng, w.xn2, ROW, 0, L.smlp, C, L.smlpb, w.gspre[i], 2 * H, 0, nn, 2 * H, C));
-    CHK(so3_linear(eng, w.xn2, L.l1w, L.l1b, w.ffh[i], nn, nullptr));
-    hipLaunchKernelGGL(k_gate_node_fwd, dim3(nblk(nn * H, 256)), B256, 0, s, w.ffh[i], w.gspre[i], w.ffhg, nn);
-    CHK(so3_linear(eng, w.ffhg, L.l2w, L.l2b, xout, nn, xmid));
-    HIPCHK(eng, hipGetLastError());
-    DBG("xn2" + t, w.xn2, nn * ROW); DBG("gspre" + t, w.gspre[i], nn * 2 * H); DBG("ffh" + t, w.ffh[i], nn * ROW); DBG("x" + t, xout, nn * ROW);
+    P.stream([=, &w]() -> int {
+      hipStream_t s = eng->stream;
+      const LayerW& L = *Lp;
+      const std::string t = "." + std::to_string(i);
+      hipLaunchKernelGGL(k_rotate_back_reduce<9>, dim3(vgrid(eng, nblk(nn, 4))), B256, 0, s, w.msg[i], w.frame, w.row_ptr, xin, xmid, nn, 1.0f);
+      HIPCHK(eng, hipGetLastError());
+      DBG("xn" + t, w.xn[i], nn * ROW); DBG("rad" + t, w.rad[i], ne * RAD);
+      if (!eng->pl) { DBG("xrot" + t, w.xrot, ne * XROT); DBG("hid" + t, w.hid, ne * ROW); }
+      DBG("hg" + t, w.hg[i], ne * HG); DBG("msg" + t, w.msg[i], ne * ROW); DBG("xmid" + t, xmid, nn * ROW);
+      // K8 atom-wise
+      hipLaunchKernelGGL(k_norm_fwd, dim3(nblk(nn, 4)), B256, 0, s, xmid, L.n2w, L.n2b, (const float*)nullptr, w.xn2, nn);
+      CHK(gemm_plain(eng, w.xn2, ROW, 0, L.smlp, C, L.smlpb, w.gspre[i], 2 * H, 0, nn, 2 * H, C));
+      CHK(so3_linear(eng, w.xn2, L.l1w, L.l1b, w.ffh[i], nn, nullptr));
+      hipLaunchKernelGGL(k_gate_node_fwd, dim3(nblk(nn * H, 256)), B256, 0, s, w.ffh[i], w.gspre[i], w.ffhg, nn);
+      CHK(so3_linear(eng, w.ffhg, L.l2w, L.l2b, xout, nn, xmid));
+      HIPCHK(eng, hipGetLastError());
+      DBG("xn2" + t, w.xn2, nn * ROW); DBG("gspre" + t, w.gspre[i], nn * 2 * H); DBG("ffh" + t, w.ffh[i], nn * ROW); DBG("x" + t, xout, nn * ROW);
+      return UMX_OK;
+    });
   }
-  // K9 readout
+  // K9 readout (+ the node-level head of the reverse pass)
   float* xlast = w.xs[2 * NL];
-  hipLaunchKernelGGL(k_norm_fwd, dim3(nblk(nn, 4)), B256, 0, s, xlast, eng->normw, eng->normb, (const float*)nullptr, w.xf, nn);
-  CHK(gemm_plain(eng, w.xf, ROW, 0, eng->e0, C, eng->e0b, w.pre1, H, 0, nn, H, C));
-  CHK(gemm_plain(eng, w.pre1, H, 0, eng->e2, H, eng->e2b, w.pre2, H, 0, nn, H, H, A_SILU));
-  hipLaunchKernelGGL(k_energy_node, dim3(nblk(nn, 4)), B256, 0, s, w.pre2, eng->e4, eng->e4b, w.enode, nn);
-  hipLaunchKernelGGL(k_energy, dim3((unsigned)nimg), B256, 0, s, w.enode, N, eng->rmsd, eng->refsum, d_energy);
-  HIPCHK(eng, hipGetLastError());
-  DBG("e_node", w.enode, nn); DBG("pre1", w.pre1, nn * H); DBG("pre2", w.pre2, nn * H);
-  if (!d_forces) return UMX_OK;
+  P.stream([=, &w]() -> int {
+    hipStream_t s = eng->stream;
+    hipLaunchKernelGGL(k_norm_fwd, dim3(nblk(nn, 4)), B256, 0, s, xlast, eng->normw, eng->normb, (const float*)nullptr, w.xf, nn);
+    CHK(gemm_plain(eng, w.xf, ROW, 0, eng->e0, C, eng->e0b, w.pre1, H, 0, nn, H, C));
+    CHK(gemm_plain(eng, w.pre1, H, 0, eng->e2, H, eng->e2b, w.pre2, H, 0, nn, H, H, A_SILU));
+    hipLaunchKernelGGL(k_energy_node, dim3(nblk(nn, 4)), B256, 0, s, w.pre2, eng->e4, eng->e4b, w.enode, nn);
+    hipLaunchKernelGGL(k_energy, dim3((unsigned)nimg), B256, 0, s, w.enode, N, eng->rmsd, eng->refsum, d_energy);
+    HIPCHK(eng, hipGetLastError());
+    DBG("e_node", w.enode, nn); DBG("pre1", w.pre1, nn * H); DBG("pre2", w.pre2, nn * H);
+    if (!d_forces) return UMX_OK;
+    // ---------------- K10: analytic reverse pass ----------------
+    if (ne > 0) {
+      HIPCHK(eng, hipMemsetAsync(w.dedd, 0, ne * sizeof(float), s));
+      HIPCHK(eng, hipMemsetAsync(w.tau, 0, ne * 4 * sizeof(float), s));
+      HIPCHK(eng, hipMemsetAsync(w.tau2, 0, ne * 4 * sizeof(float), s));
+    }
+    hipLaunchKernelGGL(k_silu_bwd, dim3(nblk(nn * H, 256)), B256, 0, s, eng->e4, 0L, w.pre2, w.n128a, nn, H);
+    CHK(gemm_plain(eng, w.n128a, H, 0, eng->e2T, H, nullptr, w.n128b, H, 0, nn, H, H));
+    hipLaunchKernelGGL(k_silu_bwd, dim3(nblk(nn * H, 256)), B256, 0, s, w.n128b, (long)H, w.pre1, w.n128a, nn, H);
+    HIPCHK(eng, hipMemsetAsync(w.G1, 0, nn * ROW * sizeof(float), s));
+    CHK(gemm_plain(eng, w.n128a, H, 0, eng->e0T, H, nullptr, w.G1, ROW, 0, nn, C, H));
+    hipLaunchKernelGGL(k_norm_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.G1, xlast, eng->normw, (const float*)nullptr, w.G0, nn);
+    HIPCHK(eng, hipGetLastError());
+    DBG("g_xfinal", w.G0, nn * ROW);
+    return UMX_OK;
+  });
+  if (!d_forces) return;
 
-  // ---------------- K10: analytic reverse pass ----------------
-  if (ne > 0) {
-    HIPCHK(eng, hipMemsetAsync(w.dedd, 0, ne * sizeof(float), s));
-    HIPCHK(eng, hipMemsetAsync(w.tau, 0, ne * 4 * sizeof(float), s));
-    HIPCHK(eng, hipMemsetAsync(w.tau2, 0, ne * 4 * sizeof(float), s));
-  }
-  hipLaunchKernelGGL(k_silu_bwd, dim3(nblk(nn * H, 256)), B256, 0, s, eng->e4, 0L, w.pre2, w.n128a, nn, H);
-  CHK(gemm_plain(eng, w.n128a, H, 0, eng->e2T, H, nullptr, w.n128b, H, 0, nn, H, H));
-  hipLaunchKernelGGL(k_silu_bwd, dim3(nblk(nn * H, 256)), B256, 0, s, w.n128b, (long)H, w.pre1, w.n128a, nn, H);
-  HIPCHK(eng, hipMemsetAsync(w.G1, 0, nn * ROW * sizeof(float), s));
-  CHK(gemm_plain(eng, w.n128a, H, 0, eng->e0T, H, nullptr, w.G1, ROW, 0, nn, C, H));
-  hipLaunchKernelGGL(k_norm_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.G1, xlast, eng->normw, (const float*)nullptr, w.G0, nn);
-  HIPCHK(eng, hipGetLastError());
-  DBG("g_xfinal", w.G0, nn * ROW);
   for (int i = NL - 1; i >= 0; --i) {
-    const LayerW& L = eng->lw[i];
-    const std::string t = "." + std::to_string(i);
+    const LayerW* Lp = &eng->lw[i];
     float* xin = w.xs[2 * i];
     float* xmid = w.xs[2 * i + 1];
-    // atom-wise backward: G0 = dE/dx_out
-    CHK(so3_linear(eng, w.G0, L.l2T, nullptr, w.G1, nn, nullptr));                         // G1 = g_ffhg
-    hipLaunchKernelGGL(k_gate_node_bwd, dim3(nblk(nn * H, 256)), B256, 0, s, w.G1, w.ffh[i], w.gspre[i], w.G2, w.ggs, nn);
-    CHK(so3_linear(eng, w.G2, L.l1T, nullptr, w.G1, nn, nullptr));                         // G1 = g_xn2
-    CHK(gemm_plain(eng, w.ggs, 2 * H, 0, L.smlpT, 2 * H, nullptr, w.G1, ROW, 0, nn, C, 2 * H, A_PLAIN, 1, 0, 0, w.G1, ROW, 0, 0));
-    hipLaunchKernelGGL(k_norm_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.G1, xmid, L.n2w, w.G0, w.G2, nn);   // G2 = g_xmid
-    HIPCHK(eng, hipGetLastError());
-    DBG("g_xmid" + t, w.G2, nn * ROW);
-    if (ne > 0 && eng->pl) {
-      hipLaunchKernelGGL(k_rotate_back_bwd_pl<2>, dim3((nblk(ne, 4) + 7) / 8 * 8), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne);
-      CHK(gemm_pl(eng, 0, 2, w.gmsgpl, ROW, 0, 0, L.c2m0T, 0, nullptr, w.hid, ROW, 0, 0, ne, 384, 384, 1.0f));
-      CHK(gemm_pl(eng, 1, 2, w.gmsgpl, ROW, 384, 640, L.c2m1T, 256, nullptr, w.hid, ROW, 384, 640, ne, 256, 256, -1.0f));
-      CHK(gemm_pl(eng, 1, 2, w.gmsgpl, ROW, 896, 1024, L.c2m2T, 128, nullptr, w.hid, ROW, 896, 1024, ne, 128, 128, -1.0f));
-      DBG("g_hid" + t, w.hid, ne * ROW);
-      hipLaunchKernelGGL(k_gate_edge_bwd_pl<2>, dim3(nblk(ne * (H / 4), 256)), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne);
-      CHK(gemm_pl(eng, 0, 2, w.ghgpl, HG, 0, 0, L.c1m0T, 0, nullptr, w.gy1, XROT, 0, 0, ne, 768, 640, 1.0f));
-      CHK(gemm_pl(eng, 1, 2, w.ghgpl, HG, 640, 896, L.c1m1T, 512, nullptr, w.gy1, XROT, 768, 1280, ne, 512, 256, -1.0f));
-      CHK(gemm_pl(eng, 1, 2, w.ghgpl, HG, 1152, 1280, L.c1m2T, 256, nullptr, w.gy1, XROT, 1792, 2048, ne, 256, 128, -1.0f));
-      if (eng->fuse_modrot) {       // one node-centric kernel: modulation backward + rotate-back + segmented sum (g_xrot stays in registers)
-        hipLaunchKernelGGL(k_modrot_bwd_pl<2>, dim3((unsigned)nn), B256, 0, s, w.gy1, w.xn[i], w.frame, w.rad[i], w.row_ptr, w.out_ptr, w.out_edge,
-                           w.gradpl, w.tau, w.tau2, w.G1, nn);
-      } else {
-        hipLaunchKernelGGL(k_modulate_bwd_pl<2>, dim3(nblk(ne, 4)), B256, 0, s, w.gy1, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.gradpl, w.tau, ne);
-        DBG("g_xrot" + t, w.gy1, ne * XROT);
-      }
-      CHK(radial_bwd(eng, w, L.rad, i, ne, nullptr, w.gradpl));
+    // atom-wise backward: G0 = dE/dx_out  (+ the first edge kernel of the layer)
+    P.stream([=, &w]() -> int {
+      hipStream_t s = eng->stream;
+      const LayerW& L = *Lp;
+      const std::string t = "." + std::to_string(i);
+      CHK(so3_linear(eng, w.G0, L.l2T, nullptr, w.G1, nn, nullptr));                         // G1 = g_ffhg
+      hipLaunchKernelGGL(k_gate_node_bwd, dim3(nblk(nn * H, 256)), B256, 0, s, w.G1, w.ffh[i], w.gspre[i], w.G2, w.ggs, nn);
+      CHK(so3_linear(eng, w.G2, L.l1T, nullptr, w.G1, nn, nullptr));                         // G1 = g_xn2
+      CHK(gemm_plain(eng, w.ggs, 2 * H, 0, L.smlpT, 2 * H, nullptr, w.G1, ROW, 0, nn, C, 2 * H, A_PLAIN, 1, 0, 0, w.G1, ROW, 0, 0));
+      hipLaunchKernelGGL(k_norm_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.G1, xmid, L.n2w, w.G0, w.G2, nn);   // G2 = g_xmid
+      HIPCHK(eng, hipGetLastError());
+      DBG("g_xmid" + t, w.G2, nn * ROW);
+      if (ne > 0 && eng->pl)
+        hipLaunchKernelGGL(k_rotate_back_bwd_pl<2>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne);
+      HIPCHK(eng, hipGetLastError());
+      return UMX_OK;
+    });
+    if (ne > 0 && pl) {
+      P.matrix([=, &w]() -> int {
+        CHK(gemm_pl(eng, 0, 2, w.gmsgpl, ROW, 0, 0, Lp->c2m0T, 0, nullptr, w.hid, ROW, 0, 0, ne, 384, 384, 1.0f));
+        CHK(gemm_pl(eng, 1, 2, w.gmsgpl, ROW, 384, 640, Lp->c2m1T, 256, nullptr, w.hid, ROW, 384, 640, ne, 256, 256, -1.0f));
+        return gemm_pl(eng, 1, 2, w.gmsgpl, ROW, 896, 1024, Lp->c2m2T, 128, nullptr, w.hid, ROW, 896, 1024, ne, 128, 128, -1.0f);
+      });
+      P.stream([=, &w]() -> int {
+        hipStream_t s = eng->stream;
+        DBG("g_hid." + std::to_string(i), w.hid, ne * ROW);
+        hipLaunchKernelGGL(k_gate_edge_bwd_pl<2>, dim3(vgrid(eng, nblk(ne * (H / 4), 256))), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne);
+        HIPCHK(eng, hipGetLastError());
+        return UMX_OK;
+      });
+      P.matrix([=, &w]() -> int {
+        CHK(gemm_pl(eng, 0, 2, w.ghgpl, HG, 0, 0, Lp->c1m0T, 0, nullptr, w.gy1, XROT, 0, 0, ne, 768, 640, 1.0f));
+        CHK(gemm_pl(eng, 1, 2, w.ghgpl, HG, 640, 896, Lp->c1m1T, 512, nullptr, w.gy1, XROT, 768, 1280, ne, 512, 256, -1.0f));
+        return gemm_pl(eng, 1, 2, w.ghgpl, HG, 1152, 1280, Lp->c1m2T, 256, nullptr, w.gy1, XROT, 1792, 2048, ne, 256, 128, -1.0f);
+      });
+      // (a matrix-token segment although it is HBM-bound: at 240 VGPRs its waves cannot share a SIMD with a GEMM wave, so beside
+      //  the other lane's GEMM it would only take CUs away from it; the other lane's throttled stream kernels do fit beside it)
+      P.matrix([=, &w]() -> int {
+        hipStream_t s = eng->stream;
+        if (eng->fuse_modrot) {       // one node-centric kernel: modulation backward + rotate-back + segmented sum (g_xrot stays in registers)
+          hipLaunchKernelGGL(k_modrot_bwd_pl<2>, dim3((unsigned)nn), B256, 0, s, w.gy1, w.xn[i], w.frame, w.rad[i], w.row_ptr, w.out_ptr, w.out_edge,
+                             w.gradpl, w.tau, w.tau2, w.G1, nn);
+        } else {
+          hipLaunchKernelGGL(k_modulate_bwd_pl<2>, dim3(nblk(ne, 4)), B256, 0, s, w.gy1, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.gradpl, w.tau, ne);
+          DBG("g_xrot." + std::to_string(i), w.gy1, ne * XROT);
+        }
+        HIPCHK(eng, hipGetLastError());
+        return UMX_OK;
+      });
+      P.matrix([=, &w]() -> int { return radial_bwd_fc3(eng, w, Lp->rad, ne, nullptr, w.gradpl); });
+      P.stream([=, &w]() -> int { return radial_bwd_tail(eng, w, Lp->rad, i, ne); });
     } else if (ne > 0) {
-      hipLaunchKernelGGL(k_rotate_back_bwd<9>, dim3(nblk(ne, 4)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsg, w.dedd, w.tau, ne, 1.0f);
-      CHK(gemm_plain(eng, w.gmsg, ROW, 0, L.c2m0T, 3 * C, nullptr, w.hid, ROW, 0, ne, 3 * H, 3 * C));
-      CHK(gemm_cplx(eng, w.gmsg, ROW, 384, 640, nullptr, 0, 0, L.c2m1T, 256, 256, w.hid, ROW, 384, 640, ne, 256, 256, -1.0f));
-      CHK(gemm_cplx(eng, w.gmsg, ROW, 896, 1024, nullptr, 0, 0, L.c2m2T, 128, 128, w.hid, ROW, 896, 1024, ne, 128, 128, -1.0f));
-      DBG("g_msg" + t, w.gmsg, ne * ROW); DBG("g_hid" + t, w.hid, ne * ROW);
-      hipLaunchKernelGGL(k_gate_edge_bwd, dim3(nblk(ne * H, 256)), B256, 0, s, w.hid, w.hg[i], w.ghg, ne);
-      CHK(gemm_plain(eng, w.ghg, HG, 0, L.c1m0T, 640, nullptr, w.gy1, XROT, 0, ne, 768, 640));
-      CHK(gemm_cplx(eng, w.ghg, HG, 640, 896, nullptr, 0, 0, L.c1m1T, 256, 512, w.gy1, XROT, 768, 1280, ne, 512, 256, -1.0f));
-      CHK(gemm_cplx(eng, w.ghg, HG, 1152, 1280, nullptr, 0, 0, L.c1m2T, 128, 256, w.gy1, XROT, 1792, 2048, ne, 256, 128, -1.0f));
-      DBG("g_hg" + t, w.ghg, ne * HG);
-      hipLaunchKernelGGL(k_gather_rotate, dim3(nblk(ne, 4)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.xrot, ne);
-      hipLaunchKernelGGL(k_modulate_bwd, dim3(nblk(ne, 4)), B256, 0, s, w.gy1, w.xrot, w.rad[i], w.grad, w.tau, ne);
-      DBG("g_xrot" + t, w.gy1, ne * XROT); DBG("g_rad" + t, w.grad, ne * RAD);
-      CHK(radial_bwd(eng, w, L.rad, i, ne, w.grad));
+      P.stream([=, &w]() -> int {
+        hipStream_t s = eng->stream;
+        const LayerW& L = *Lp;
+        const std::string t = "." + std::to_string(i);
+        hipLaunchKernelGGL(k_rotate_back_bwd<9>, dim3(nblk(ne, 4)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsg, w.dedd, w.tau, ne, 1.0f);
+        CHK(gemm_plain(eng, w.gmsg, ROW, 0, L.c2m0T, 3 * C, nullptr, w.hid, ROW, 0, ne, 3 * H, 3 * C));
+        CHK(gemm_cplx(eng, w.gmsg, ROW, 384, 640, nullptr, 0, 0, L.c2m1T, 256, 256, w.hid, ROW, 384, 640, ne, 256, 256, -1.0f));
+        CHK(gemm_cplx(eng, w.gmsg, ROW, 896, 1024, nullptr, 0, 0, L.c2m2T, 128, 128, w.hid, ROW, 896, 1024, ne, 128, 128, -1.0f));
+        DBG("g_msg" + t, w.gmsg, ne * ROW); DBG("g_hid" + t, w.hid, ne * ROW);
+        hipLaunchKernelGGL(k_gate_edge_bwd, dim3(nblk(ne * H, 256)), B256, 0, s, w.hid, w.hg[i], w.ghg, ne);
+        CHK(gemm_plain(eng, w.ghg, HG, 0, L.c1m0T, 640, nullptr, w.gy1, XROT, 0, ne, 768, 640));
+        CHK(gemm_cplx(eng, w.ghg, HG, 640, 896, nullptr, 0, 0, L.c1m1T, 256, 512, w.gy1, XROT, 768, 1280, ne, 512, 256, -1.0f));
+        CHK(gemm_cplx(eng, w.ghg, HG, 1152, 1280, nullptr, 0, 0, L.c1m2T, 128, 256, w.gy1, XROT, 1792, 2048, ne, 256, 128, -1.0f));
+        DBG("g_hg" + t, w.ghg, ne * HG);
+        hipLaunchKernelGGL(k_gather_rotate, dim3(nblk(ne, 4)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.xrot, ne);
+        hipLaunchKernelGGL(k_modulate_bwd, dim3(nblk(ne, 4)), B256, 0, s, w.gy1, w.xrot, w.rad[i], w.grad, w.tau, ne);
+        DBG("g_xrot" + t, w.gy1, ne * XROT); DBG("g_rad" + t, w.grad, ne * RAD);
+        return radial_bwd(eng, w, L.rad, i, ne, w.grad);
+      });
     }
-    if (!(ne > 0 && eng->pl && eng->fuse_modrot))
-      hipLaunchKernelGGL(k_gather_rotate_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.gy1, w.frame, w.row_ptr, w.out_ptr, w.out_edge, w.G1, nn);   // G1 = g_xn
-    hipLaunchKernelGGL(k_norm_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.G1, xin, L.n1w, w.G2, w.G0, nn);                      // G0 = g_xin
+    P.stream([=, &w]() -> int {
+      hipStream_t s = eng->stream;
+      const std::string t = "." + std::to_string(i);
+      if (!(ne > 0 && eng->pl && eng->fuse_modrot))
+        hipLaunchKernelGGL(k_gather_rotate_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.gy1, w.frame, w.row_ptr, w.out_ptr, w.out_edge, w.G1, nn);   // G1 = g_xn
+      hipLaunchKernelGGL(k_norm_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.G1, xin, Lp->n1w, w.G2, w.G0, nn);                      // G0 = g_xin
+      HIPCHK(eng, hipGetLastError());
+      DBG("g_xn" + t, w.G1, nn * ROW); DBG("g_xin" + t, w.G0, nn * ROW);
+      return UMX_OK;
+    });
+  }
+  P.stream([=, &w]() -> int {
+    hipStream_t s = eng->stream;
+    if (ne > 0) {
+      hipLaunchKernelGGL(k_rotate_back_bwd<3>, dim3(nblk(ne, 4)), B256, 0, s, w.G0, w.rad_deg, w.frame, w.edst, w.gmsg, w.dedd, w.tau, ne,
+                         1.0f / DEG_RESCALE);
+      CHK(radial_bwd(eng, w, eng->rdeg, NL, ne, w.gmsg));
+      if (eng->pl && eng->fuse_modrot) hipLaunchKernelGGL(k_add4, dim3(nblk(ne, 256)), B256, 0, s, w.tau, w.tau2, ne);
+      hipLaunchKernelGGL(k_force_edge, dim3(nblk(ne, 256)), B256, 0, s, w.dedd, w.tau, w.frame, w.evec, w.gvec, ne);
+    }
+    hipLaunchKernelGGL(k_force_node, dim3(nblk(nn, 4)), B256, 0, s, w.gvec, w.row_ptr, w.out_ptr, w.out_edge, (float)eng->rmsd, d_forces, nn);
     HIPCHK(eng, hipGetLastError());
-    DBG("g_xn" + t, w.G1, nn * ROW); DBG("g_xin" + t, w.G0, nn * ROW);
-  }
-  if (ne > 0) {
-    hipLaunchKernelGGL(k_rotate_back_bwd<3>, dim3(nblk(ne, 4)), B256, 0, s, w.G0, w.rad_deg, w.frame, w.edst, w.gmsg, w.dedd, w.tau, ne,
-                       1.0f / DEG_RESCALE);
-    CHK(radial_bwd(eng, w, eng->rdeg, NL, ne, w.gmsg));
-    if (eng->pl && eng->fuse_modrot) hipLaunchKernelGGL(k_add4, dim3(nblk(ne, 256)), B256, 0, s, w.tau, w.tau2, ne);
-    hipLaunchKernelGGL(k_force_edge, dim3(nblk(ne, 256)), B256, 0, s, w.dedd, w.tau, w.frame, w.evec, w.gvec, ne);
-  }
-  hipLaunchKernelGGL(k_force_node, dim3(nblk(nn, 4)), B256, 0, s, w.gvec, w.row_ptr, w.out_ptr, w.out_edge, (float)eng->rmsd, d_forces, nn);
-  HIPCHK(eng, hipGetLastError());
-  DBG("dedd", w.dedd, ne); DBG("tau", w.tau, ne * 4); DBG("gvec", w.gvec, ne * 4);
+    DBG("dedd", w.dedd, ne); DBG("tau", w.tau, ne * 4); DBG("gvec", w.gvec, ne * 4);
+    return UMX_OK;
+  });
+}
+
+// Issue one plan on the stream eng->stream points at.
+int run_plan(umx_engine* eng, Plan& P) {
+  for (auto& sg : P.segs) CHK(sg.fn());
   return UMX_OK;
+}
+
+// Issue two plans on two streams, alternating between the lanes after every matrix segment and passing the matrix token:
+// lane L's matrix segment waits (on the device) for the other lane's most recent matrix segment to finish and nothing else,
+// so the other lane's stream segments run beside it.  Host-side issue order == token order, which is what makes the
+// hipStreamWaitEvent calls see an already-recorded event.
+int run_plans_alternating(umx_engine* eng, Plan (&P)[2], hipStream_t (&st)[2], hipEvent_t (&tok)[2]) {
+  size_t at[2] = {0, 0};
+  bool recorded[2] = {false, false};
+  hipStream_t keep = eng->stream;
+  int stt = UMX_OK;
+  while (stt == UMX_OK && (at[0] < P[0].segs.size() || at[1] < P[1].segs.size())) {
+    for (int l = 0; l < 2 && stt == UMX_OK; ++l) {
+      eng->stream = st[l];
+      // stream segments up to and including the next matrix segment of this lane
+      while (at[l] < P[l].segs.size()) {
+        Seg& sg = P[l].segs[at[l]++];
+        if (sg.matrix && recorded[1 - l]) {
+          hipError_t e = hipStreamWaitEvent(st[l], tok[1 - l], 0);
+          if (e != hipSuccess) { stt = fail(eng, UMX_ERR_HIP, std::string("token wait: ") + hipGetErrorName(e)); break; }
+        }
+        stt = sg.fn();
+        if (stt != UMX_OK) break;
+        if (sg.matrix) {
+          hipError_t e = hipEventRecord(tok[l], st[l]);
+          if (e != hipSuccess) { stt = fail(eng, UMX_ERR_HIP, std::string("token record: ") + hipGetErrorName(e)); break; }
+          recorded[l] = true;
+          break;
+        }
+      }
+    }
+  }
+  eng->stream = keep;
+  return stt;
 }
 
 // per-image edge totals from the per-node degrees
@@ -601,9 +757,12 @@ int umx_create(umx_engine** out, int device_ordinal) {
   if (const char* ev = std::getenv("UMX_Q3WIDE")) e->q3_wide = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_FUSE_MODROT")) e->fuse_modrot = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_STREAMS")) e->n_lanes = std::atoi(ev) >= 2 ? 2 : 1;
+  e->stream_cap = 512;
+  if (const char* ev = std::getenv("UMX_STREAM_BLOCKS")) e->stream_cap = std::max(0, std::atoi(ev)) / 8 * 8;
   if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_tok[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_tok[1], hipEventDisableTiming) != hipSuccess) {
     g_create_err = "umx_create: hipSetDevice/hipStreamCreate failed";
     delete e;
     return UMX_ERR_HIP;
@@ -621,6 +780,7 @@ int umx_destroy(umx_engine* eng) {
   for (void* p : ptrs) if (p) (void)hipFree(p);
   (void)hipStreamSynchronize(eng->stream2);
   (void)hipEventDestroy(eng->ev_fork); (void)hipEventDestroy(eng->ev_join);
+  (void)hipEventDestroy(eng->ev_tok[0]); (void)hipEventDestroy(eng->ev_tok[1]);
   (void)hipStreamDestroy(eng->stream2);
   (void)hipStreamDestroy(eng->stream);
   delete eng;
@@ -968,26 +1128,36 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
     HIPCHK(eng, hipMemGetInfo(&fr, &tot));
     budget = (size_t)((fr + eng->arena_bytes) * 0.85);
   }
-  int lanes = (eng->n_lanes >= 2 && K >= 2) ? 2 : 1;
+  int lanes = (eng->n_lanes >= 2 && K >= 2 && !eng->dbg_on) ? 2 : 1;      // debug captures name ONE chunk's buffers
   budget /= lanes;
   long max_chunk = (K + lanes - 1) / lanes;          // at least `lanes` chunks so both streams have work
   if (const char* ev = std::getenv("UMX_MAX_CHUNK_IMAGES")) { long v = std::atol(ev); if (v > 0) max_chunk = std::min(max_chunk, v); }
   std::vector<std::pair<long, long>> chunks;   // [k0, k1)
   long need_nodes = 0, need_edges = 0;
-  for (long k0 = 0; k0 < K;) {
-    long k1 = k0, e = 0;
-    while (k1 < K && (k1 - k0) < max_chunk) {
-      const long e2 = e + img_edges[k1];
-      if (k1 > k0 && carve(nullptr, (k1 - k0 + 1) * N, e2, nullptr, eng->pl) > budget) break;
-      e = e2; ++k1;
+  auto plan = [&](long cap) -> int {
+    chunks.clear(); need_nodes = 0; need_edges = 0;
+    for (long k0 = 0; k0 < K;) {
+      long k1 = k0, e = 0;
+      while (k1 < K && (k1 - k0) < cap) {
+        const long e2 = e + img_edges[k1];
+        if (k1 > k0 && carve(nullptr, (k1 - k0 + 1) * N, e2, nullptr, eng->pl) > budget) break;
+        e = e2; ++k1;
+      }
+      if (carve(nullptr, (k1 - k0) * N, e, nullptr, eng->pl) > budget)
+        return fail(eng, UMX_ERR_CAPACITY, "one image needs " + std::to_string(carve(nullptr, N, e, nullptr, eng->pl) >> 20) + " MiB of workspace, budget is " +
+                                               std::to_string(budget >> 20) + " MiB");
+      chunks.push_back({k0, k1});
+      need_nodes = std::max(need_nodes, (k1 - k0) * N);
+      need_edges = std::max(need_edges, e);
+      k0 = k1;
     }
-    if (carve(nullptr, (k1 - k0) * N, e, nullptr, eng->pl) > budget)
-      return fail(eng, UMX_ERR_CAPACITY, "one image needs " + std::to_string(carve(nullptr, N, e, nullptr, eng->pl) >> 20) + " MiB of workspace, budget is " +
-                                             std::to_string(budget >> 20) + " MiB");
-    chunks.push_back({k0, k1});
-    need_nodes = std::max(need_nodes, (k1 - k0) * N);
-    need_edges = std::max(need_edges, e);
-    k0 = k1;
+    return UMX_OK;
+  };
+  CHK(plan(max_chunk));
+  if (lanes == 2 && chunks.size() > 1) {
+    // the lanes work in pairs of chunks: an even number of chunks of (nearly) equal size, so that no chunk runs without a partner
+    const long n_even = (long)((chunks.size() + 1) / 2 * 2);
+    CHK(plan((K + n_even - 1) / n_even));
   }
   if (need_nodes > eng->cap_nodes || need_edges > eng->cap_edges) {
     HIPCHK(eng, hipStreamSynchronize(s));
@@ -1010,18 +1180,38 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
     HIPCHK(eng, hipStreamWaitEvent(eng->stream2, eng->ev_fork, 0));
   }
   int st = UMX_OK;
-  size_t ci = 0;
-  for (auto& ch : chunks) {
-    const long k0 = ch.first, k1 = ch.second;
+  auto plan_of = [&](size_t ci, int lane, Plan& P) {
+    const long k0 = chunks[ci].first, k1 = chunks[ci].second;
     long e = 0;
     for (long k = k0; k < k1; ++k) e += img_edges[k];
-    const int lane = (lanes == 2) ? (int)(ci & 1) : 0;
-    eng->stream = lane ? eng->stream2 : s;
-    st = run_chunk(eng, wl[lane], d_pos + k0 * N * 3, eng->d_deg_all + k0 * N, eng->d_cand_all + k0 * N, k1 - k0, e, d_energy + k0, d_forces ? d_forces + k0 * N * 3 : nullptr);
-    eng->stream = s;
-    if (st != UMX_OK) break;
-    ++ci;
+    plan_chunk(eng, wl[lane], d_pos + k0 * N * 3, eng->d_deg_all + k0 * N, eng->d_cand_all + k0 * N, k1 - k0, e, d_energy + k0,
+               d_forces ? d_forces + k0 * N * 3 : nullptr, P);
+  };
+  if (lanes == 2) {          // chunks in pairs, one per lane, matrix segments alternating between the lanes (run_plans_alternating)
+    hipStream_t sts[2] = {s, eng->stream2};
+    hipEvent_t tok[2] = {eng->ev_tok[0], eng->ev_tok[1]};
+    for (size_t ci = 0; ci < chunks.size() && st == UMX_OK; ci += 2) {
+      Plan P[2];
+      plan_of(ci, 0, P[0]);
+      if (ci + 1 < chunks.size()) {
+        plan_of(ci + 1, 1, P[1]);
+        eng->throttle = true;
+        st = run_plans_alternating(eng, P, sts, tok);
+        eng->throttle = false;
+      } else {
+        eng->stream = s;
+        st = run_plan(eng, P[0]);
+      }
+    }
+  } else {
+    for (size_t ci = 0; ci < chunks.size() && st == UMX_OK; ++ci) {
+      Plan P;
+      plan_of(ci, 0, P);
+      eng->stream = s;
+      st = run_plan(eng, P);
+    }
   }
+  eng->stream = s;
   if (lanes == 2) {          // join: the primary stream continues only after lane 1 has drained
     HIPCHK(eng, hipEventRecord(eng->ev_join, eng->stream2));
     HIPCHK(eng, hipStreamWaitEvent(s, eng->ev_join, 0));

@@ -36,6 +36,15 @@ __device__ __forceinline__ float silu_grad_f(float x) {
   return s * (1.0f + x * (1.0f - s));
 }
 
+// Grid-stride forms ("virtual blocks"): the kernel body is the loop body, so ANY grid size does the same work in the same per-item
+// arithmetic order.  Launched with the full grid it is one iteration per wave (as UMX_WAVE_ITEM); launched with a capped grid
+// (engine "throttled" mode: a few resident workgroups per CU) the kernel leaves room on every CU for the other lane's GEMM
+// workgroups instead of flooding the chip (two-lane execution).   Usage:  UMX_WAVE_LOOP(idx, count) { body }
+#define UMX_WAVE_LOOP(idx, count)                                                     \
+  const int lane = threadIdx.x & 63;                                                  \
+  for (long _it = (long)blockIdx.x * 4 + (threadIdx.x >> 6); _it < (count); _it += (long)gridDim.x * 4) \
+    if (const long idx = __builtin_amdgcn_readfirstlane((int)_it); true)
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd(const float* __restrict__ gy, 
 // LayerNorm(128) + SiLU on rows of the radial MLP
 __global__ __launch_bounds__(256) void k_ln_silu_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ b, float* __restrict__ y, long rows) {
-  UMX_WAVE_ITEM(row, rows)
+  UMX_WAVE_LOOP(row, rows) {
   const int c0 = lane * 2;
   float2 v = *reinterpret_cast<const float2*>(x + row * RH + c0);
   const float mu = wave_sum(v.x + v.y) * (1.0f / RH);
@@ -309,12 +309,13 @@ __global__ __launch_bounds__(256) void k_ln_silu_fwd(const float* __restrict__ x
   const float2 ww = *reinterpret_cast<const float2*>(w + c0), bb = *reinterpret_cast<const float2*>(b + c0);
   *reinterpret_cast<float2*>(y + row * RH + c0) =
       make_float2(silu_f(v.x * rstd * ww.x + bb.x), silu_f(v.y * rstd * ww.y + bb.y));
+  }
 }
 
 __global__ __launch_bounds__(256) void k_ln_silu_bwd(const float* __restrict__ gout, const float* __restrict__ x,
                                                      const float* __restrict__ w, const float* __restrict__ b,
                                                      float* __restrict__ gx, long rows) {
-  UMX_WAVE_ITEM(row, rows)
+  UMX_WAVE_LOOP(row, rows) {
   const int c0 = lane * 2;
   float2 v = *reinterpret_cast<const float2*>(x + row * RH + c0);
   const float2 go = *reinterpret_cast<const float2*>(gout + row * RH + c0);
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(256) void k_ln_silu_bwd(const float* __restrict__ g
   const float m2 = wave_sum(gw0 * xh0 + gw1 * xh1) * (1.0f / RH);
   *reinterpret_cast<float2*>(gx + row * RH + c0) =
       make_float2(rstd * (gw0 - m1 - xh0 * m2), rstd * (gw1 - m1 - xh1 * m2));
+  }
 }
 
 // atom-wise gate (l-primary rows): row 0 SiLU, rows of degree l>0 * sigmoid(silu(gs_pre[l-1]))
@@ -490,7 +492,7 @@ template <int NROWS>
 __global__ __launch_bounds__(256) void k_rotate_back_reduce(const float* __restrict__ msg, const float* __restrict__ frame,
                                                             const int* __restrict__ row_ptr, const float* xin,
                                                             float* xout, long nt, float scale) {
-  UMX_WAVE_ITEM(node, nt)
+  UMX_WAVE_LOOP(node, nt) {
   const int c0 = lane * 2;
   float ax[9], ay[9];
 #pragma unroll
@@ -513,6 +515,7 @@ __global__ __launch_bounds__(256) void k_rotate_back_reduce(const float* __restr
   for (int r = 0; r < 9; ++r) {
     const float2 b = *reinterpret_cast<const float2*>(xin + node * ROW + r * C + c0);
     *reinterpret_cast<float2*>(xout + node * ROW + r * C + c0) = make_float2(b.x + ax[r], b.y + ay[r]);
+  }
   }
 }
 
@@ -634,12 +637,13 @@ __global__ __launch_bounds__(256) void k_gather_rotate_bwd(const float* __restri
 // dE/dd through the gaussian basis: dedd[e] += sum_k ggauss[e][k] * d/dd exp(gcoef (d - mu_k)^2)
 __global__ __launch_bounds__(256) void k_radial_dd(const float* __restrict__ ggauss, const float* __restrict__ evec,
                                                    float gcoef, const float* __restrict__ gmu, float* __restrict__ dedd, long ne) {
-  UMX_WAVE_ITEM(e, ne)
+  UMX_WAVE_LOOP(e, ne) {
   const float d = evec[e * 4 + 3];
   const float t = d - gmu[lane];
   float v = ggauss[e * NG + lane] * exp_f(gcoef * t * t) * 2.0f * gcoef * t;
   v = wave_sum(v);
   if (lane == 0) dedd[e] += v;
+  }
 }
 
 // dE/dvec per edge from dE/dd and the torque (frame detached at the +y pole, as the reference does)

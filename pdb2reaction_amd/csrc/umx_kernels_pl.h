@@ -77,11 +77,21 @@ __device__ __forceinline__ void q3_store4(unsigned short* base, long row, int co
   const long idx = __builtin_amdgcn_readfirstlane((int)(_blk * 4 + (threadIdx.x >> 6))); \
   if (idx >= (count)) return;
 
+// grid-stride forms of the two macros above (see UMX_WAVE_LOOP in umx_kernels.h): body = loop body, any grid size.  The XCD form
+// keeps the contiguous-range-per-XCD mapping in terms of VIRTUAL blocks: virtual block v = blockIdx.x + k * gridDim.x has
+// v & 7 == blockIdx.x & 7 (gridDim.x is a multiple of 8), so a physical workgroup only ever works for its own XCD's range.
+#define UMX_WAVE_LOOP_PL_XCD(idx, count)                                              \
+  const int lane = threadIdx.x & 63;                                                  \
+  const long _nvb = ((((count) + 3) / 4 + 7) / 8) * 8;                                \
+  const long _per = _nvb >> 3;                                                        \
+  for (long _vb = blockIdx.x; _vb < _nvb; _vb += gridDim.x)                           \
+    if (const long idx = __builtin_amdgcn_readfirstlane((int)(((_vb & 7) * _per + (_vb >> 3)) * 4 + (threadIdx.x >> 6))); idx < (count))
+
 // LayerNorm(128)+SiLU of the radial MLP, output as PL planes (A operand of the fc3 GEMM)
 template <int P, bool Q = false>
 __global__ __launch_bounds__(256) void k_ln_silu_fwd_pl(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, unsigned short* __restrict__ y, long rows) {
-  UMX_WAVE_ITEM_PL(row, rows)
+  UMX_WAVE_LOOP(row, rows) {
   const int c0 = lane * 2;
   float2 v = *reinterpret_cast<const float2*>(x + row * RH + c0);
   const float mu = wave_sum(v.x + v.y) * (1.0f / RH);
@@ -92,6 +102,7 @@ __global__ __launch_bounds__(256) void k_ln_silu_fwd_pl(const float* __restrict_
   const float o0 = silu_f(v.x * rstd * ww.x + bb.x), o1 = silu_f(v.y * rstd * ww.y + bb.y);
   if (Q) q3_store2(y, row, RH, c0, o0, o1);
   else pl_store2<P>(y + row * (RH * P), c0, o0, o1);
+  }
 }
 
 // K7a fused: y1[e] = (W_e [xn[src] | xn[dst]]) .* rad[e]  as PL planes (9 m-primary rows x 256 columns)
@@ -139,10 +150,13 @@ __global__ __launch_bounds__(256) void k_gather_rotate_mod_q3(const float* __res
                                                               const float* __restrict__ rad, unsigned short* __restrict__ y1, long ne) {
   __shared__ __attribute__((aligned(16))) unsigned int stage[2][16][4][24];      // [buffer][16-column block][row in group][q*8 + pair]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long per = gridDim.x >> 3;                                               // XCD-contiguous groups (see UMX_WAVE_ITEM_PL_XCD)
-  const long grp = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const long nvb = (((ne + 3) / 4 + 7) / 8) * 8;                                 // virtual blocks = row groups, padded to the 8 XCDs
+  const long per = nvb >> 3;                                                     // XCD-contiguous groups (see UMX_WAVE_LOOP_PL_XCD)
+  for (long vb = blockIdx.x; vb < nvb; vb += gridDim.x) {                        // grid-stride: any grid size (multiple of 8) works
+  const long grp = (vb & 7) * per + (vb >> 3);
   const long e0 = grp * 4;
-  if (e0 >= ne) return;                                                          // block-uniform
+  if (e0 >= ne) continue;                                                        // block-uniform
+  __syncthreads();                                                               // the previous virtual block's last stage buffer is free
   const long e = e0 + wave;
   const bool valid = e < ne;
   const int c0 = lane * 2;
@@ -186,6 +200,7 @@ __global__ __launch_bounds__(256) void k_gather_rotate_mod_q3(const float* __res
     dst[threadIdx.x] = src[threadIdx.x];
     if (threadIdx.x < 128) dst[256 + threadIdx.x] = src[256 + threadIdx.x];
   }
+  }
 }
 
 // SO(2) gate: hg = [gate(256) | hpre(9x128)] (fp32) -> hid (9x128) as PL planes
@@ -220,8 +235,10 @@ __global__ void k_gate_edge_fwd_pl(const float* __restrict__ hg, unsigned short*
 // 16-B stores (same reason as k_gather_rotate_mod_q3).
 __global__ __launch_bounds__(256) void k_gate_edge_fwd_q3(const float* __restrict__ hg, unsigned short* __restrict__ hid, long ne) {
   __shared__ __attribute__((aligned(16))) unsigned int stage[2][2][8][4][24];    // [buffer][row group][16-column block][row][q*8 + pair]
-  const long e0 = (long)blockIdx.x * 8;
-  if (e0 >= ne) return;                                                          // block-uniform
+  const long nvb = (ne + 7) / 8;
+  for (long vb = blockIdx.x; vb < nvb; vb += gridDim.x) {                        // grid-stride over groups of 8 edges: any grid size works
+  const long e0 = vb * 8;
+  __syncthreads();                                                               // the previous virtual block's last stage buffer is free
   const int le = threadIdx.x >> 5;                                               // edge within the workgroup
   const int c = (threadIdx.x & 31) * 4;
   const long e = (e0 + le < ne) ? e0 + le : e0;                                  // tail lanes recompute edge e0 (their rows are padding)
@@ -261,6 +278,7 @@ __global__ __launch_bounds__(256) void k_gate_edge_fwd_q3(const float* __restric
       }
     }
   }
+  }
 }
 
 // backward of K7b for the SO(2) messages: g_msg[e] = env_e (W_e g[dst e]) as PL planes; dedd/tau as the fp32 kernel
@@ -269,7 +287,7 @@ __global__ __launch_bounds__(256) void k_rotate_back_bwd_pl(const float* __restr
                                                             const float* __restrict__ frame, const int* __restrict__ edst,
                                                             unsigned short* __restrict__ gmsg, float* __restrict__ dedd,
                                                             float* __restrict__ tau, long ne) {
-  UMX_WAVE_ITEM_PL_XCD(e, ne)
+  UMX_WAVE_LOOP_PL_XCD(e, ne) {
   const int c0 = lane * 2;
   const float* f = frame + e * FRAME;
   const long jd = edst[e];
@@ -299,13 +317,13 @@ __global__ __launch_bounds__(256) void k_rotate_back_bwd_pl(const float* __restr
     dedd[e] += f[35] * s;
     tau[e * 4 + 0] += tx; tau[e * 4 + 1] += ty; tau[e * 4 + 2] += tz;
   }
+  }
 }
 
 // backward of the edge gate: ghid (9x128 fp32), hg (forward, fp32) -> g_hg = [ggate | ghpre] as PL planes (1408 columns)
 template <int P>
 __global__ void k_gate_edge_bwd_pl(const float* __restrict__ ghid, const float* __restrict__ hg, unsigned short* __restrict__ ghg, long ne) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ne * (H / 4)) return;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ne * (H / 4); i += (long)gridDim.x * blockDim.x) {   // grid-stride
   const long e = i / (H / 4);
   const int c = (int)(i % (H / 4)) * 4;
   const float* p = hg + e * HG;
@@ -333,6 +351,7 @@ __global__ void k_gate_edge_bwd_pl(const float* __restrict__ ghid, const float* 
   }
   pl_store4<P>(o, c, make_float4(a1[0] * s1[0] * (1.0f - s1[0]), a1[1] * s1[1] * (1.0f - s1[1]), a1[2] * s1[2] * (1.0f - s1[2]), a1[3] * s1[3] * (1.0f - s1[3])));
   pl_store4<P>(o, H + c, make_float4(a2[0] * s2[0] * (1.0f - s2[0]), a2[1] * s2[1] * (1.0f - s2[1]), a2[2] * s2[2] * (1.0f - s2[2]), a2[3] * s2[3] * (1.0f - s2[3])));
+  }
 }
 
 // backward of the radial modulation with the rotated message RE-DERIVED in place (gather + rotate, no HBM round trip):

@@ -57,6 +57,7 @@ struct umx_engine {
   hipStream_t stream2 = nullptr;   // second lane: half-chunks alternate streams so HBM-bound producers overlap the other lane's GEMMs
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev_tok[2] = {nullptr, nullptr};   // matrix-pipe token of the two lanes (run_plans_alternating)
+  int q3_stages = 2;               // UMX_Q3S: LDS ring depth of the forward Q3 GEMMs (2 or 3)
   bool q3_wide = true;             // UMX_Q3WIDE=0 (dev): 256x128 tiles for every forward GEMM
   bool q3 = true;                  // UMX_Q3=0: forward operands in the 32-column PL layout + 256x128 tiles (set before umx_load_weights)
   bool wide_tiles = true;          // UMX_WIDE=0: 256x128 tiles for every GEMM
@@ -222,8 +223,14 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
     const int bnq = wq ? (cplx ? 128 : 256) : (cplx ? 64 : 128);
     const long nNq = (N + bnq - 1) / bnq;
     dim3 gq((unsigned)(((nM + 7) / 8) * 8 * nNq));
-    if (cplx) { if (wq) hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<1, 0>), gq, block, 0, eng->stream, q); }
-    else      { if (wq) hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0>), gq, block, 0, eng->stream, q); }
+    const int S = eng->q3_stages;             // ring depth: 2 (default) or 3 (UMX_Q3S=3: 144 KB wide / 108 KB narrow)
+    if (cplx) {
+      if (wq) { if (S == 3) hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1, 3, 3>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1>), gq, block, 0, eng->stream, q); }
+      else    { if (S == 3) hipLaunchKernelGGL((umx_gemm_q_kernel<1, 0, 3, 3>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<1, 0>), gq, block, 0, eng->stream, q); }
+    } else {
+      if (wq) { if (S == 3) hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 3, 3>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1>), gq, block, 0, eng->stream, q); }
+      else    { if (S == 3) hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0, 3, 3>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0>), gq, block, 0, eng->stream, q); }
+    }
   } else if (P == 3) {
     if (use16) {
       if (cplx) hipLaunchKernelGGL((umx_gemm_pl16_kernel<1, 3, 2, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
@@ -755,6 +762,7 @@ int umx_create(umx_engine** out, int device_ordinal) {
   if (const char* ev = std::getenv("UMX_WIDE")) e->wide_tiles = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_Q3")) e->q3 = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_Q3WIDE")) e->q3_wide = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("UMX_Q3S")) e->q3_stages = std::atoi(ev) == 3 ? 3 : 2;
   if (const char* ev = std::getenv("UMX_FUSE_MODROT")) e->fuse_modrot = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_STREAMS")) e->n_lanes = std::atoi(ev) >= 2 ? 2 : 1;
   e->stream_cap = 512;

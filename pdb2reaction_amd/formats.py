@@ -8,6 +8,9 @@ tests/test_formats.py pin it); pure Python/numpy, no third-party IO:
   ``path_opt.py:983-1004`` / ``path_search.py:407-423`` (pysisyphus images).
 * reader ``read_energies_xyz``: first decimal number on the comment line, exponents not parsed -- ``trj2fig.py:86-109``.
 * ``deep_update`` / ``apply_yaml_overrides`` / ``load_yaml_dict``: defaults <- CLI <- YAML precedence -- ``utils.py:243-313``.
+* ``summary.yaml`` of a path search: ``out_dir / n_images / n_segments / segments[index, tag, kind, barrier_kcal, delta_kcal,
+  bond_changes]`` (+ optional ``energy_diagrams``), dumped with ``yaml.safe_dump(sort_keys=False, allow_unicode=True)``; the
+  bond-change report text becomes a list of one-key mappings (``path_search.py:245-293,2762-2786``).
 * HEI rule lives in :func:`pdb2reaction_amd.string.select_hei_index` (``path_opt.py:259-273``).
 """
 from __future__ import annotations
@@ -155,3 +158,84 @@ def load_yaml_dict(path: Optional[PathLike]) -> Dict[str, Any]:
     if not isinstance(data, dict):
         raise ValueError(f"YAML root must be a mapping, got: {type(data)}")
     return data
+
+
+# ---- summary.yaml (run-level summary of a path search) ------------------------------------------------------
+try:  # Hartree -> kcal/mol exactly as pysisyphus.constants builds it: E_h * N_A / 1000 / 4.184
+    from scipy import constants as _sc
+
+    AU2KCALPERMOL = _sc.value("Hartree energy") * _sc.N_A / 1000.0 / 4.184
+except Exception:  # CODATA 2022
+    AU2KCALPERMOL = 627.5094740630558
+
+
+def barrier_and_delta_kcal(energies_hartree: Sequence[float]) -> Tuple[float, float]:
+    """(max(E) - E[0], E[-1] - E[0]) in kcal/mol -- the two numbers reported per MEP segment (``path_search.py:1206-1207``)."""
+    e = [float(x) for x in energies_hartree]
+    return (max(e) - e[0]) * AU2KCALPERMOL, (e[-1] - e[0]) * AU2KCALPERMOL
+
+
+def bond_changes_block(text: Optional[str]):
+    """The ``bond_changes`` value of a summary segment.
+
+    ``summarize_changes`` text such as ``"Bond formed (1):\n  - C1-O2 : 1.500 Å --> 1.360 Å\nBond broken: None"`` becomes
+    ``[{"Bond formed (1)": ["C1-O2 : 1.500 Å --> 1.360 Å"]}, {"Bond broken": ["None"]}]``; empty / None -> ``""``; text
+    without any ``Bond ...`` heading is kept as is (behaviour of the reference's ``_bond_changes_block``,
+    ``path_search.py:245-293``; multi-line fallback text is dumped in YAML literal style by :func:`write_summary_yaml`)."""
+    body = "" if text is None else str(text).strip()
+    if not body:
+        return ""
+    out: List[Dict[str, List[str]]] = []
+    open_title: Optional[str] = None
+    items: List[str] = []
+
+    def close():
+        nonlocal open_title, items
+        if open_title is not None:
+            out.append({open_title: items or ["None"]})
+        open_title, items = None, []
+
+    for raw in body.splitlines():
+        line = raw.strip()
+        if line.startswith("Bond "):
+            close()
+            if line.endswith(": None"):
+                out.append({line[: -len(": None")]: ["None"]})
+            else:
+                open_title = line.rstrip(":")
+        elif line.startswith("- "):
+            items.append(line[2:])
+    close()
+    return out if out else body
+
+
+def summary_dict(out_dir: PathLike, n_images: int, segments: Sequence[Mapping[str, Any]],
+                 energy_diagram: Optional[Mapping[str, Any]] = None) -> Dict[str, Any]:
+    """Key order and types of the reference's summary (``path_search.py:2762-2782``).  Each segment mapping carries
+    ``index, tag, kind ("seg" | "bridge"), barrier_kcal, delta_kcal`` and the ``summarize_changes`` text under ``summary``
+    (bridges report no bond changes)."""
+    segs = []
+    for sg in segments:
+        kind = str(sg.get("kind", "seg"))
+        segs.append({"index": int(sg["index"]), "tag": sg["tag"], "kind": kind, "barrier_kcal": float(sg["barrier_kcal"]),
+                     "delta_kcal": float(sg["delta_kcal"]), "bond_changes": bond_changes_block(sg.get("summary")) if kind != "bridge" else ""})
+    d: Dict[str, Any] = {"out_dir": str(out_dir), "n_images": int(n_images), "n_segments": len(segs), "segments": segs}
+    if energy_diagram is not None:
+        d["energy_diagrams"] = [dict(energy_diagram)]
+    return d
+
+
+def write_summary_yaml(path: PathLike, summary: Mapping[str, Any]) -> str:
+    """Dump `summary` as the reference does (block style, insertion order, unicode kept; multi-line strings literal)."""
+    import yaml
+
+    class _Dumper(yaml.SafeDumper):
+        pass
+
+    def _str(dumper, data):
+        return dumper.represent_scalar("tag:yaml.org,2002:str", data, style="|" if "\n" in data else None)
+
+    _Dumper.add_representer(str, _str)
+    text = yaml.dump(dict(summary), Dumper=_Dumper, sort_keys=False, allow_unicode=True)
+    Path(path).write_text(text, encoding="utf-8")
+    return text

@@ -9,8 +9,11 @@ PARITY UNPINNED: pysisyphus is not installed here, so the loop follows the publi
 SURVEY.md Appendix B -- frontier growth at ``perp_thresh``, equal-arc ("equi") reparametrisation, perpendicular-force
 steps scaled to ``max_step``, climbing image once the fully grown string is below ``climb_rms``, convergence on the
 ``thresh`` presets of reference ``opt.py:176-187`` -- not pysisyphus' source.  Keyword names and defaults are those of
-reference ``GS_KW`` / ``STOPT_KW`` (``path_opt.py:168-200``); ``climb_lanczos`` (Lanczos HEI tangent) and DLC
-coordinates are not implemented: the climbing tangent is the string tangent, coordinates are Cartesian.
+reference ``GS_KW`` / ``STOPT_KW`` (``path_opt.py:168-200``).  Tangents come from a parametric cubic spline through the
+images (Appendix B; central differences for fewer than four images, ``tangent="central"`` forces them); with
+``climb_lanczos`` (the reference default, ``path_opt.py:181-182``) the climbing image's tangent is the lowest-curvature mode
+from a Lanczos iteration on finite-difference Hessian-vector products once the string is below ``climb_lanczos_rms``
+(:func:`lanczos_lowest_mode`; one single-image evaluation per Lanczos step).  Coordinates are Cartesian (no DLC).
 """
 from __future__ import annotations
 
@@ -55,12 +58,73 @@ class GSMResult:
     history: List[Dict[str, float]] = field(default_factory=list)
 
 
-def _tangents(x: np.ndarray) -> np.ndarray:
+def _tangents_central(x: np.ndarray) -> np.ndarray:
     t = np.empty_like(x)
     t[1:-1] = x[2:] - x[:-2]
     t[0] = x[1] - x[0]
     t[-1] = x[-1] - x[-2]
     return t / np.maximum(np.linalg.norm(t, axis=1, keepdims=True), 1e-30)
+
+
+def _tangents(x: np.ndarray, kind: str = "spline") -> np.ndarray:
+    """Unit tangents at the images.  "spline": derivative of the interpolating parametric cubic spline (not-a-knot) over
+    the cumulative chord length -- what a spline through the string gives; needs >= 4 images with
+    distinct positions, otherwise (and for "central") central differences with one-sided ends."""
+    if kind == "spline" and len(x) >= 4:
+        seg = np.linalg.norm(np.diff(x, axis=0), axis=1)
+        if np.all(seg > 1e-12):
+            from scipy.interpolate import make_interp_spline
+
+            u = np.concatenate([[0.0], np.cumsum(seg)])
+            t = make_interp_spline(u, x, k=3)(u, 1)
+            return t / np.maximum(np.linalg.norm(t, axis=1, keepdims=True), 1e-30)
+    return _tangents_central(x)
+
+
+def lanczos_lowest_mode(grad_fn: Callable[[np.ndarray], np.ndarray], x: np.ndarray, g0: np.ndarray, guess: np.ndarray, *,
+                        dx: float = 5e-3, dl: float = 1e-2, max_cycles: int = 25):
+    """Lowest Hessian eigenpair at x from a Lanczos recursion on forward-difference Hessian-vector products
+    H q ~ (g(x + dx q) - g(x)) / dx; one gradient per step, started from `guess` (the string tangent).
+
+    Returns (eigenvalue, unit eigenvector, gradient evaluations).  Stops when the lowest Ritz value changes by less than
+    `dl` (relative) between two steps, when the Krylov space is exhausted, or after `max_cycles` steps.  The vector is
+    oriented along `guess`."""
+    n = x.size
+    r = np.asarray(guess, dtype=np.float64).reshape(-1).copy()
+    beta = float(np.linalg.norm(r))
+    if beta < 1e-14:
+        raise ValueError("lanczos: zero start vector")
+    qs: List[np.ndarray] = []
+    alphas: List[float] = []
+    betas: List[float] = []
+    q_prev = np.zeros(n)
+    w_prev: Optional[float] = None
+    w_min, v_min = 0.0, r / beta
+    steps = 0
+    for steps in range(1, min(int(max_cycles), n) + 1):
+        q = r / beta
+        for qq in qs:                                  # full re-orthogonalisation: the space is small and FD noise is not
+            q -= (qq @ q) * qq
+        q /= max(float(np.linalg.norm(q)), 1e-30)
+        u = (grad_fn(x + dx * q) - g0) / dx - beta * q_prev if qs else (grad_fn(x + dx * q) - g0) / dx
+        alpha = float(q @ u)
+        r = u - alpha * q
+        qs.append(q); alphas.append(alpha)
+        t = np.diag(alphas) + np.diag(betas, 1) + np.diag(betas, -1)
+        w, v = np.linalg.eigh(t)
+        w_min = float(w[0])
+        v_min = np.stack(qs, axis=1) @ v[:, 0]
+        beta = float(np.linalg.norm(r))
+        if w_prev is not None and abs(w_min - w_prev) <= dl * max(abs(w_prev), 1e-12):
+            break
+        if beta < 1e-10:
+            break
+        w_prev, q_prev = w_min, q
+        betas.append(beta)
+    v_min = v_min / max(float(np.linalg.norm(v_min)), 1e-30)
+    if float(v_min @ np.asarray(guess, dtype=np.float64).reshape(-1)) < 0.0:
+        v_min = -v_min
+    return w_min, v_min, steps
 
 
 def _place(x: np.ndarray, targets: np.ndarray) -> np.ndarray:
@@ -110,6 +174,8 @@ class GrowingStringDriver:
         self.energies: Optional[np.ndarray] = None
         self.forces: Optional[np.ndarray] = None
         self.n_eval = 0
+        self.lanczos_evals = 0
+        self.tangent_kind = str(self.gs.get("tangent", "spline"))
         self._lbfgs_s: List[np.ndarray] = []
         self._lbfgs_y: List[np.ndarray] = []
         self._prev = None
@@ -143,6 +209,15 @@ class GrowingStringDriver:
         self.energies[idx] = np.asarray(e, dtype=np.float64)
         self.forces[idx] = np.asarray(f, dtype=np.float64).reshape(len(idx), -1)
         self.n_eval += len(idx)
+
+    def _single_forces(self, xq: np.ndarray) -> np.ndarray:
+        """Forces of ONE geometry through the same (batched) evaluator -- the serial steps of the Lanczos recursion."""
+        if self._evaluate is not None:
+            _, f = self._evaluate(xq[None])
+        else:
+            f = self.calc.get_forces_batch(self.atoms, xq[None])["forces"]
+        self.n_eval += 1
+        return np.asarray(f, dtype=np.float64).reshape(-1)
 
     def _reparametrize(self, x: np.ndarray) -> np.ndarray:
         k, nl = len(x), len(self.left)
@@ -196,7 +271,7 @@ class GrowingStringDriver:
             moving = np.ones(k, dtype=bool)
             moving[0] = not gs["fix_first"]
             moving[-1] = not gs["fix_last"]
-            t = _tangents(x)
+            t = _tangents(x, self.tangent_kind)
             f = self.forces
             fpar = np.einsum("ij,ij->i", f, t)[:, None] * t
             fperp = f - fpar
@@ -212,7 +287,14 @@ class GrowingStringDriver:
                 self._lbfgs_s.clear(); self._lbfgs_y.clear(); self._prev = None
             step_force = fperp.copy()
             if climbing and 0 < hei < k - 1:
-                step_force[hei] = f[hei] - 2.0 * fpar[hei]           # invert the parallel component on the climbing image
+                t_ci = t[hei]
+                if gs["climb_lanczos"] and rms_all <= gs["climb_lanczos_rms"]:
+                    # lowest-curvature direction at the HEI instead of the string tangent (reference GS_KW climb_lanczos)
+                    def grad_at(xq):
+                        return -self._single_forces(xq)
+                    _, t_ci, n_l = lanczos_lowest_mode(grad_at, x[hei], -f[hei], t[hei])
+                    self.lanczos_evals += n_l
+                step_force[hei] = f[hei] - 2.0 * float(f[hei] @ t_ci) * t_ci   # invert the component along the climbing tangent
             history.append({"cycle": cycle, "images": k, "rms_fperp": rms_all, "max_fperp": max_all, "e_hei": float(self.energies[hei]),
                             "climbing": float(climbing)})
             if cycle % max(int(opt["print_every"]), 1) == 0:

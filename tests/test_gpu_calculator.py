@@ -135,12 +135,30 @@ def test_gsm_driver_on_the_engine(tmp_path, setup):
     z, elem, imgs = setup
     calc = U.uma_pysis(model="synthetic", freeze_atoms=[0])
     r, p = (imgs[0] * U.ANG2BOHR).reshape(-1), (imgs[3] * U.ANG2BOHR).reshape(-1)
-    drv = GrowingStringDriver(elem, r, p, calc, gs_kw={"max_nodes": 4, "perp_thresh": 1e3, "climb": False}, stopt_kw={"max_cycles": 4, "max_step": 0.05})
+    drv = GrowingStringDriver(elem, r, p, calc, gs_kw={"max_nodes": 4, "perp_thresh": 1e3, "climb": False}, stopt_kw={"max_cycles": 12, "max_step": 0.05})
     res = drv.run()
     assert res.fully_grown and res.coords.shape == (6, 42) and np.isfinite(res.energies).all()
     assert res.force_evaluations >= 4 + 6 + 4 + 4
-    e_first = calc.get_energy(elem, res.coords[0])["energy"]
-    assert e_first == pytest.approx(res.energies[0], abs=1e-9)
+    # behaviour, not just finiteness:
+    #  - the returned energies ARE the energies of the returned geometries (bitwise: one batched call either way)
+    chk = calc.get_forces_batch(elem, res.coords)
+    assert np.array_equal(chk["energy"][1:-1], res.energies[1:-1])
+    assert calc.get_energy(elem, res.coords[0])["energy"] == pytest.approx(res.energies[0], abs=1e-9)
+    #  - fixed endpoints are untouched
+    assert np.array_equal(res.coords[0], r) and np.array_equal(res.coords[-1], p)
+    #  - the optimiser does its job: the perpendicular force of the fully grown string falls from its first to its last cycle
+    full = [h for h in res.history if h["images"] == 6]
+    assert len(full) >= 6 and full[-1]["rms_fperp"] < 0.95 * full[0]["rms_fperp"]
+    #  - "equi" reparametrisation keeps the nodes evenly spread along the path
+    seg = np.linalg.norm(np.diff(res.coords, axis=0), axis=1)
+    assert seg.max() / seg.min() < 1.5
+    #  - forces of interior images are perpendicular-dominated no more than at the start: F_perp of the final string from a
+    #    fresh evaluation agrees with the driver's last bookkeeping (same tangents, same forces)
+    from pdb2reaction_amd.gsm import _tangents
+    t = _tangents(res.coords)
+    f = chk["forces"]
+    fperp = f - (f * t).sum(1, keepdims=True) * t
+    assert np.sqrt((fperp[1:-1] ** 2).mean()) < 1.05 * full[0]["rms_fperp"]
     path = tmp_path / "final_geometries.trj"
     formats.write_trj_with_energy([e.capitalize() for e in elem], res.coords.reshape(6, -1, 3) * U.BOHR2ANG, res.energies, path)
     assert np.allclose(formats.read_energies_xyz(path), res.energies, atol=1e-12)

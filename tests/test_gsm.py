@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from pdb2reaction_amd.gsm import GS_KW, STOPT_KW, GrowingStringDriver
+from pdb2reaction_amd.gsm import GS_KW, STOPT_KW, GrowingStringDriver, _tangents, lanczos_lowest_mode
 
 A = np.array([-200.0, -100.0, -170.0, 15.0])
 a = np.array([-1.0, -1.0, -6.5, 0.7])
@@ -54,9 +54,11 @@ def test_gsm_finds_the_mueller_brown_saddle():
     assert np.abs(res.coords[:, 2]).max() < 1e-6
     assert np.array_equal(res.coords[0], MIN_A) and np.array_equal(res.coords[-1], MIN_B)   # fixed endpoints untouched
     # one batched call per cycle; fixed endpoints are evaluated only when the string changes size
-    assert len(calc.batches) <= res.cycles + 1 and max(calc.batches) <= 15
+    # (the Lanczos tangent of the climbing image costs extra single-image evaluations: counted separately)
+    assert drv.lanczos_evals > 0 and calc.batches.count(1) >= drv.lanczos_evals
+    assert len(calc.batches) - drv.lanczos_evals <= res.cycles + 1 and max(calc.batches) <= 15
     assert res.force_evaluations == sum(calc.batches)
-    assert min(calc.batches[-5:]) == 13                                               # K-2 evaluations per cycle once grown
+    assert sorted(set(calc.batches[-12:])) == [1, 13]                                 # K-2 evaluations per cycle once grown (+ Lanczos singles)
     # nodes (except the climbing image's neighbourhood) are spread along the path
     seg = np.linalg.norm(np.diff(res.coords, axis=0), axis=1)
     assert seg.max() / seg.min() < 4.0
@@ -101,3 +103,33 @@ def test_unconverged_exit_returns_energies_of_the_returned_coordinates():
     assert not res.converged and res.cycles == 5
     e_now = calc.get_forces_batch(["X"], res.coords)["energy"]
     np.testing.assert_allclose(res.energies, e_now, rtol=0, atol=1e-12)
+
+
+def test_lanczos_finds_the_lowest_mode_of_a_known_hessian():
+    """climb_lanczos (reference GS_KW, path_opt.py:181-182): lowest-curvature direction from gradient differences only."""
+    rng = np.random.default_rng(3)
+    n = 30
+    qmat, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    evals = np.concatenate([[-0.8], np.linspace(0.3, 4.0, n - 1)])
+    hess = (qmat * evals) @ qmat.T
+    x0 = rng.standard_normal(n)
+    grad = lambda x: hess @ (x - 0.1) + 1e-3 * np.sin(x)          # slightly anharmonic
+    guess = qmat[:, 0] + 0.6 * rng.standard_normal(n) / np.sqrt(n)
+    w, v, steps = lanczos_lowest_mode(grad, x0, grad(x0), guess, dx=1e-4, dl=1e-5, max_cycles=30)
+    assert abs(w - (-0.8)) < 5e-3 and steps <= 30
+    assert abs(v @ qmat[:, 0]) > 0.995 and v @ guess > 0 and abs(np.linalg.norm(v) - 1) < 1e-12
+    with pytest.raises(ValueError):
+        lanczos_lowest_mode(grad, x0, grad(x0), np.zeros(n))
+
+
+def test_spline_tangents_follow_the_curve():
+    th = np.linspace(0.2, 2.6, 9)
+    x = np.stack([2 * np.cos(th), 2 * np.sin(th), 0.3 * th], axis=1)
+    exact = np.stack([-2 * np.sin(th), 2 * np.cos(th), 0.3 * np.ones_like(th)], axis=1)
+    exact /= np.linalg.norm(exact, axis=1, keepdims=True)
+    ts, tc = _tangents(x, "spline"), _tangents(x, "central")
+    err_s = np.linalg.norm(ts - exact, axis=1).max()
+    err_c = np.linalg.norm(tc - exact, axis=1).max()
+    assert err_s < 5e-3 and err_s < 0.1 * err_c                    # one-sided end differences are the weak spot of "central"
+    assert np.allclose(np.linalg.norm(ts, axis=1), 1.0)
+    assert np.array_equal(_tangents(x[:3], "spline"), _tangents(x[:3], "central"))     # too few images: fallback

@@ -113,3 +113,17 @@ def test_yaml_helpers_match_reference(fx, tmp_path):
             assert case["raises"] == "ValueError" and str(ei.value) == case["message"]
         else:
             assert F.load_yaml_dict(p) == case["data"]
+
+
+def test_summary_yaml_matches_reference(fx, tmp_path):
+    """summary.yaml (path_search.py:2762-2786): the bond-change block builder and the exact YAML text."""
+    for case in fx["bond_changes_block"]:
+        got = F.bond_changes_block(case["text"])
+        assert got == case["result"], case["text"]
+    for case in fx["summary_yaml"]:
+        d = F.summary_dict(case["out_dir"], case["n_images"], case["segments"], case["energy_diagram"])
+        text = F.write_summary_yaml(tmp_path / "summary.yaml", d)
+        assert text == case["text"]
+        assert (tmp_path / "summary.yaml").read_text(encoding="utf-8") == case["text"]
+    b, dlt = F.barrier_and_delta_kcal([-1.0, -0.98, -1.01])
+    assert b == pytest.approx(0.02 * 627.509474, rel=1e-7) and dlt == pytest.approx(-0.01 * 627.509474, rel=1e-7)

@@ -14,6 +14,9 @@ stored.  tests/test_reference_fixtures.py then holds this repo's restatements to
   pdb2reaction/opt.py                 HarmonicBiasCalculator._bias_energy_forces_bohr -> prestep.HarmonicBias._bias
   pdb2reaction/bond_changes.py        _bond_str, summarize_changes              -> pdb2reaction_amd.bond_changes.*
   pdb2reaction/trj2fig.py             read_energies_xyz                         -> pdb2reaction_amd.formats.read_energies_xyz
+  pdb2reaction/path_search.py         _bond_changes_block (+ the summary.yaml
+                                      dump call as written at :2784-2785)       -> pdb2reaction_amd.formats.bond_changes_block,
+                                                                                   summary_dict, write_summary_yaml
   pdb2reaction/utils.py               deep_update, apply_yaml_overrides,
                                       load_yaml_dict                            -> pdb2reaction_amd.formats.*
 
@@ -177,8 +180,36 @@ def main():
                 fx["load_yaml_dict"].append({"text": t, "raises": type(exc).__name__, "message": str(exc)})
         fx["load_yaml_dict"].append({"text": None, "data": ut["load_yaml_dict"](None)})
 
+    # ---- summary.yaml (path_search.py:234-293, 2762-2786): the block builder is the reference's; the dict literal and the dump
+    #      call mirror :2762-2785 (safe_dump, sort_keys=False, allow_unicode=True)
+    import yaml as _yaml
+    ps = grab(REF / "path_search.py", ["_LiteralStr", "_literal_str_representer", "_bond_changes_block"], extra={"yaml": _yaml})
+    _yaml.add_representer(ps["_LiteralStr"], ps["_literal_str_representer"], Dumper=_yaml.SafeDumper)
+    texts_bc = ["Bond formed (1):\n  - C1-O2 : 1.500 Å --> 1.360 Å\nBond broken: None", "Bond formed: None\nBond broken (2):\n  - H3-O4 : 0.980 Å --> 2.310 Å\n  - C1-H9 : 1.090 Å --> 1.900 Å",
+                "", None, "   ", "(no covalent changes detected)", "two lines\nof free text", "Bond formed (1):", "Bond formed: None\nBond broken: None"]
+    fx["bond_changes_block"] = []
+    for t in texts_bc:
+        r = ps["_bond_changes_block"](t)
+        fx["bond_changes_block"].append({"text": t, "result": r if not isinstance(r, str) else str(r), "literal": isinstance(r, ps["_LiteralStr"])})
+    segs_in = [{"index": 1, "tag": "seg_000", "kind": "seg", "barrier_kcal": 23.456789012345, "delta_kcal": -5.5, "summary": texts_bc[0]},
+               {"index": 2, "tag": "bridge_000_001", "kind": "bridge", "barrier_kcal": float("nan"), "delta_kcal": 1e-7, "summary": ""},
+               {"index": 3, "tag": "seg_001", "kind": "seg", "barrier_kcal": 0.0, "delta_kcal": 12.0, "summary": "two lines\nof free text"},
+               {"index": 4, "tag": "seg_002", "kind": "seg", "barrier_kcal": 3.25, "delta_kcal": -0.125, "summary": "(no covalent changes detected)"}]
+    summary = {"out_dir": "result_path_search", "n_images": 37, "n_segments": len(segs_in),
+               "segments": [{"index": int(sg["index"]), "tag": sg["tag"], "kind": sg["kind"], "barrier_kcal": float(sg["barrier_kcal"]),
+                             "delta_kcal": float(sg["delta_kcal"]),
+                             "bond_changes": (ps["_bond_changes_block"](sg["summary"]) if (sg["kind"] != "bridge") else "")} for sg in segs_in]}
+    diagram = {"name": "energy_diagram_MEP", "labels": ["R", "TS1", "IM1", "P"], "energies_kcal": [0.0, 23.5, -2.0, -5.5], "ylabel": "ΔE (kcal/mol)"}
+    fx["summary_yaml"] = []
+    for dg in (None, diagram):
+        sm = dict(summary)
+        if dg is not None:
+            sm["energy_diagrams"] = [dg]
+        fx["summary_yaml"].append({"out_dir": "result_path_search", "n_images": 37, "segments": segs_in, "energy_diagram": dg,
+                                   "text": _yaml.safe_dump(sm, sort_keys=False, allow_unicode=True)})
+
     OUT.parent.mkdir(parents=True, exist_ok=True)
-    OUT.write_text(json.dumps(fx, indent=1, sort_keys=True) + "\n")
+    OUT.write_text(json.dumps(fx, indent=1) + "\n")          # insertion order matters (YAML key order of dict-valued inputs)
     print(f"wrote {OUT} ({OUT.stat().st_size} bytes): " + ", ".join(f"{k}={len(v)}" for k, v in fx.items() if isinstance(v, list)))
 
 

@@ -10,10 +10,16 @@ reaction path.  This module does the same arithmet
   ``weights.param_shapes()`` (the names the engine loads), float32 conversion;
 * ``convert``: state dict -> blob bytes for ``Engine.load_weights`` / ``umx_load_weights``.
 
-[3P-UNVERIFIED] The real checkpoint's key names and its routing network could not be inspected.  The defaults below assume
-fairchem-style names (``backbone.`` prefix, expert-stacked tensors of shape (n_experts, out, in) under ``<layer>.weights``);
-pass ``rename=`` / ``coefficients=`` for anything else.  The routing network itself is NOT restated: hand in the coefficient
-vector (e.g. dumped once from fairchem for the system at hand), or a state dict that is already merged.
+* ``mole_coefficients`` / ``convert_for_system``: the ROUTING network restated from SURVEY.md Appendix A.7 -- alpha =
+  softmax(routing_mlp([mean_i comp_emb[Z_i] || sys_emb])) with sys_emb = SiLU(mix_csd([chg_emb, spin_emb, dataset_emb])) --
+  so a fairchem-style state dict can be turned into a merged blob FOR ONE SYSTEM without fairchem.  The blob records that
+  system (``merged_for``) and every consumer refuses to bind it to another one (``weights.check_merged_for``).
+
+[3P-UNVERIFIED] The real checkpoint's key names and the exact form of its routing network could not be inspected (neither
+fairchem nor a checkpoint exists here).  The defaults assume fairchem-style names (``backbone.`` prefix, expert-stacked tensors
+of shape (n_experts, out, in) under ``<layer>.weights``, ``routing_mlp.<2i>.{weight,bias}`` Linear layers with SiLU between
+them, ``composition_embedding.weight``); every name is a keyword argument, and ``coefficients=`` accepts a vector dumped
+from fairchem itself, which is the safer path until the restatement has been checked against a real checkpoint.
 """
 from __future__ import annotations
 
@@ -83,6 +89,70 @@ def from_state_dict(state: Mapping[str, object], *, prefix: str = "backbone.", c
     if missing and strict:
         raise KeyError(f"{len(missing)} parameters missing, first: {missing[:4]}")
     return out
+
+
+def _silu(x: Array) -> Array:
+    return x / (1.0 + np.exp(-x))
+
+
+def mole_coefficients(state: Mapping[str, object], atomic_numbers, charge: int, spin: int, task: str, *, prefix: str = "backbone.",
+                      composition_key: str = "composition_embedding.weight", routing_prefix: str = "routing_mlp",
+                      use_system_embedding: bool = True) -> Array:
+    """Expert mixing coefficients alpha (n_experts,) of ONE system -- SURVEY.md Appendix A.7, [3P-UNVERIFIED].
+
+    composition = mean over atoms of ``composition_embedding[Z_i]`` (order independent); with ``use_system_embedding`` the
+    charge / spin / task embedding of Appendix A.5, ``SiLU(mix_csd([chg_emb[q+100], spin_emb[s], dataset_emb[t]]))``, is
+    appended; the routing MLP is every ``<routing_prefix>.<n>.weight/bias`` Linear in ascending n with SiLU between them;
+    alpha = softmax of its output.  float64 throughout (the merge is setup work, once per system)."""
+    def get(name: str) -> Array:
+        for key in (prefix + name, name):
+            if key in state:
+                return _np(state[key])
+        raise KeyError(f"state dict has no {prefix}{name!r} (needed for MoLE routing)")
+
+    z = np.asarray(atomic_numbers, dtype=np.int64).reshape(-1)
+    if z.size == 0:
+        raise ValueError("mole_coefficients: empty system")
+    x = get(composition_key)[z].mean(axis=0)
+    if use_system_embedding:
+        if task not in W.DATASET_LIST:
+            raise ValueError(f"task_name {task!r} not in {W.DATASET_LIST}")
+        v = np.concatenate([get("charge_embedding.weight")[int(charge) + W.CHARGE_OFFSET], get("spin_embedding.weight")[int(spin)],
+                            get("dataset_embedding.weight")[W.DATASET_LIST.index(task)]])
+        x = np.concatenate([x, _silu(get("mix_csd.weight") @ v + get("mix_csd.bias"))])
+    layers = sorted({int(k[len(p):].split(".")[0]) for p in (prefix + routing_prefix + ".", routing_prefix + ".")
+                     for k in state if k.startswith(p) and k.endswith(".weight")})
+    if not layers:
+        raise KeyError(f"state dict has no {prefix}{routing_prefix}.<n>.weight layers")
+    for n, li in enumerate(layers):
+        w, b = get(f"{routing_prefix}.{li}.weight"), get(f"{routing_prefix}.{li}.bias")
+        if w.shape[1] != x.shape[0]:
+            raise ValueError(f"{routing_prefix}.{li}.weight expects {w.shape[1]} inputs, got {x.shape[0]}")
+        x = w @ x + b
+        if n + 1 < len(layers):
+            x = _silu(x)
+    e = np.exp(x - x.max())
+    return e / e.sum()
+
+
+def convert_for_system(state: Mapping[str, object], atomic_numbers, charge: int, spin: int, task: str, *, routing_kw: Optional[dict] = None,
+                       **kw) -> bytes:
+    """State dict with MoLE experts + routing network -> merged blob for exactly this system: alpha from
+    :func:`mole_coefficients`, merge, ``merged_for`` stamped.  Routing / composition tensors are dropped from the engine's
+    parameter set (``rename`` is extended accordingly)."""
+    rk = dict(routing_kw or {})
+    alpha = mole_coefficients(state, atomic_numbers, charge, spin, task, prefix=kw.get("prefix", "backbone."), **rk)
+    user_rename = kw.pop("rename", None)
+    drop = (rk.get("routing_prefix", "routing_mlp") + ".", rk.get("composition_key", "composition_embedding.weight"))
+
+    def rename(name: str):
+        if name.startswith(drop[0]) or name == drop[1]:
+            return None
+        if user_rename is None:
+            return name
+        return user_rename(name) if callable(user_rename) else user_rename.get(name, name)
+
+    return convert(state, coefficients=alpha, merged_for=W.system_record(atomic_numbers, charge, spin, task), rename=rename, **kw)
 
 
 def convert(state: Mapping[str, object], *, merged_for: Optional[Mapping[str, object]] = None, **kw) -> bytes:

@@ -78,3 +78,42 @@ def test_errors_and_renaming():
     got = CK.from_state_dict(ren, coefficients=alpha, extra=extra,
                              rename=lambda n: None if n.startswith("routing_mlp.") else n.replace("final_norm.", "norm."))
     assert set(got) == set(W.param_shapes())
+
+
+def test_mole_routing_and_convert_for_system():
+    """Row f4: routing network restated from SURVEY.md App. A.7 ([3P-UNVERIFIED]) -> alpha -> merged blob bound to one system."""
+    w = W.make_synthetic_weights(0)
+    state, _, extra = _fake_state(w)
+    rng = np.random.default_rng(11)
+    n_exp = next(v.shape[0] for k, v in state.items() if k.endswith(".weights"))
+    c = W.SPHERE_CHANNELS
+    state["backbone.composition_embedding.weight"] = torch.tensor(rng.standard_normal((W.MAX_NUM_ELEMENTS, c)))
+    state["backbone.routing_mlp.0.weight"] = torch.tensor(rng.standard_normal((64, 2 * c)) / np.sqrt(2 * c))
+    state["backbone.routing_mlp.0.bias"] = torch.tensor(0.1 * rng.standard_normal(64))
+    state["backbone.routing_mlp.2.weight"] = torch.tensor(rng.standard_normal((n_exp, 64)) / 8.0)
+    state["backbone.routing_mlp.2.bias"] = torch.tensor(0.1 * rng.standard_normal(n_exp))
+    z = [8, 1, 1, 6, 1, 1, 1, 7]
+    a = CK.mole_coefficients(state, z, 0, 1, "omol")
+    assert a.shape == (n_exp,) and np.all(a > 0) and abs(a.sum() - 1.0) < 1e-14
+    np.testing.assert_allclose(CK.mole_coefficients(state, z[::-1], 0, 1, "omol"), a, rtol=1e-13)      # composition, not order
+    assert np.abs(CK.mole_coefficients(state, z, -1, 2, "omol") - a).max() > 1e-6                       # charge / spin matter
+    assert np.abs(CK.mole_coefficients(state, z, 0, 1, "omat") - a).max() > 1e-6                        # so does the task
+    assert np.abs(CK.mole_coefficients(state, z + [26], 0, 1, "omol") - a).max() > 1e-6                 # and the composition
+    # independent restatement of the formula
+    sd = {k[len("backbone."):]: v.double().numpy() for k, v in state.items() if k.startswith("backbone.")}
+    silu = lambda t: t / (1 + np.exp(-t))
+    v = np.concatenate([sd["charge_embedding.weight"][100], sd["spin_embedding.weight"][1], sd["dataset_embedding.weight"][1]])
+    x = np.concatenate([sd["composition_embedding.weight"][z].mean(0), silu(sd["mix_csd.weight"] @ v + sd["mix_csd.bias"])])
+    h = sd["routing_mlp.2.weight"] @ silu(sd["routing_mlp.0.weight"] @ x + sd["routing_mlp.0.bias"]) + sd["routing_mlp.2.bias"]
+    np.testing.assert_allclose(a, np.exp(h - h.max()) / np.exp(h - h.max()).sum(), rtol=1e-12)
+    # full conversion: merged with alpha, routing tensors dropped, bound to the system
+    blob = CK.convert_for_system(state, z, 0, 1, "omol", extra=extra)
+    back = W.unpack_blob(blob)
+    assert set(back) == set(W.param_shapes()) and back.meta["merged_for"] == W.system_record(z, 0, 1, "omol")
+    key = "blocks.0.edge_wise.so2_conv_1.fc_m0.weight"
+    want = CK.merge_mole(state["backbone." + key[:-len(".weight")] + ".weights"].double().numpy(), a).astype(np.float32)
+    assert np.array_equal(back[key], want)
+    with pytest.raises(ValueError, match="composition"):
+        W.check_merged_for(back, z + [1], 0, 1, "omol")
+    with pytest.raises(KeyError, match="routing"):
+        CK.mole_coefficients({k: v for k, v in state.items() if "routing_mlp" not in k}, z, 0, 1, "omol")

@@ -211,3 +211,43 @@ def test_engine_first_then_torch_cuda_in_one_process():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "OK 3.0" in out.stdout, out.stderr[-2000:]
+
+
+def test_real_checkpoint_path_end_to_end(tmp_path, monkeypatch, oracle, setup):
+    """Rows a5 / f4: fairchem-style state dict (MoLE experts + routing net) -> checkpoint.convert_for_system -> a .umxw blob under
+    $UMX_WEIGHTS_DIR -> ``uma_pysis(model="uma-s-1p1")`` loads THAT file (reference uma_pysis.py:246-250 loads its checkpoint by
+    name), energies match the oracle run on the merged weights, and binding the blob to another system is refused."""
+    import torch as T
+    from test_checkpoint import _fake_state
+    from pdb2reaction_amd import checkpoint as CK, weights as W
+
+    z, elem, imgs = setup
+    w = W.make_synthetic_weights(0)
+    state, _, extra = _fake_state(w)
+    rng = np.random.default_rng(5)
+    n_exp = next(v.shape[0] for k, v in state.items() if k.endswith(".weights"))
+    c = W.SPHERE_CHANNELS
+    state["backbone.composition_embedding.weight"] = T.tensor(rng.standard_normal((W.MAX_NUM_ELEMENTS, c)))
+    state["backbone.routing_mlp.0.weight"] = T.tensor(rng.standard_normal((32, 2 * c)) / np.sqrt(2 * c))
+    state["backbone.routing_mlp.0.bias"] = T.tensor(0.1 * rng.standard_normal(32))
+    state["backbone.routing_mlp.2.weight"] = T.tensor(rng.standard_normal((n_exp, 32)) / 6.0)
+    state["backbone.routing_mlp.2.bias"] = T.tensor(0.1 * rng.standard_normal(n_exp))
+    blob = CK.convert_for_system(state, z, 0, 1, "omol", extra=extra)
+    (tmp_path / "uma-s-1p1.umxw").write_bytes(blob)
+    monkeypatch.setenv("UMX_WEIGHTS_DIR", str(tmp_path))
+    monkeypatch.delenv("UMX_ALLOW_SYNTHETIC", raising=False)
+    calc = U.uma_pysis()                                       # reference defaults: model="uma-s-1p1"
+    x_bohr = (imgs[0] * U.ANG2BOHR).reshape(-1)
+    r = calc.get_forces(elem, x_bohr)
+    from oracle.escn_md_oracle import Oracle
+    merged = W.unpack_blob(blob)
+    e_ref, f_ref = Oracle(merged).energy_forces(z, imgs[0].astype(np.float32).astype(np.float64))
+    assert abs(r["energy"] / U.EV2AU - e_ref) <= 1e-4
+    assert np.abs(r["forces"].reshape(-1, 3) / U.F_EVAA_2_AU - f_ref).max() <= 1e-3
+    # the merged experts differ from the un-routed synthetic set, so this really is the file's physics
+    e_syn = U.uma_pysis(model="synthetic").get_energy(elem, x_bohr)["energy"]
+    assert abs(e_syn - r["energy"]) > 1e-6
+    with pytest.raises(ValueError, match="MoLE-merged for another system"):
+        U.uma_pysis(charge=1).get_energy(elem, x_bohr)
+    with pytest.raises(ValueError, match="composition"):
+        U.uma_pysis().get_energy(elem[:-1], x_bohr[:-3])

@@ -80,6 +80,12 @@ class UMXCalculator(_AseBase):
             self._bound = key
         return self._engine
 
+    def close(self) -> None:
+        """Release the engine (HBM workspace, weights) now; it is rebuilt lazily on the next calculation."""
+        if self._engine is not None:
+            self._engine.close()
+            self._engine, self._bound = None, None
+
     # ---- ASE protocol -------------------------------------------------------------------------------
     def calculate(self, atoms=None, properties: Sequence[str] = ("energy", "forces"), system_changes=all_changes):
         if atoms is None:

@@ -95,6 +95,7 @@ struct umx_engine {
   double refsum = 0.0;
   // workspace
   size_t ws_limit = 0;
+  size_t ws_cap_default = (size_t)160 << 30;
   char* arena = nullptr;
   size_t arena_bytes = 0;
   long cap_nodes = 0, cap_edges = 0;
@@ -765,6 +766,7 @@ int umx_create(umx_engine** out, int device_ordinal) {
   if (const char* ev = std::getenv("UMX_Q3S")) e->q3_stages = std::atoi(ev) == 3 ? 3 : 2;
   if (const char* ev = std::getenv("UMX_FUSE_MODROT")) e->fuse_modrot = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_STREAMS")) e->n_lanes = std::atoi(ev) >= 2 ? 2 : 1;
+  if (const char* ev = std::getenv("UMX_WS_GB")) e->ws_cap_default = (size_t)std::max(0L, std::atol(ev)) << 30;
   e->stream_cap = 512;
   if (const char* ev = std::getenv("UMX_STREAM_BLOCKS")) e->stream_cap = std::max(0, std::atoi(ev)) / 8 * 8;
   if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -1135,6 +1137,13 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
     size_t fr = 0, tot = 0;
     HIPCHK(eng, hipMemGetInfo(&fr, &tot));
     budget = (size_t)((fr + eng->arena_bytes) * 0.85);
+    // default cap (UMX_WS_GB, 0 = none): chunks beyond a few images buy no speed, and an engine that takes
+    // 85 % of the HBM starves every other engine of the process (a second calculator, the FD-Hessian helper, ...)
+    if (eng->ws_cap_default && budget > eng->ws_cap_default) {
+      long emax = 0;
+      for (long k = 0; k < K; ++k) emax = std::max(emax, (long)img_edges[k]);
+      if (carve(nullptr, N, emax, nullptr, eng->pl) <= eng->ws_cap_default) budget = eng->ws_cap_default;   // (a single image larger than the cap keeps the full budget)
+    }
   }
   int lanes = (eng->n_lanes >= 2 && K >= 2 && !eng->dbg_on) ? 2 : 1;      // debug captures name ONE chunk's buffers
   budget /= lanes;

@@ -229,6 +229,22 @@ class uma_pysis(Calculator):
             self._core = UMAcore(elem, **self._core_kw)
         return self._core
 
+    def close(self) -> None:
+        """Release the engine (HBM workspace, weights) now instead of at garbage collection; the calculator can be used
+        again afterwards (the core is rebuilt lazily on the next call)."""
+        if self._core is not None:
+            eng = getattr(self._core, "engine", None)
+            if eng is not None:
+                eng.close()
+            self._core = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def enable_hessian_sharding(self, on: bool = True, group=None) -> None:
         """Deal the FD-Hessian columns over the ranks of `group` (default: the world) -- c4's "freq Hessian (3N force
         batches) on 8 GPUs".  From then on ``get_hessian`` is a COLLECTIVE: every rank of the group must call it with the

@@ -95,6 +95,7 @@ def test_c4_dmf_24_images_one_batched_call(gold):
         assert calc.get_potential_energy(images[k]) == e[k]
         assert np.array_equal(calc.get_forces(images[k]), f[k])
     assert np.abs(f.sum(axis=1)).max() <= 5e-4                                   # Newton's third law, every image
+    calc.close()                                                                 # hand the HBM workspace back (24 images of 2000 atoms)
 
 
 def test_c4_fd_hessian_2000_atoms(gold):
@@ -143,3 +144,38 @@ def test_c4_fd_hessian_2000_atoms(gold):
     assert isinstance(h2, torch.Tensor) and h2.is_cuda and h2.dtype == torch.float32 and tuple(h2.shape) == (66, 66)
     h2 = h2.cpu().numpy().astype(np.float64)
     assert np.abs(h2 - h[np.ix_(act_dof, act_dof)]).max() <= 1e-6 * np.abs(h2).max() + 1e-7
+    calc.close(); calc2.close()
+
+
+def test_c2_gsm_12_images_500_atoms():
+    """BASELINE configs[1]: ~500-atom cluster, GSM with 12 images (max_nodes = 10, path_opt.py:58,171) on one GPU: the batched
+    driver grows the string to 12 images with ONE engine call per cycle, and the images it started from match the c2 golden."""
+    from pdb2reaction_amd.gsm import GrowingStringDriver
+
+    g = load_golden("c2_n500_k2")
+    z, imgs, frozen = synth.make_images(500, 12)
+    assert np.array_equal(imgs[[0, 6]].astype(np.float32), g["pos"])
+    elem = [synth.SYMBOLS[int(q)] for q in z]
+    calc = U.uma_pysis(model="synthetic", freeze_atoms=frozen)
+    calls = []
+    inner = calc.get_forces_batch
+
+    def counted(el, c):
+        calls.append(len(c))
+        return inner(el, c)
+
+    calc.get_forces_batch = counted
+    r, p = (imgs[0] * U.ANG2BOHR).reshape(-1), (imgs[11] * U.ANG2BOHR).reshape(-1)
+    drv = GrowingStringDriver(elem, r, p, calc, gs_kw={"max_nodes": 10, "perp_thresh": 1e3, "climb": False}, stopt_kw={"max_cycles": 8, "max_step": 0.05})
+    res = drv.run()
+    assert res.fully_grown and res.coords.shape == (12, 1500) and np.isfinite(res.energies).all()
+    assert len(calls) <= res.cycles + 1 and max(calls) == 12 and res.force_evaluations == sum(calls)
+    # endpoint energy of the driver == golden energy of c2 image 0 (Hartree vs eV), forces of the frozen atoms are zero
+    assert abs(res.energies[0] / U.EV2AU - g["energy"][0]) <= TOL_E
+    f0 = inner(elem, res.coords[:1])["forces"].reshape(500, 3)
+    assert np.all(f0[frozen] == 0.0)
+    act = np.setdiff1d(np.arange(500), frozen)
+    assert np.abs(f0[act] / U.F_EVAA_2_AU - g["forces"][0][act]).max() <= TOL_F
+    full = [h for h in res.history if h["images"] == 12]
+    assert full and full[-1]["rms_fperp"] <= full[0]["rms_fperp"]
+    calc.close()

@@ -1,0 +1,15 @@
+#!/bin/bash
+set -o pipefail
+R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/j
+for cfg in "UMX_WS_GB=0" "UMX_WS_GB=160" "UMX_WS_GB=96" "UMX_WS_GB=64" "UMX_WS_GB=40"; do
+  tag=$(echo "$cfg" | tr ' =' '__')
+  echo "== bench $cfg" && env $cfg timeout -k 10 300 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-fp32-mode > $R/gpurun_out/j/bench_$tag.log 2>&1 &&
+  python - "$tag" <<'PY'
+import json,sys
+tag=sys.argv[1]
+d=json.loads([l for l in open(f"gpurun_out/j/bench_{tag}.log") if l.startswith("{")][-1])
+r=d["roofline"]
+print(f"   {tag}: {d['ms_per_step']:.1f} ms/step, GEMM {r['ms_per_step']:.1f} ms ({r['launches']} launches), other-gemm {r['other_gemm_family']['ms_per_step']:.1f}, rest {r['hbm_regime']['ms_per_step']:.1f}")
+PY
+done
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q 2>&1 | tee gpurun_out/j/pytest.log | tail -6

@@ -18,7 +18,7 @@ from pdb2reaction_amd.build import source_digest  # noqa: E402  (the build the p
 
 
 def load(d, counter):
-    f = glob.glob(f"{d}/*/*counter_collection.csv")[0]
+    f = (glob.glob(f"{d}/*counter_collection.csv") + glob.glob(f"{d}/*/*counter_collection.csv"))[0]
     agg = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter or "umx::" not in r["Kernel_Name"]:

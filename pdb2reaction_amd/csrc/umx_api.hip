@@ -24,6 +24,7 @@
 #include "umx_gemm_q.h"
 #include "umx_kernels_pl.h"
 #include "umx_kernels.h"
+#include "umx_radial.h"
 
 using namespace umx;
 
@@ -57,6 +58,8 @@ struct umx_engine {
   hipStream_t stream2 = nullptr;   // second lane: half-chunks alternate streams so HBM-bound producers overlap the other lane's GEMMs
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev_tok[2] = {nullptr, nullptr};   // matrix-pipe token of the two lanes (run_plans_alternating)
+  int radial_fast = 0;             // UMX_RADIAL_FAST: transcendentals inside the fused radial kernels: 0 libm, 1 raw hardware, 2 refined hardware (umx_radial.h)
+  bool fused_radial = true;        // UMX_FUSED_RADIAL=0: the radial MLP's small layers as separate GEMM / LayerNorm launches (umx_radial.h fuses them)
   int q3_stages = 2;               // UMX_Q3S: LDS ring depth of the forward Q3 GEMMs (2 or 3)
   bool q3_wide = true;             // UMX_Q3WIDE=0 (dev): 256x128 tiles for every forward GEMM
   bool q3 = true;                  // UMX_Q3=0: forward operands in the 32-column PL layout + 256x128 tiles (set before umx_load_weights)
@@ -346,6 +349,26 @@ int dbg_capture(umx_engine* eng, const std::string& name, const void* dptr, size
 // the two-lane executor can treat the large GEMM as a matrix-pipe segment (see Plan below).
 int radial_fwd_head(umx_engine* eng, const WS& w, const RadialW& r, int slot, long ne) {
   hipStream_t s = eng->stream;
+  const bool planes = eng->pl && eng->planes.count(r.w3);
+  if (eng->fused_radial && (!planes || eng->q3)) {
+    // one persistent kernel: gaussians -> fc1 -> LN+SiLU -> fc2 -> LN+SiLU -> fc3 operand (Q3 planes, or fp32 rows in w.ra)
+    const unsigned tiles = nblk(ne, RT);
+    const dim3 grid(vgrid(eng, tiles < 512u ? tiles : 512u));
+#define UMX_RH_ARGS grid, dim3(256), 0, s, w.evec, w.ez, eng->gcoef, eng->d_gmu, r.w1g, r.ts, r.tt, r.ln1w, r.ln1b, r.w2, r.b2, r.ln2w, r.ln2b, w.h1pre[slot], w.h2pre[slot]
+    const int fm = eng->radial_fast;
+    if (planes) {
+      if (fm == 2) hipLaunchKernelGGL((k_radial_head<true, 2>), UMX_RH_ARGS, (void*)w.a2pl, ne);
+      else if (fm == 1) hipLaunchKernelGGL((k_radial_head<true, 1>), UMX_RH_ARGS, (void*)w.a2pl, ne);
+      else hipLaunchKernelGGL((k_radial_head<true, 0>), UMX_RH_ARGS, (void*)w.a2pl, ne);
+    } else {
+      if (fm == 2) hipLaunchKernelGGL((k_radial_head<false, 2>), UMX_RH_ARGS, (void*)w.ra, ne);
+      else if (fm == 1) hipLaunchKernelGGL((k_radial_head<false, 1>), UMX_RH_ARGS, (void*)w.ra, ne);
+      else hipLaunchKernelGGL((k_radial_head<false, 0>), UMX_RH_ARGS, (void*)w.ra, ne);
+    }
+#undef UMX_RH_ARGS
+    HIPCHK(eng, hipGetLastError());
+    return UMX_OK;
+  }
   GemmP p = gp_zero();
   p.evec = w.evec; p.gcoef = eng->gcoef; p.gmu = eng->d_gmu; p.B = r.w1g; p.ldb = NG; p.Cp = w.h1pre[slot]; p.ldc = RH;
   p.TS = r.ts; p.TT = r.tt; p.ez = w.ez;
@@ -377,6 +400,18 @@ int radial_bwd_fc3(umx_engine* eng, const WS& w, const RadialW& r, long ne, cons
 }
 int radial_bwd_tail(umx_engine* eng, const WS& w, const RadialW& r, int slot, long ne) {
   hipStream_t s = eng->stream;
+  if (eng->fused_radial) {
+    // one persistent kernel: LN+SiLU bwd -> fc2^T -> LN+SiLU bwd -> fc1^T -> dE/dd through the gaussians (accumulated into dedd)
+    const unsigned tiles = nblk(ne, RT);
+    const dim3 grid(vgrid(eng, tiles < 512u ? tiles : 512u));
+#define UMX_RT_ARGS grid, dim3(256), 0, s, w.e128a, w.h2pre[slot], w.h1pre[slot], w.evec, eng->gcoef, eng->d_gmu, r.ln2w, r.ln2b, r.ln1w, r.ln1b, r.w2T, r.w1gT, w.dedd, ne
+    if (eng->radial_fast == 2) hipLaunchKernelGGL(k_radial_tail<2>, UMX_RT_ARGS);
+    else if (eng->radial_fast == 1) hipLaunchKernelGGL(k_radial_tail<1>, UMX_RT_ARGS);
+    else hipLaunchKernelGGL(k_radial_tail<0>, UMX_RT_ARGS);
+#undef UMX_RT_ARGS
+    HIPCHK(eng, hipGetLastError());
+    return UMX_OK;
+  }
   hipLaunchKernelGGL(k_ln_silu_bwd, dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.e128a, w.h2pre[slot], r.ln2w, r.ln2b, w.e128b, ne);
   CHK(gemm_plain(eng, w.e128b, RH, 0, r.w2T, RH, nullptr, w.e128a, RH, 0, ne, RH, RH));
   hipLaunchKernelGGL(k_ln_silu_bwd, dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.e128a, w.h1pre[slot], r.ln1w, r.ln1b, w.e128b, ne);
@@ -763,6 +798,8 @@ int umx_create(umx_engine** out, int device_ordinal) {
   if (const char* ev = std::getenv("UMX_WIDE")) e->wide_tiles = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_Q3")) e->q3 = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_Q3WIDE")) e->q3_wide = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("UMX_RADIAL_FAST")) e->radial_fast = std::max(0, std::min(2, std::atoi(ev)));
+  if (const char* ev = std::getenv("UMX_FUSED_RADIAL")) e->fused_radial = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_Q3S")) e->q3_stages = std::atoi(ev) == 3 ? 3 : 2;
   if (const char* ev = std::getenv("UMX_FUSE_MODROT")) e->fuse_modrot = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_STREAMS")) e->n_lanes = std::atoi(ev) >= 2 ? 2 : 1;

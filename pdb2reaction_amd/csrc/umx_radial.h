@@ -1,0 +1,310 @@
+// umx_radial.h -- the small layers of the radial MLP as ONE kernel per direction (gfx950).
+//
+// RadialMLP(x_edge) = fc3( SiLU(LN( fc2( SiLU(LN( fc1(x_edge) )) ) )) ),  x_edge = [64 gaussians of d | emb(Z_src) | emb(Z_dst)].
+// fc3 (128 -> 1536, the large GEMM) stays on the split-bf16 path; everything in front of it -- and, in the reverse pass,
+// everything behind fc3^T -- used to be 4 / 5 launches with an HBM round trip of a 128-float row between each of them:
+//     forward  gaussians+fc1 (fp32 GEMM) -> LN+SiLU -> fc2 (fp32 GEMM) -> LN+SiLU+split          1.55 ms per 8-image c3 chunk
+//     reverse  LN+SiLU bwd -> fc2^T (fp32 GEMM) -> LN+SiLU bwd -> fc1^T (fp32 GEMM) -> d/dd dot   1.8 ms
+// Both chains are row-local (a 128-float row per edge), so here a workgroup keeps a 64-edge tile in LDS from the gaussians to the
+// fc3 operand (forward) and from fc3^T's output to the scalar dE/dd (reverse).  The weights (128x64 and 128x128 fp32) live in
+// REGISTERS: wave w owns output columns [32w, 32w+32) of both linears, and a lane holds, for its column, the k-values its
+// v_mfma_f32_32x32x2_f32 operand slots need (lane-half h supplies k = 8c + 4h + r, as in umx_gemm.h) -- 96 / 128 VGPRs, loaded once
+// per (persistent) workgroup.  LDS holds only activations: two 64 x 132-float buffers (row pad 4 floats: the 16-lane groups of
+// ds_read_b128 hit 16 distinct 4-bank slots).  Arithmetic is the fp32 MFMA's (exact fp32 fma chains), i.e. what umx_gemm_kernel does.
+// HBM traffic per edge: forward 20 B in, 1024 B (h1pre, h2pre for the reverse pass) + 768 B (Q3 planes) out; reverse 1.5 KB in, 4 B out.
+#pragma once
+#include "umx_common.h"
+#include "umx_gemm.h"
+#include "umx_kernels_pl.h"
+
+namespace umx {
+
+constexpr int RT = 64;         // edges per tile
+constexpr int R_LD = 132;      // padded LDS row of a 128-wide activation tile (floats)
+constexpr int R_LDG = 68;      // padded LDS row of the 64-wide gaussian tile
+
+// Wave-wide sum on the VALU (DPP) instead of six dependent ds_bpermute round trips: these kernels run at two waves per SIMD, so the
+// ~600-cycle latency of a __shfl_xor butterfly is NOT hidden by other waves (measured: the LayerNorm passes took as long as the MFMAs).
+// quad_perm / row_ror adds leave every lane with the sum of its 16-lane row; the four row sums are combined through v_readlane.
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
+  return v + __builtin_bit_cast(float, moved);
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);       // quad_perm:[1,0,3,2]
+  v = dpp_add<0x4E>(v);       // quad_perm:[2,3,0,1]
+  v = dpp_add<0x124>(v);      // row_ror:4
+  v = dpp_add<0x128>(v);      // row_ror:8
+  return v;
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  const int r = __builtin_bit_cast(int, row16_sum(v));
+  return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 16))) +
+         (__builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 48)));
+}
+
+// Transcendentals (template parameter FAST = UMX_RADIAL_FAST): these kernels are VALU-bound on exactly these functions (two
+// SiLU + one rsqrt per element pair and LayerNorm row, 64 gaussians per edge).
+// MODE 0: libm-accurate (umx_common.h policy).  MODE 1: hardware approximations as they are.  MODE 2: hardware instructions with
+// the argument reduced / the result refined so that each function is accurate to about 1 ulp without the libm call sequences:
+// exp by Cody-Waite reduction to |r| <= ln2/2 before v_exp_f32 (the plain v_exp_f32(x * log2e) form loses absolute accuracy in the
+// product for large |x|), reciprocal and reciprocal square root by one Newton step on v_rcp_f32 / v_rsq_f32.
+template <int FAST> __device__ __forceinline__ float r_exp(float x) {
+  if (FAST == 0) return expf(x);
+  if (FAST == 1) return __expf(x);
+  const float n = rintf(x * 1.44269504088896341f);
+  float r = fmaf(n, -0.693145751953125f, x);            // ln2 split hi / lo (hi has 11 trailing zero bits: n * hi is exact)
+  r = fmaf(n, -1.42860682030941723e-6f, r);
+  return ldexpf(__expf(r), (int)n);
+}
+template <int FAST> __device__ __forceinline__ float r_rcp(float x) {
+  if (FAST == 0) return 1.0f / x;
+  float y = __frcp_rn(x);
+  if (FAST == 2) y = fmaf(fmaf(-x, y, 1.0f), y, y);
+  return y;
+}
+template <int FAST> __device__ __forceinline__ float r_rsqrt(float x) {
+  if (FAST == 0) return 1.0f / sqrtf(x);
+  float y = __frsqrt_rn(x);
+  if (FAST == 2) y = fmaf(fmaf(-0.5f * x * y, y, 0.5f), y, y);
+  return y;
+}
+template <int FAST> __device__ __forceinline__ float r_sigmoid(float x) { return r_rcp<FAST>(1.0f + r_exp<FAST>(-x)); }
+template <int FAST> __device__ __forceinline__ float r_silu(float x) { return x * r_sigmoid<FAST>(x); }
+template <int FAST> __device__ __forceinline__ float r_silu_grad(float x) {
+  const float sg = r_sigmoid<FAST>(x);
+  return sg * (1.0f + x * (1.0f - sg));
+}
+
+// LayerNorm(128) + SiLU of one row held as 2 values per lane (the arithmetic of k_ln_silu_fwd)
+template <int FAST>
+__device__ __forceinline__ float2 ln_silu_row(float2 v, float2 ww, float2 bb) {
+  const float mu = wave_sum_dpp(v.x + v.y) * (1.0f / RH);
+  v.x -= mu; v.y -= mu;
+  const float var = wave_sum_dpp(v.x * v.x + v.y * v.y) * (1.0f / RH);
+  const float rstd = r_rsqrt<FAST>(var + LN_EPS);
+  return make_float2(r_silu<FAST>(v.x * rstd * ww.x + bb.x), r_silu<FAST>(v.y * rstd * ww.y + bb.y));
+}
+// backward of it (the arithmetic of k_ln_silu_bwd): go = dE/d(output), v = the pre-LayerNorm row
+template <int FAST>
+__device__ __forceinline__ float2 ln_silu_row_bwd(float2 go, float2 v, float2 ww, float2 bb) {
+  const float mu = wave_sum_dpp(v.x + v.y) * (1.0f / RH);
+  v.x -= mu; v.y -= mu;
+  const float var = wave_sum_dpp(v.x * v.x + v.y * v.y) * (1.0f / RH);
+  const float rstd = r_rsqrt<FAST>(var + LN_EPS);
+  const float xh0 = v.x * rstd, xh1 = v.y * rstd;
+  const float gw0 = go.x * r_silu_grad<FAST>(xh0 * ww.x + bb.x) * ww.x;
+  const float gw1 = go.y * r_silu_grad<FAST>(xh1 * ww.y + bb.y) * ww.y;
+  const float m1 = wave_sum_dpp(gw0 + gw1) * (1.0f / RH);
+  const float m2 = wave_sum_dpp(gw0 * xh0 + gw1 * xh1) * (1.0f / RH);
+  return make_float2(rstd * (gw0 - m1 - xh0 * m2), rstd * (gw1 - m1 - xh1 * m2));
+}
+
+// acc[i] += A[rows i*32 + l31][k] . W[col][k] over NC chunks of 8 k-values; A in LDS (row pitch LD), W in registers
+template <int NC, int LD>
+__device__ __forceinline__ void rad_mma(const float* __restrict__ a_lds, const float4 (&wr)[NC], f32x16 (&acc)[2], int l31, int h) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    float4 a[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(a_lds + (i * 32 + l31) * LD + c * 8 + 4 * h);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, wr[c].x, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, wr[c].y, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, wr[c].z, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, wr[c].w, acc[i], 0, 0, 0);
+    }
+  }
+}
+
+// ---- forward: d, Z_src, Z_dst  ->  h1pre, h2pre (kept for the reverse pass) and the fc3 operand --------------------------------
+// OUTQ3 = true: the fc3 operand as Q3 bf16 planes (umx_gemm_q.h);  false: fp32 rows (fp32 precision mode, and the edge-degree MLP
+// whose fc3 runs on the fp32 GEMM).   ts / tt: per-element tables of the embedding part of fc1 (tt includes the fc1 bias).
+template <bool OUTQ3, int FAST>
+__global__ __launch_bounds__(256, 2) void k_radial_head(const float* __restrict__ evec, const int* __restrict__ ez, float gcoef,
+                                                        const float* __restrict__ gmu, const float* __restrict__ w1g,
+                                                        const float* __restrict__ ts, const float* __restrict__ tt,
+                                                        const float* __restrict__ ln1w, const float* __restrict__ ln1b,
+                                                        const float* __restrict__ w2, const float* __restrict__ b2,
+                                                        const float* __restrict__ ln2w, const float* __restrict__ ln2b,
+                                                        float* __restrict__ h1pre, float* __restrict__ h2pre, void* __restrict__ out, long ne) {
+  __shared__ __attribute__((aligned(16))) float bufA[RT * R_LD];
+  __shared__ __attribute__((aligned(16))) float bufB[RT * R_LD];
+  __shared__ float dbuf[RT];
+  __shared__ int zbuf[RT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int col = wave * 32 + l31;                   // the output column this lane owns in both linears
+  float4 W1[NG / 8], W2[RH / 8];
+#pragma unroll
+  for (int c = 0; c < NG / 8; ++c) W1[c] = *reinterpret_cast<const float4*>(w1g + col * NG + c * 8 + 4 * h);
+#pragma unroll
+  for (int c = 0; c < RH / 8; ++c) W2[c] = *reinterpret_cast<const float4*>(w2 + col * RH + c * 8 + 4 * h);
+  const float bias2 = b2[col];
+  const float2 l1w = *reinterpret_cast<const float2*>(ln1w + 2 * lane), l1b = *reinterpret_cast<const float2*>(ln1b + 2 * lane);
+  const float2 l2w = *reinterpret_cast<const float2*>(ln2w + 2 * lane), l2b = *reinterpret_cast<const float2*>(ln2b + 2 * lane);
+  const long ntiles = (ne + RT - 1) / RT;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long e0 = tile * RT;
+    __syncthreads();                                 // the previous tile's buffers are free
+    if (tid < RT) {
+      const long e = e0 + tid < ne ? e0 + tid : ne - 1;
+      dbuf[tid] = evec[e * 4 + 3];
+      zbuf[tid] = ez[e];
+    }
+    __syncthreads();
+    {   // gaussian basis of the tile -> bufA as [64][R_LDG]
+      const int row = tid >> 2, c0 = (tid & 3) * 16;
+      const float d = dbuf[row];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 mu = *reinterpret_cast<const float4*>(gmu + c0 + 4 * q);
+        float4 v; float t;
+        t = d - mu.x; v.x = r_exp<FAST>(gcoef * t * t);
+        t = d - mu.y; v.y = r_exp<FAST>(gcoef * t * t);
+        t = d - mu.z; v.z = r_exp<FAST>(gcoef * t * t);
+        t = d - mu.w; v.w = r_exp<FAST>(gcoef * t * t);
+        *reinterpret_cast<float4*>(bufA + row * R_LDG + c0 + 4 * q) = v;
+      }
+    }
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    rad_mma<NG / 8, R_LDG>(bufA, W1, acc, l31, h);
+    // epilogue 1: the raw fc1 tile to bufB; the row pass below adds the element tables, writes h1pre (whole 512-B rows) and normalises
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bufB[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * R_LD + col] = acc[i][r];
+    __syncthreads();
+#pragma unroll 2
+    for (int rr = 0; rr < RT / 4; ++rr) {            // wave w owns rows 16w .. 16w+15: + tables, h1pre out, LN + SiLU in place
+      const int row = wave * (RT / 4) + rr;
+      const int zz = zbuf[row];
+      float* p = bufB + row * R_LD + 2 * lane;
+      float2 v = *reinterpret_cast<const float2*>(p);
+      const float2 a = *reinterpret_cast<const float2*>(ts + (zz & 0xffff) * RH + 2 * lane);
+      const float2 b = *reinterpret_cast<const float2*>(tt + (zz >> 16) * RH + 2 * lane);
+      v.x += a.x + b.x; v.y += a.y + b.y;
+      if (e0 + row < ne) *reinterpret_cast<float2*>(h1pre + (e0 + row) * RH + 2 * lane) = v;
+      *reinterpret_cast<float2*>(p) = ln_silu_row<FAST>(v, l1w, l1b);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    rad_mma<RH / 8, R_LD>(bufB, W2, acc, l31, h);
+    // epilogue 2: fc2 tile + bias to bufA (the gaussian tile is dead: every wave passed the barriers behind fc1)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bufA[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * R_LD + col] = acc[i][r] + bias2;
+    __syncthreads();
+#pragma unroll 2
+    for (int rr = 0; rr < RT / 4; ++rr) {            // h2pre out, LN + SiLU -> the fc3 operand
+      const int row = wave * (RT / 4) + rr;
+      const long e = e0 + row;
+      const float2 v = *reinterpret_cast<const float2*>(bufA + row * R_LD + 2 * lane);
+      const float2 o = ln_silu_row<FAST>(v, l2w, l2b);
+      if (e < ne) {
+        *reinterpret_cast<float2*>(h2pre + e * RH + 2 * lane) = v;
+        if (OUTQ3) q3_store2(reinterpret_cast<unsigned short*>(out), e, RH, 2 * lane, o.x, o.y);
+        else *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + e * RH + 2 * lane) = o;
+      }
+    }
+  }
+}
+
+// ---- reverse: dE/d(fc3 operand) -> dE/dd (accumulated into dedd) ------------------------------------------------------------------
+// ga2 = output of the fc3^T GEMM; w2T = W2^T ([k][j]), w1gT = W1g^T ([64 gaussians][128]).
+template <int FAST>
+__global__ __launch_bounds__(256, 2) void k_radial_tail(const float* __restrict__ ga2, const float* __restrict__ h2pre,
+                                                        const float* __restrict__ h1pre, const float* __restrict__ evec, float gcoef,
+                                                        const float* __restrict__ gmu, const float* __restrict__ ln2w,
+                                                        const float* __restrict__ ln2b, const float* __restrict__ ln1w,
+                                                        const float* __restrict__ ln1b, const float* __restrict__ w2T,
+                                                        const float* __restrict__ w1gT, float* __restrict__ dedd, long ne) {
+  __shared__ __attribute__((aligned(16))) float bufA[RT * R_LD];
+  __shared__ __attribute__((aligned(16))) float bufB[RT * R_LD];
+  __shared__ float dbuf[RT];
+  __shared__ float part[2][RT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int col = wave * 32 + l31;
+  const int gi = wave >> 1, gj = wave & 1;           // last linear (128 -> 64): wave -> (row tile, column tile)
+  float4 W2T[RH / 8], W1T[RH / 8];
+#pragma unroll
+  for (int c = 0; c < RH / 8; ++c) W2T[c] = *reinterpret_cast<const float4*>(w2T + col * RH + c * 8 + 4 * h);
+#pragma unroll
+  for (int c = 0; c < RH / 8; ++c) W1T[c] = *reinterpret_cast<const float4*>(w1gT + (gj * 32 + l31) * RH + c * 8 + 4 * h);
+  const float2 l1w = *reinterpret_cast<const float2*>(ln1w + 2 * lane), l1b = *reinterpret_cast<const float2*>(ln1b + 2 * lane);
+  const float2 l2w = *reinterpret_cast<const float2*>(ln2w + 2 * lane), l2b = *reinterpret_cast<const float2*>(ln2b + 2 * lane);
+  const float mu_col = gmu[gj * 32 + l31];
+  const long ntiles = (ne + RT - 1) / RT;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long e0 = tile * RT;
+    __syncthreads();
+    if (tid < RT) dbuf[tid] = evec[(e0 + tid < ne ? e0 + tid : ne - 1) * 4 + 3];
+#pragma unroll 4
+    for (int rr = 0; rr < RT / 4; ++rr) {            // LN2 + SiLU backward: g_h2 -> bufA
+      const int row = wave * (RT / 4) + rr;
+      const long e = e0 + row < ne ? e0 + row : ne - 1;
+      const float2 go = *reinterpret_cast<const float2*>(ga2 + e * RH + 2 * lane);
+      const float2 x = *reinterpret_cast<const float2*>(h2pre + e * RH + 2 * lane);
+      *reinterpret_cast<float2*>(bufA + row * R_LD + 2 * lane) = ln_silu_row_bwd<FAST>(go, x, l2w, l2b);
+    }
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    rad_mma<RH / 8, R_LD>(bufA, W2T, acc, l31, h);   // g_a1 = g_h2 . W2
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bufB[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * R_LD + col] = acc[i][r];
+    __syncthreads();
+#pragma unroll 4
+    for (int rr = 0; rr < RT / 4; ++rr) {            // LN1 + SiLU backward: g_h1 -> bufA (its fc2^T reads finished at the barrier above)
+      const int row = wave * (RT / 4) + rr;
+      const long e = e0 + row < ne ? e0 + row : ne - 1;
+      const float2 go = *reinterpret_cast<const float2*>(bufB + row * R_LD + 2 * lane);
+      const float2 x = *reinterpret_cast<const float2*>(h1pre + e * RH + 2 * lane);
+      *reinterpret_cast<float2*>(bufA + row * R_LD + 2 * lane) = ln_silu_row_bwd<FAST>(go, x, l1w, l1b);
+    }
+    __syncthreads();
+    {   // g_gauss = g_h1 . W1g (128 -> 64): one 32 x 32 tile per wave, then dE/dd = sum_k g_gauss[k] d/dd exp(gcoef (d - mu_k)^2)
+      f32x16 a1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[r] = 0.f;
+#pragma unroll
+      for (int c = 0; c < RH / 8; ++c) {
+        const float4 a = *reinterpret_cast<const float4*>(bufA + (gi * 32 + l31) * R_LD + c * 8 + 4 * h);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, W1T[c].x, a1, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, W1T[c].y, a1, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, W1T[c].z, a1, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, W1T[c].w, a1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = gi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float t = dbuf[row] - mu_col;
+        // sum over the 32 columns of this half-wave (two 16-lane rows), for both halves at once
+        const int rs = __builtin_bit_cast(int, row16_sum(a1[r] * r_exp<FAST>(gcoef * t * t) * 2.0f * gcoef * t));
+        const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rs, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(rs, 16));
+        const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rs, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(rs, 48));
+        if (lane == 0) { part[gj][row] = s0; part[gj][row + 4] = s1; }      // lane 0 sees h = 0: `row` is the first half's row, +4 the second's
+      }
+    }
+    __syncthreads();
+    if (tid < RT && e0 + tid < ne) dedd[e0 + tid] += part[0][tid] + part[1][tid];
+  }
+}
+
+}  // namespace umx

@@ -1,0 +1,15 @@
+#!/bin/bash
+set -o pipefail
+R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/k
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_sizes.py -x -q -k "engine_matches or precision_modes or stage_by_stage or c3_energy or charge_spin or golden or c3_energy_and_forces" 2>&1 | tail -4 &&
+for cfg in "UMX_FUSED_RADIAL=0" "UMX_FUSED_RADIAL=1" "UMX_FUSED_RADIAL=0" "UMX_FUSED_RADIAL=1"; do
+  tag=$(echo "$cfg" | tr ' =' '__')
+  echo "== bench $cfg" && env $cfg timeout -k 10 300 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-fp32-mode > $R/gpurun_out/k/bench_$tag.log 2>&1 &&
+  python - "$tag" <<'PY'
+import json,sys
+tag=sys.argv[1]
+d=json.loads([l for l in open(f"gpurun_out/k/bench_{tag}.log") if l.startswith("{")][-1])
+r=d["roofline"]
+print(f"   {tag}: {d['ms_per_step']:.1f} ms/step, GEMM {r['ms_per_step']:.1f} ms, other-gemm {r['other_gemm_family']['ms_per_step']:.1f}, rest {r['hbm_regime']['ms_per_step']:.1f}")
+PY
+done

@@ -93,6 +93,10 @@ int main(int argc, char** argv) {
     for (size_t o = 0; o < (size_t)Mp * K * 6; o += h.size() * 2) CK(hipMemcpy(Aq + o, h.data(), std::min(h.size() * 2, (size_t)Mp * K * 6 - o), hipMemcpyHostToDevice));
     CK(hipMemcpy(Bq, h.data() + 17, (size_t)N * K * 6, hipMemcpyHostToDevice));
   }
+  if (getenv("ZERO")) {   // DVFS check: the same kernel on all-zero operands (less switching power -> higher clock, MI355X_MICROARCH.md give-back item 1)
+    CK(hipMemset(Aq, 0, (size_t)Mp * K * 6)); CK(hipMemset(Bq, 0, (size_t)N * K * 6));
+    printf("operands: ALL ZERO\n");
+  }
   const long n4 = (long)(copy_gb * 1e9 / 16);
   float4 *src, *dst;
   CK(hipMalloc(&src, n4 * 16)); CK(hipMalloc(&dst, n4 * 16)); CK(hipMemset(src, 1, n4 * 16));

@@ -260,7 +260,7 @@ def main():
         # second regime: the HBM-bound gather / rotate / gate / segmented-reduce kernels = everything outside the
         # two GEMM families; time measured live, bytes from the PMC summary of this exact build (or omitted)
         rest_ms = ms - (dom["ms"] + (f32["ms"] if split else 0.0)) / args.steps
-        hb = {"bound": "hbm", "kernels": "all non-GEMM kernels (k_gather_rotate_mod_q3, k_modrot_bwd_pl, k_gate_edge_*, k_rotate_back_*, ...)",
+        hb = {"bound": "hbm", "kernels": "everything outside the two GEMM families: HBM-bound edge kernels (k_gather_rotate_mod_q3, k_modrot_bwd_pl, k_gate_edge_*, k_rotate_back_*) + the fused radial-MLP kernels (k_radial_head/tail, VALU/fp32-MFMA bound, ~26 ms) + node-level kernels",
               "ms_per_step": rest_ms, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "traffic_per_step": None, "achieved": None, "frac": None,
               "traffic_source": pmc_note}
         if pmc:

@@ -85,6 +85,20 @@ int umx_energy_forces(umx_engine* eng, int n_images, const float* pos_ang, doubl
 int umx_energy_forces_dev(umx_engine* eng, int n_images, const float* d_pos_ang,
                           double* d_energy_ev, float* d_forces_ev_ang, void* hip_stream);
 
+/* Graph-parallel evaluation of ONE image across several engines / ranks (ABI v5) -- the reference's `workers > 1` semantics
+ * (ParallelMLIPPredictUnit: the atoms' graph partitioned over workers, uma_pysis.py:220-242), for single large systems when there are
+ * fewer images than GPUs.  Every rank passes the FULL positions; rank r builds the incoming edges of the
+ * target nodes [node_lo, node_hi) only and runs the edge pipeline on them; node-level work is replicated.  The evaluation is a
+ * sequence of segments separated by EXCHANGE POINTS at which a float32 device buffer holds this rank's partial sums over its own
+ * edges: umx_gp_step issues segments until the next exchange point and reports the buffer; the caller sums it over the ranks IN PLACE
+ * (RCCL all-reduce on the same stream, or any other collective) and calls umx_gp_step again, until *done = 1.  Exchange points:
+ * the edge-degree aggregate, one node aggregate per layer (forward), one node gradient per layer (reverse) and the forces --
+ * 9 all-reduces of n_atoms*1152 floats and one of n_atoms*3.  Energies are complete on every rank (node-level work is replicated);
+ * forces are complete after the last all-reduce.  Default split-precision path only.                                          */
+int umx_gp_begin(umx_engine* eng, const float* d_pos_ang, int node_lo, int node_hi, double* d_energy_ev,
+                 float* d_forces_ev_ang, void* hip_stream);
+int umx_gp_step(umx_engine* eng, float** d_buf, size_t* count, int* done);
+
 /* Block until all work enqueued by this engine has finished (including work it put on a
  * caller's stream through umx_energy_forces_dev).                                              */
 int umx_synchronize(umx_engine* eng);

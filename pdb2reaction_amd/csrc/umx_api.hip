@@ -70,6 +70,12 @@ struct umx_engine {
   int stream_cap = 0;              // UMX_STREAM_BLOCKS: two-lane mode caps the grids of the grid-stride streaming kernels at this many
                                    // workgroups (multiple of 8; default 512 = two per CU) so they run BESIDE the other lane's GEMM
   bool throttle = false;           // set while a two-lane evaluation is being issued
+  // graph-parallel single-image mode (umx_gp_begin / umx_gp_step): this rank builds the incoming edges of targets [gp_lo, gp_hi)
+  bool gp = false; long gp_lo = 0, gp_hi = 0;
+  void* gp_plan = nullptr;         // Plan* of the evaluation in progress (opaque here: Plan is defined below)
+  size_t gp_at = 0;
+  hipStream_t gp_stream = nullptr;
+  void* gp_ws = nullptr;           // WS* kept alive between the steps
   std::string err;
   // weights
   bool have_weights = false;
@@ -441,11 +447,14 @@ int so3_linear(umx_engine* eng, const float* A, const float* Wl, const float* bi
 // TOKEN from matrix segment to matrix segment across the lanes (events), so that at any time at most one lane occupies the
 // matrix pipe while the other lane's stream segments run beside it on the same CUs -- the two bounds (MFMA and HBM)
 // overlap instead of adding up.
-struct Seg { bool matrix; std::function<int()> fn; };
+struct Seg { bool matrix; std::function<int()> fn; float* sync_buf = nullptr; size_t sync_count = 0; };
 struct Plan {
   std::vector<Seg> segs;
   void stream(std::function<int()> f) { segs.push_back({false, std::move(f)}); }
   void matrix(std::function<int()> f) { segs.push_back({true, std::move(f)}); }
+  // graph-parallel single-image mode: an exchange point -- the buffer holds this rank's partial sums over ITS edges and must be
+  // summed over the ranks (all-reduce, done by the caller between two umx_gp_step calls) before the next segment runs
+  void sync(float* buf, size_t count) { Seg sg{false, nullptr}; sg.sync_buf = buf; sg.sync_count = count; segs.push_back(std::move(sg)); }
 };
 
 void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, const int* d_cand, long nimg, long ne, double* d_energy,
@@ -455,12 +464,14 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
   const float rc2 = eng->cutoff * eng->cutoff;
   const dim3 B256(256);
   const bool pl = eng->pl;
+  const bool gp = eng->gp;                                       // graph-parallel: partial sums over this rank's edges + exchange points
+  const long g_lo = gp ? eng->gp_lo : 0, g_hi = gp ? eng->gp_hi : nn;
   // every closure reads eng->stream when it RUNS (the executor points it at the lane's stream)
   // K1 graph, K4 + K5
   P.stream([=, &w]() -> int {
     hipStream_t s = eng->stream;
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, d_deg, nn, w.row_ptr, w.stats);
-    hipLaunchKernelGGL(k_graph_fill, dim3(nblk(nn, 4)), B256, 0, s, d_pos, N, nn, rc2, eng->max_neigh, d_cand, w.row_ptr, w.esrc, w.edst, w.evec);
+    hipLaunchKernelGGL(k_graph_fill, dim3(nblk(nn, 4)), B256, 0, s, d_pos, N, nn, rc2, eng->max_neigh, d_cand, w.row_ptr, w.esrc, w.edst, w.evec, g_lo, g_hi);
     HIPCHK(eng, hipMemsetAsync(w.out_cur, 0, (nn + 1) * sizeof(int), s));
     if (ne > 0) hipLaunchKernelGGL(k_out_count, dim3(nblk(ne, 256)), B256, 0, s, w.esrc, ne, w.out_cur);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, w.out_cur, nn, w.out_ptr, w.stats + 2);
@@ -476,12 +487,21 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
     DBG("evec", w.evec, ne * 4); DBG("frame", w.frame, ne * FRAME);
     hipLaunchKernelGGL(k_node_init, dim3(nblk(nn * ROW, 256)), B256, 0, s, eng->d_z, N, nn, eng->emb_sphere, eng->d_sysemb, w.xs[0]);
     if (ne > 0) CHK(radial_fwd(eng, w, eng->rdeg, NL, ne, w.rad_deg));
-    hipLaunchKernelGGL(k_rotate_back_reduce<3>, dim3(nblk(nn, 4)), B256, 0, s, w.rad_deg, w.frame, w.row_ptr, w.xs[0], w.xs[0], nn,
-                       1.0f / DEG_RESCALE);
+    // x0 = node init + sum over incoming edges; graph-parallel: the bare partial sum goes to G1 and is all-reduced first
+    hipLaunchKernelGGL(k_rotate_back_reduce<3>, dim3(nblk(nn, 4)), B256, 0, s, w.rad_deg, w.frame, w.row_ptr, gp ? (const float*)nullptr : w.xs[0],
+                       gp ? w.G1 : w.xs[0], nn, 1.0f / DEG_RESCALE);
     HIPCHK(eng, hipGetLastError());
-    DBG("rad.deg", w.rad_deg, ne * 3 * C); DBG("x0", w.xs[0], nn * ROW);
+    if (!gp) { DBG("rad.deg", w.rad_deg, ne * 3 * C); DBG("x0", w.xs[0], nn * ROW); }
     return UMX_OK;
   });
+  if (gp) {
+    P.sync(w.G1, (size_t)nn * ROW);
+    P.stream([=, &w]() -> int {
+      hipLaunchKernelGGL(k_add_rows, dim3(nblk(nn * ROW / 4, 256)), B256, 0, eng->stream, w.xs[0], w.xs[0], w.G1, nn * ROW / 4);
+      HIPCHK(eng, hipGetLastError());
+      return UMX_OK;
+    });
+  }
 
   for (int i = 0; i < NL; ++i) {
     const LayerW* Lp = &eng->lw[i];
@@ -547,11 +567,20 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
         return UMX_OK;
       });
     }
+    if (gp) {      // partial aggregate of this rank's edges -> xn2 (free until the norm below), all-reduce, xmid = xin + sum
+      P.stream([=, &w]() -> int {
+        hipLaunchKernelGGL(k_rotate_back_reduce<9>, dim3(nblk(nn, 4)), B256, 0, eng->stream, w.msg[i], w.frame, w.row_ptr, (const float*)nullptr, w.xn2, nn, 1.0f);
+        HIPCHK(eng, hipGetLastError());
+        return UMX_OK;
+      });
+      P.sync(w.xn2, (size_t)nn * ROW);
+    }
     P.stream([=, &w]() -> int {
       hipStream_t s = eng->stream;
       const LayerW& L = *Lp;
       const std::string t = "." + std::to_string(i);
-      hipLaunchKernelGGL(k_rotate_back_reduce<9>, dim3(vgrid(eng, nblk(nn, 4))), B256, 0, s, w.msg[i], w.frame, w.row_ptr, xin, xmid, nn, 1.0f);
+      if (gp) hipLaunchKernelGGL(k_add_rows, dim3(nblk(nn * ROW / 4, 256)), B256, 0, s, xmid, xin, w.xn2, nn * ROW / 4);
+      else hipLaunchKernelGGL(k_rotate_back_reduce<9>, dim3(vgrid(eng, nblk(nn, 4))), B256, 0, s, w.msg[i], w.frame, w.row_ptr, xin, xmid, nn, 1.0f);
       HIPCHK(eng, hipGetLastError());
       DBG("xn" + t, w.xn[i], nn * ROW); DBG("rad" + t, w.rad[i], ne * RAD);
       if (!eng->pl) { DBG("xrot" + t, w.xrot, ne * XROT); DBG("hid" + t, w.hid, ne * ROW); }
@@ -673,6 +702,7 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
         return radial_bwd(eng, w, L.rad, i, ne, w.grad);
       });
     }
+    if (gp) P.sync(w.G1, (size_t)nn * ROW);           // g_xn: every rank holds the contributions of its own edges only
     P.stream([=, &w]() -> int {
       hipStream_t s = eng->stream;
       const std::string t = "." + std::to_string(i);
@@ -698,6 +728,7 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
     DBG("dedd", w.dedd, ne); DBG("tau", w.tau, ne * 4); DBG("gvec", w.gvec, ne * 4);
     return UMX_OK;
   });
+  if (gp) P.sync(d_forces, (size_t)nn * 3);           // forces: sum of the ranks' edge contributions
 }
 
 // Issue one plan on the stream eng->stream points at.
@@ -771,7 +802,7 @@ std::vector<float> transpose(const float* src, int rows, int cols) {
 // ================================================================================================
 extern "C" {
 
-int umx_abi_version(void) { return 4; }
+int umx_abi_version(void) { return 5; }
 
 #ifndef UMX_SRC_DIGEST
 #define UMX_SRC_DIGEST "unknown"
@@ -1159,7 +1190,8 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
     eng->img_edges_cap = K + 1;
   }
   HIPCHK(eng, hipMemsetAsync(eng->d_img_edges + K, 0, sizeof(int), s));
-  hipLaunchKernelGGL(k_graph_count, dim3(nblk(nt, 4)), dim3(256), 0, s, d_pos, N, nt, eng->cutoff * eng->cutoff, eng->max_neigh, eng->d_deg_all, eng->d_cand_all);
+  hipLaunchKernelGGL(k_graph_count, dim3(nblk(nt, 4)), dim3(256), 0, s, d_pos, N, nt, eng->cutoff * eng->cutoff, eng->max_neigh, eng->d_deg_all, eng->d_cand_all,
+                     eng->gp ? eng->gp_lo : 0L, eng->gp ? eng->gp_hi : nt);
   hipLaunchKernelGGL(k_image_edges, dim3((unsigned)K), dim3(256), 0, s, eng->d_deg_all, N, eng->d_img_edges, eng->d_img_edges + K);
   HIPCHK(eng, hipGetLastError());
   std::vector<int> img_edges(K + 1);
@@ -1182,7 +1214,7 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
       if (carve(nullptr, N, emax, nullptr, eng->pl) <= eng->ws_cap_default) budget = eng->ws_cap_default;   // (a single image larger than the cap keeps the full budget)
     }
   }
-  int lanes = (eng->n_lanes >= 2 && K >= 2 && !eng->dbg_on) ? 2 : 1;      // debug captures name ONE chunk's buffers
+  int lanes = (eng->n_lanes >= 2 && K >= 2 && !eng->dbg_on && !eng->gp) ? 2 : 1;      // debug captures name ONE chunk's buffers
   budget /= lanes;
   long max_chunk = (K + lanes - 1) / lanes;          // at least `lanes` chunks so both streams have work
   if (const char* ev = std::getenv("UMX_MAX_CHUNK_IMAGES")) { long v = std::atol(ev); if (v > 0) max_chunk = std::min(max_chunk, v); }
@@ -1232,6 +1264,15 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
   if (lanes == 2) {          // lane 1 starts after everything enqueued so far on the primary stream (degree pass, caller's work)
     HIPCHK(eng, hipEventRecord(eng->ev_fork, s));
     HIPCHK(eng, hipStreamWaitEvent(eng->stream2, eng->ev_fork, 0));
+  }
+  if (eng->gp) {
+    // graph-parallel: record the plan of the one chunk and hand control back; umx_gp_step issues it segment by segment, pausing at
+    // every exchange point.  The workspace view must outlive this call (the closures hold a reference to it).
+    WS* keep = new WS(wl[0]);
+    Plan* P = new Plan();
+    plan_chunk(eng, *keep, d_pos, eng->d_deg_all, eng->d_cand_all, 1, img_edges[0], d_energy, d_forces, *P);
+    eng->gp_ws = keep; eng->gp_plan = P; eng->gp_at = 0; eng->gp_stream = s;
+    return UMX_OK;
   }
   int st = UMX_OK;
   auto plan_of = [&](size_t ci, int lane, Plan& P) {
@@ -1283,6 +1324,47 @@ int umx_energy_forces_dev(umx_engine* eng, int n_images, const float* d_pos, dou
   // the default stream (the producer of d_pos) and before whatever it enqueues next (the consumer of d_energy / d_forces),
   // exactly as with an explicit stream.  The engine's private non-blocking stream is never used for caller-owned buffers.
   return energy_forces_on(eng, static_cast<hipStream_t>(hip_stream), n_images, d_pos, d_energy, d_forces);
+}
+
+static void gp_clear(umx_engine* eng) {
+  delete static_cast<Plan*>(eng->gp_plan);
+  delete static_cast<WS*>(eng->gp_ws);
+  eng->gp_plan = nullptr; eng->gp_ws = nullptr; eng->gp_at = 0; eng->gp = false;
+}
+
+int umx_gp_begin(umx_engine* eng, const float* d_pos, int node_lo, int node_hi, double* d_energy, float* d_forces, void* hip_stream) {
+  if (!eng) return UMX_ERR_ARG;
+  if (!eng->have_system) return fail(eng, UMX_ERR_ARG, "umx_gp_begin: bind a system first (umx_set_system)");
+  if (!d_pos || !d_energy || !d_forces) return fail(eng, UMX_ERR_ARG, "umx_gp_begin: bad arguments (forces are part of the exchange)");
+  if (node_lo < 0 || node_hi > eng->natoms || node_lo > node_hi) return fail(eng, UMX_ERR_ARG, "umx_gp_begin: node range outside [0, n_atoms]");
+  if (!eng->pl || !eng->fuse_modrot) return fail(eng, UMX_ERR_ARG, "umx_gp_begin: graph-parallel mode needs the default split-precision path");
+  if (eng->gp_plan) gp_clear(eng);                       // an abandoned evaluation
+  HIPCHK(eng, hipSetDevice(eng->dev));
+  eng->gp = true; eng->gp_lo = node_lo; eng->gp_hi = node_hi;
+  const int st = energy_forces_on(eng, static_cast<hipStream_t>(hip_stream), 1, d_pos, d_energy, d_forces);
+  if (st != UMX_OK) gp_clear(eng);
+  return st;
+}
+
+int umx_gp_step(umx_engine* eng, float** d_buf, size_t* count, int* done) {
+  if (!eng || !d_buf || !count || !done) return UMX_ERR_ARG;
+  if (!eng->gp_plan) return fail(eng, UMX_ERR_ARG, "umx_gp_step: no graph-parallel evaluation in progress (umx_gp_begin)");
+  HIPCHK(eng, hipSetDevice(eng->dev));
+  Plan* P = static_cast<Plan*>(eng->gp_plan);
+  hipStream_t own = eng->stream;
+  eng->stream = eng->gp_stream;
+  int st = UMX_OK;
+  *d_buf = nullptr; *count = 0; *done = 0;
+  while (eng->gp_at < P->segs.size()) {
+    Seg& sg = P->segs[eng->gp_at++];
+    if (sg.sync_buf) { *d_buf = sg.sync_buf; *count = sg.sync_count; eng->stream = own; return UMX_OK; }
+    st = sg.fn();
+    if (st != UMX_OK) break;
+  }
+  eng->stream = own;
+  if (st == UMX_OK) *done = 1;
+  gp_clear(eng);
+  return st;
 }
 
 int umx_energy_forces(umx_engine* eng, int n_images, const float* pos, double* energy, float* forces) {

@@ -23,9 +23,15 @@ __device__ __forceinline__ float dist2_f(float dx, float dy, float dz) { return 
 // K1 radius graph: brute force inside each image, wave per target, ballot compaction (ascending
 // source order => CSR rows sorted by source).  pos: [NT][3] f32.
 // ------------------------------------------------------------------------------------------------
+// [lo, hi): the target nodes whose incoming edges this engine builds (all of them normally; one rank's share in the graph-parallel
+// single-image mode, where every other node gets an empty row).
 __global__ __launch_bounds__(256) void k_graph_count(const float* __restrict__ pos, int natoms, long nt, float rc2, int max_neigh,
-                                                     int* __restrict__ deg, int* __restrict__ cand) {
+                                                     int* __restrict__ deg, int* __restrict__ cand, long lo, long hi) {
   UMX_WAVE_ITEM(node, nt)
+  if (node < lo || node >= hi) {                 // wave-uniform
+    if (lane == 0) { cand[node] = 0; deg[node] = 0; }
+    return;
+  }
   const long base = (node / natoms) * natoms;
   const float xi = pos[node * 3 + 0], yi = pos[node * 3 + 1], zi = pos[node * 3 + 2];
   int cnt = 0;
@@ -70,8 +76,9 @@ __global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ deg, long
 // (rank by (d^2, source index), the oracle's stable argsort) -- the rare path scans the image once per candidate chunk.
 __global__ __launch_bounds__(256) void k_graph_fill(const float* __restrict__ pos, int natoms, long nt, float rc2, int max_neigh,
                                                     const int* __restrict__ cand, const int* __restrict__ row_ptr, int* __restrict__ esrc,
-                                                    int* __restrict__ edst, float* __restrict__ evec) {
+                                                    int* __restrict__ edst, float* __restrict__ evec, long lo, long hi) {
   UMX_WAVE_ITEM(node, nt)
+  if (node < lo || node >= hi) return;           // wave-uniform: rows outside the owned target range are empty
   const long base = (node / natoms) * natoms;
   const float xi = pos[node * 3 + 0], yi = pos[node * 3 + 1], zi = pos[node * 3 + 2];
   const bool truncate = cand[node] > max_neigh;
@@ -513,7 +520,7 @@ __global__ __launch_bounds__(256) void k_rotate_back_reduce(const float* __restr
   }
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
-    const float2 b = *reinterpret_cast<const float2*>(xin + node * ROW + r * C + c0);
+    const float2 b = xin ? *reinterpret_cast<const float2*>(xin + node * ROW + r * C + c0) : make_float2(0.f, 0.f);   // null: the bare sum (graph-parallel partial)
     *reinterpret_cast<float2*>(xout + node * ROW + r * C + c0) = make_float2(b.x + ax[r], b.y + ay[r]);
   }
   }
@@ -644,6 +651,14 @@ __global__ __launch_bounds__(256) void k_radial_dd(const float* __restrict__ gga
   v = wave_sum(v);
   if (lane == 0) dedd[e] += v;
   }
+}
+
+// dst = a + b (a may alias dst); graph-parallel mode: residual + the all-reduced sum of the ranks' partial aggregates
+__global__ void k_add_rows(float* dst, const float* a, const float* __restrict__ b, long n4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+  reinterpret_cast<float4*>(dst)[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
 }
 
 // dE/dvec per edge from dE/dd and the torque (frame detached at the +y pole, as the reference does)

@@ -68,6 +68,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "umx_set_workspace_limit": ([vp, C.c_size_t], i32),
         "umx_energy_forces": ([vp, i32, fp, dp, fp], i32),
         "umx_energy_forces_dev": ([vp, i32, vp, vp, vp, vp], i32),
+        "umx_gp_begin": ([vp, vp, i32, i32, vp, vp, vp], i32),
+        "umx_gp_step": ([vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(i32)], i32),
         "umx_synchronize": ([vp], i32),
         "umx_last_graph_stats": ([vp, i64p, C.POINTER(C.c_int32)], i32),
         "umx_profile_enable": ([vp, i32], i32),
@@ -94,7 +96,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 
 EXPORTED_SYMBOLS = (
     "umx_abi_version", "umx_build_digest", "umx_create", "umx_destroy", "umx_last_error", "umx_load_weights", "umx_set_system",
-    "umx_set_workspace_limit", "umx_energy_forces", "umx_energy_forces_dev", "umx_synchronize",
+    "umx_set_workspace_limit", "umx_energy_forces", "umx_energy_forces_dev", "umx_gp_begin", "umx_gp_step", "umx_synchronize",
     "umx_last_graph_stats", "umx_profile_enable", "umx_profile_read", "umx_bond_changes", "umx_debug_fetch", "umx_debug_keep",
 )
 
@@ -168,6 +170,17 @@ class Engine:
         self._chk(self.lib.umx_energy_forces_dev(self._h, int(n_images), C.c_void_p(d_pos), C.c_void_p(d_energy),
                                                  C.c_void_p(d_forces) if d_forces else None,
                                                  C.c_void_p(stream) if stream else None), "umx_energy_forces_dev")
+
+    # ---- graph-parallel single-image mode (reference workers > 1; see parallel.GraphParallelEvaluator) -----------------
+    def gp_begin(self, d_pos: int, node_lo: int, node_hi: int, d_energy: int, d_forces: int, stream: int = 0):
+        self._chk(self.lib.umx_gp_begin(self._h, C.c_void_p(d_pos), int(node_lo), int(node_hi), C.c_void_p(d_energy), C.c_void_p(d_forces),
+                                        C.c_void_p(stream) if stream else None), "umx_gp_begin")
+
+    def gp_step(self) -> Tuple[int, int, bool]:
+        """Issue segments up to the next exchange point: (device pointer, float32 count, done)."""
+        buf, cnt, done = C.c_void_p(), C.c_size_t(), C.c_int()
+        self._chk(self.lib.umx_gp_step(self._h, C.byref(buf), C.byref(cnt), C.byref(done)), "umx_gp_step")
+        return int(buf.value or 0), int(cnt.value), bool(done.value)
 
     def synchronize(self):
         self._chk(self.lib.umx_synchronize(self._h), "umx_synchronize")

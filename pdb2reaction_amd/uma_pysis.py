@@ -162,9 +162,36 @@ class UMAcore:
         import torch
         return torch.device("cuda", self.engine.device)
 
+    def enable_graph_parallel(self, on: bool = True, group=None) -> None:
+        """Evaluate every geometry with its GRAPH partitioned over the ranks of `group` (default: the world) -- the reference's
+        ``workers > 1`` mode (``ParallelMLIPPredictUnit``, ``:220-242``), for single large structures when there are fewer images
+        than GPUs.  From then on ``compute`` / ``compute_batch`` are COLLECTIVES: every rank must call them with the same
+        coordinates.  Images stay the preferred unit of parallelism (``parallel.ShardedImageEvaluator``): this mode moves
+        9 x N x 4.6 KB through all-reduces per evaluation."""
+        if not on:
+            self._gp = None
+            return
+        from .parallel import GraphParallelEvaluator
+
+        self._gp = GraphParallelEvaluator(self.engine, len(self.z), self.device, group)
+
+    def _gp_eval(self, coords_ang: np.ndarray):
+        import torch
+
+        c = np.asarray(coords_ang, dtype=np.float64).reshape(-1, len(self.z), 3)
+        es, fs = [], []
+        for k in range(c.shape[0]):                       # images one after another, each spread over all ranks
+            e, f = self._gp(torch.as_tensor(c[k], dtype=torch.float32, device=self.device))
+            es.append(float(e[0]))
+            fs.append(f.cpu().numpy())
+        return np.asarray(es, dtype=np.float64), np.stack(fs)
+
     # ----------------------------------------------------------------
     def compute_batch(self, coords_ang: np.ndarray, *, forces: bool = True) -> Dict[str, Any]:
         """Batched evaluation: (K,N,3) A -> {"energy": (K,) float64 eV, "forces": (K,N,3) float32 eV/A}."""
+        if getattr(self, "_gp", None) is not None:
+            e, f = self._gp_eval(coords_ang)
+            return {"energy": e, "forces": f if forces else None}
         e, f = self.engine.energy_forces(np.asarray(coords_ang), forces=forces)
         return {"energy": e, "forces": f}
 
@@ -175,7 +202,10 @@ class UMAcore:
                 "Analytical Hessian is not available when predictor workers > 1 "
                 "or when predictor.model is not exposed. Use FiniteDifference Hessian."
             )
-        e, f = self.engine.energy_forces(np.asarray(coord_ang, dtype=np.float64).reshape(1, -1, 3), forces=forces)
+        if getattr(self, "_gp", None) is not None:
+            e, f = self._gp_eval(coord_ang)
+        else:
+            e, f = self.engine.energy_forces(np.asarray(coord_ang, dtype=np.float64).reshape(1, -1, 3), forces=forces)
         return {"energy": float(e[0]), "forces": (f[0] if forces else None), "hessian": None}
 
 
@@ -244,6 +274,11 @@ class uma_pysis(Calculator):
     def __exit__(self, *exc):
         self.close()
         return False
+
+    def enable_graph_parallel(self, elem: Sequence[str], on: bool = True, group=None) -> None:
+        """Reference ``workers > 1`` semantics on the engine: partition the graph of each geometry over the ranks of `group`
+        (see ``UMAcore.enable_graph_parallel``).  Every later ``get_energy / get_forces / get_hessian`` call is then a collective."""
+        self._ensure_core(elem).enable_graph_parallel(on, group)
 
     def enable_hessian_sharding(self, on: bool = True, group=None) -> None:
         """Deal the FD-Hessian columns over the ranks of `group` (default: the world) -- c4's "freq Hessian (3N force

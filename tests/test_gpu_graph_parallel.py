@@ -1,0 +1,101 @@
+"""Graph-parallel single-image mode (rows a12 / f4): the reference's ``workers > 1`` semantics -- the graph of ONE image partitioned
+over ranks (``uma_pysis.py:220-242``) -- on the engine's exchange-point API (umx_gp_begin / umx_gp_step).
+
+World size 1: the partial-sum path with all edges local must reproduce the ordinary evaluation bit for bit.
+World size 2 and 3: ranks share the one GPU of the test box (gloo group, host-staged all-reduce: the collective the RCCL path does on
+device); every rank must end with the same energies / forces as a single engine, up to float32 summation order."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pdb2reaction_amd import synth, weights as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _single(z, pos):
+    from pdb2reaction_amd.engine import Engine
+
+    eng = Engine(0)
+    eng.load_weights(W.make_synthetic_weights(0))
+    eng.set_system(z)
+    e, f = eng.energy_forces(pos)
+    ne = eng.graph_stats()[0]
+    return eng, e, f, ne
+
+
+def test_world_size_one_is_bitwise_the_ordinary_path():
+    from pdb2reaction_amd.parallel import GraphParallelEvaluator
+
+    z, imgs, _ = synth.make_images(120, 2, seed=5)
+    eng, e, f, _ = _single(z, imgs)
+    dev = torch.device("cuda", 0)
+    gp = GraphParallelEvaluator(eng, len(z), dev)
+    for k in range(2):
+        ek, fk = gp(torch.as_tensor(imgs[k], dtype=torch.float32, device=dev))
+        assert gp.n_exchanges == 10                                   # edge-degree aggregate + 4 layers x (forward, reverse) + forces
+        assert float(ek[0]) == e[k] and np.array_equal(fk.cpu().numpy(), f[k])
+    e2, f2 = eng.energy_forces(imgs)                                  # the engine is back in its ordinary mode afterwards
+    assert np.array_equal(e2, e) and np.array_equal(f2, f)
+    eng.close()
+
+
+def _worker(rank, world, port, n_atoms, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pdb2reaction_amd.engine import Engine
+        from pdb2reaction_amd.parallel import GraphParallelEvaluator
+
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        z, imgs, _ = synth.make_images(n_atoms, 1, seed=8)
+        eng = Engine(0)
+        eng.load_weights(W.make_synthetic_weights(0))
+        eng.set_system(z)
+        gp = GraphParallelEvaluator(eng, n_atoms, dev)
+        e, f = gp(torch.as_tensor(imgs[0], dtype=torch.float32, device=dev))
+        ne_local = eng.graph_stats()[0]
+        eng.close()
+        # the calculator boundary: uma_pysis with the graph-parallel mode switched on (the reference's workers > 1)
+        import importlib
+        U = importlib.import_module("pdb2reaction_amd.uma_pysis")
+        elem = [synth.SYMBOLS[int(q)] for q in z]
+        calc = U.uma_pysis(model="synthetic", freeze_atoms=[1])
+        calc.enable_graph_parallel(elem)
+        r = calc.get_forces(elem, (imgs[0] * U.ANG2BOHR).reshape(-1))
+        calc.close()
+        out[rank] = (float(e[0]), f.cpu().numpy(), ne_local, (gp.lo, gp.hi), r["energy"] / U.EV2AU, r["forces"].reshape(-1, 3) / U.F_EVAA_2_AU)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_atoms", [(2, 300), (3, 157)])
+def test_ranks_partition_one_image(world, n_atoms):
+    z, imgs, _ = synth.make_images(n_atoms, 1, seed=8)
+    eng, e_ref, f_ref, ne_all = _single(z, imgs)
+    eng.close()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, n_atoms, out), nprocs=world, join=True)
+    assert sorted(out.keys()) == list(range(world))
+    assert sum(out[r][2] for r in range(world)) == ne_all               # every directed edge is built by exactly one rank
+    assert [out[r][3] for r in range(world)][0][0] == 0 and out[world - 1][3][1] == n_atoms
+    for r in range(world):
+        e, f, ne_r, _, e_calc, f_calc = out[r]
+        assert abs(e_calc - e_ref[0]) <= 2e-5 and np.all(f_calc[1] == 0.0)              # frozen atom zeroed as usual
+        act = np.arange(n_atoms) != 1
+        assert np.abs(f_calc[act] - f_ref[0][act]).max() <= 2e-5
+        assert 0 < ne_r < ne_all
+        assert abs(e - e_ref[0]) <= 2e-5                                # summation order of float32 partial sums differs
+        assert np.abs(f - f_ref[0]).max() <= 2e-5
+        assert np.array_equal(f, out[0][1]) and e == out[0][0]          # all ranks hold the same reduced result

@@ -849,8 +849,11 @@ int umx_create(umx_engine** out, int device_ordinal) {
   return UMX_OK;
 }
 
+static void gp_clear(umx_engine* eng);
+
 int umx_destroy(umx_engine* eng) {
   if (!eng) return UMX_OK;
+  if (eng->gp_plan) gp_clear(eng);
   (void)hipSetDevice(eng->dev);
   (void)hipStreamSynchronize(eng->stream);
   for (auto& r : eng->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -1319,6 +1322,7 @@ int umx_energy_forces_dev(umx_engine* eng, int n_images, const float* d_pos, dou
   if (!eng) return UMX_ERR_ARG;
   if (!eng->have_system) return fail(eng, UMX_ERR_ARG, "umx_energy_forces: bind a system first (umx_set_system)");
   if (n_images <= 0 || !d_pos || !d_energy) return fail(eng, UMX_ERR_ARG, "umx_energy_forces: bad arguments");
+  if (eng->gp_plan) return fail(eng, UMX_ERR_ARG, "umx_energy_forces: a graph-parallel evaluation is in progress (finish it with umx_gp_step)");
   HIPCHK(eng, hipSetDevice(eng->dev));
   // NULL = the legacy default stream (hipStream_t 0): the work is then ordered after everything the caller has enqueued on
   // the default stream (the producer of d_pos) and before whatever it enqueues next (the consumer of d_energy / d_forces),
@@ -1371,6 +1375,7 @@ int umx_energy_forces(umx_engine* eng, int n_images, const float* pos, double* e
   if (!eng) return UMX_ERR_ARG;
   if (!eng->have_system) return fail(eng, UMX_ERR_ARG, "umx_energy_forces: bind a system first (umx_set_system)");
   if (n_images <= 0 || !pos || !energy) return fail(eng, UMX_ERR_ARG, "umx_energy_forces: bad arguments");
+  if (eng->gp_plan) return fail(eng, UMX_ERR_ARG, "umx_energy_forces: a graph-parallel evaluation is in progress (finish it with umx_gp_step)");
   HIPCHK(eng, hipSetDevice(eng->dev));
   const long nt = (long)n_images * eng->natoms;
   if (eng->io_cap < nt) {

@@ -330,3 +330,25 @@ def test_c5_size_invariants(engine):
     assert np.abs(f1.astype(np.float64).sum(axis=1)).max() <= 2e-3
     e2, f2 = engine.energy_forces(imgs)
     assert e2[0] == e1[0] and np.array_equal(f2[0], f1[0])
+
+
+def test_two_lane_execution_is_bitwise_identical(weights, monkeypatch):
+    """UMX_STREAMS=2 (two chunks in flight, matrix segments alternating through an event token, capped grids of the grid-stride
+    stream kernels) must not change a single bit: same kernels, same per-item arithmetic, only the issue order differs."""
+    from pdb2reaction_amd.engine import Engine
+
+    z, imgs, _ = synth.make_images(260, 5, seed=21)
+    res = {}
+    for lanes, cap in (("1", "512"), ("2", "512"), ("2", "64"), ("2", "0")):
+        monkeypatch.setenv("UMX_STREAMS", lanes)
+        monkeypatch.setenv("UMX_STREAM_BLOCKS", cap)
+        eng = Engine(0)
+        try:
+            eng.load_weights(weights)
+            eng.set_system(z)
+            res[(lanes, cap)] = eng.energy_forces(imgs)
+        finally:
+            eng.close()
+    e0, f0 = res[("1", "512")]
+    for key, (e, f) in res.items():
+        assert np.array_equal(e, e0) and np.array_equal(f, f0), key

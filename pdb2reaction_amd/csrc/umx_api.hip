@@ -431,12 +431,13 @@ int radial_bwd(umx_engine* eng, const WS& w, const RadialW& r, int slot, long ne
   return radial_bwd_tail(eng, w, r, slot, ne);
 }
 
-// SO(3) linear on l-primary node rows: per degree l one GEMM with gridDim.z = 2l+1
+// SO(3) linear on l-primary node rows: ONE launch, gridDim.z = 9 coefficients, the weights of degree l(z) picked per z (zBl);
+// the bias acts on the l = 0 row only
 int so3_linear(umx_engine* eng, const float* A, const float* Wl, const float* bias, float* Cp, long nn, const float* resid) {
-  for (int l = 0; l < 3; ++l)
-    CHK(gemm_plain(eng, A, ROW, l * l * C, Wl + (long)l * C * C, C, l == 0 ? bias : nullptr, Cp, ROW, l * l * C, nn, C, C, A_PLAIN,
-                   2 * l + 1, C, C, resid, ROW, l * l * C, C));
-  return UMX_OK;
+  GemmP p = gp_zero();
+  p.A = A; p.lda = ROW; p.offA0 = 0; p.B = Wl; p.ldb = C; p.bias = bias; p.Cp = Cp; p.ldc = ROW; p.offC = 0;
+  p.M = (int)nn; p.N = C; p.K = C; p.zA = C; p.zC = C; p.resid = resid; p.ldres = ROW; p.offRes = 0; p.zRes = C; p.zBl = (long)C * C;
+  return launch_gemm(eng, p, A_PLAIN, 0, E_BIAS, S);
 }
 
 // ---- one chunk: nn nodes (= images * natoms), edges counted on the fly --------------------------

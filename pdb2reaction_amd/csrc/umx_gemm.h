@@ -44,6 +44,8 @@ struct GemmP {
   const int* ez;                                 // E_TABLES: per-edge packed element indices z_src | z_dst << 16 (k_edge_z)
   float conj;                                    // CPLX combine sign
   long zA, zC, zRes;
+  long zBl;                                      // != 0: SO(3)-linear mode -- blockIdx.z = l-primary coefficient (0..8), weights of degree l(z) at B + l*zBl,
+                                                 //       bias only on z = 0 (one launch instead of one per degree)
   int M, N, K;                                   // CPLX: M = edges, N = channels per half
 };
 
@@ -88,7 +90,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[2][2
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = nt * 128 + wn * 64 + j * 32 + l31;
-      bv[j] = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+      bv[j] = (p.bias && col < p.N && (p.zBl == 0 || blockIdx.z == 0)) ? p.bias[col] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -144,6 +146,7 @@ __global__ __launch_bounds__(256, 2) void umx_gemm_kernel(const GemmP p) {
   const int mt = (slot / nN) * 8 + xcd, nt = slot % nN;
   if (mt >= nM) return;
   const long zoffA = (long)blockIdx.z * p.zA;
+  const float* Bz = p.B + (p.zBl ? (blockIdx.z == 0 ? 0 : blockIdx.z < 4 ? 1 : 2) * p.zBl : 0);
 
   // ---- staging assignment: thread -> 4 rows x one float4 of A and of B ------------------------
   const int k4 = (tid & 7) * 4;
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void umx_gemm_kernel(const GemmP p) {
       int brow; bool ok;
       if (CPLX) { const int c = nt * 64 + (trow & 63); ok = c < p.N; brow = (trow >> 6) * p.bHalf + c; }
       else      { brow = nt * 128 + trow; ok = brow < p.N; }
-      rb[r] = ok ? *reinterpret_cast<const float4*>(p.B + (long)brow * p.ldb + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[r] = ok ? *reinterpret_cast<const float4*>(Bz + (long)brow * p.ldb + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto lstore = [&](int buf) {

@@ -6,8 +6,6 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof; P=$O/profiles_out
 mkdir -p $O $P
 cd /tmp && export TMPDIR=/tmp && cd $R
 BENCH="python3 bench.py --no-cpu-baseline --no-fp32-mode"
-echo "== 1. bench line (default build)" &&
-timeout -k 10 600 python3 bench.py --steps 3 --warmup 1 > $O/bench.log 2>&1 && grep '^{' $O/bench.log | tail -1 > $P/r02_bench_c3_n1_split.json &&
 echo "== 2. kernel trace + stats (split)" &&
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -f csv -- $BENCH --steps 2 --warmup 1 > $O/kt.log 2>&1 &&
 ( echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-mode  (MI355X, round 2, default split-bf16 build, 3 iterations incl. warm-up)"; cat $O/kt/kt_kernel_stats.csv ) > $P/r02_bench_c3_kernel_stats_split.csv &&
@@ -22,6 +20,9 @@ echo "== 5. GEMM PMC counters at the real c3 shapes" &&
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS -d $O/g1 -o g -f csv -- $R/build/overlap_bench pmc 1 > $O/g1.log 2>&1 &&
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS GRBM_GUI_ACTIVE -d $O/g2 -o g -f csv -- $R/build/overlap_bench pmc 1 > $O/g2.log 2>&1 &&
 python3 tools/gemm_pmc_summary.py $O/g1 $O/g2 $P/r02_gemm_pmc_counters.json | tee $O/gemm_pmc_summary.log &&
+echo "== 1. bench line (default build; AFTER the PMC summary so that `traffic` is the one of this very build)" &&
+cp $P/r02_pmc_hbm_traffic.json profiles/r02_pmc_hbm_traffic.json &&
+timeout -k 10 600 python3 bench.py --steps 3 --warmup 1 > $O/bench.log 2>&1 && grep '^{' $O/bench.log | tail -1 > $P/r02_bench_c3_n1_split.json &&
 echo "== 6. c5 (20 000 atoms x 8 images) kernel stats" &&
 rocprofv3 --kernel-trace --stats -d $O/c5 -o kt -f csv -- python3 tools/gpu_c5_check.py > $O/c5.log 2>&1 &&
 ( echo "# rocprofv3 --kernel-trace --stats -- python3 tools/gpu_c5_check.py  (MI355X, round 2: c5 = 20 000 atoms x 8 images, one batched E+F, split mode)"; cat $O/c5/kt_kernel_stats.csv ) > $P/r02_c5_kernel_stats_split.csv &&

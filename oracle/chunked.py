@@ -25,6 +25,31 @@ C, H, S = O.C, O.H, O.S
 L_OF_LP, L_OF_MP = ST.L_OF_LP, ST.L_OF_MP
 
 
+def radius_graph_blocked(pos: torch.Tensor, cutoff: float, max_neigh: Optional[int], block: int = 2048):
+    """Same edge list as ``escn_md_oracle.radius_graph`` (ordered pairs j -> i with 0 < d <= cutoff, sorted by (target, source),
+    nearest ``max_neigh`` sources per target with a stable rank on (d^2, source)), built in row blocks so that 20 000 atoms need
+    block x N instead of N x N x 3 temporaries."""
+    p = pos.detach().to(torch.float64)
+    n = p.shape[0]
+    srcs, dsts = [], []
+    for s0 in range(0, n, block):
+        q = p[s0:s0 + block]
+        d2 = ((q[:, None, :] - p[None, :, :]) ** 2).sum(-1)                       # (b, N): row = target
+        rows = torch.arange(s0, s0 + len(q))
+        mask = d2 <= cutoff * cutoff
+        mask[torch.arange(len(q)), rows] = False
+        if max_neigh is not None:
+            d2m = torch.where(mask, d2, torch.full_like(d2, float("inf")))
+            order = torch.argsort(d2m, dim=1, stable=True)
+            rank = torch.empty_like(order)
+            rank.scatter_(1, order, torch.arange(n).expand(len(q), n))
+            mask = mask & (rank < max_neigh)
+        ti, sj = torch.nonzero(mask, as_tuple=True)
+        dsts.append(ti + s0)
+        srcs.append(sj)
+    return torch.cat(srcs), torch.cat(dsts)
+
+
 class ChunkedForces:
     def __init__(self, weights: Dict[str, np.ndarray], dtype=torch.float64, cutoff: float = W.CUTOFF, chunk: int = 16384):
         self.st = ST.Staged(weights, dtype=dtype, cutoff=cutoff)
@@ -78,7 +103,7 @@ class ChunkedForces:
         pos = torch.as_tensor(np.asarray(pos), dtype=self.dtype)
         n = pos.shape[0]
         with torch.no_grad():
-            src, dst = O.radius_graph(pos, self.cutoff, max_neigh)
+            src, dst = (O.radius_graph if n <= 4096 else radius_graph_blocked)(pos, self.cutoff, max_neigh)
             vec = pos[src] - pos[dst]
             dist = vec.norm(dim=1)
             nhat = vec / dist[:, None]

@@ -58,6 +58,7 @@ struct umx_engine {
   hipStream_t stream2 = nullptr;   // second lane: half-chunks alternate streams so HBM-bound producers overlap the other lane's GEMMs
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev_tok[2] = {nullptr, nullptr};   // matrix-pipe token of the two lanes (run_plans_alternating)
+  int radial_tr = 2;               // UMX_RADIAL_TR: 32-row MFMA tiles per workgroup tile of the fused radial kernels (1: 3 workgroups per CU, 2: 2)
   int radial_fast = 0;             // UMX_RADIAL_FAST: transcendentals inside the fused radial kernels: 0 libm, 1 raw hardware, 2 refined hardware (umx_radial.h)
   bool fused_radial = true;        // UMX_FUSED_RADIAL=0: the radial MLP's small layers as separate GEMM / LayerNorm launches (umx_radial.h fuses them)
   int q3_stages = 2;               // UMX_Q3S: LDS ring depth of the forward Q3 GEMMs (2 or 3)
@@ -358,19 +359,26 @@ int radial_fwd_head(umx_engine* eng, const WS& w, const RadialW& r, int slot, lo
   const bool planes = eng->pl && eng->planes.count(r.w3);
   if (eng->fused_radial && (!planes || eng->q3)) {
     // one persistent kernel: gaussians -> fc1 -> LN+SiLU -> fc2 -> LN+SiLU -> fc3 operand (Q3 planes, or fp32 rows in w.ra)
-    const unsigned tiles = nblk(ne, RT);
-    const dim3 grid(vgrid(eng, tiles < 512u ? tiles : 512u));
+    const int TR = eng->radial_tr;
+    const unsigned tiles = nblk(ne, 32 * TR);
+    const unsigned cap = TR == 1 ? 768u : 512u;          // persistent: three / two workgroups per CU
+    const dim3 grid(vgrid(eng, tiles < cap ? tiles : cap));
 #define UMX_RH_ARGS grid, dim3(256), 0, s, w.evec, w.ez, eng->gcoef, eng->d_gmu, r.w1g, r.ts, r.tt, r.ln1w, r.ln1b, r.w2, r.b2, r.ln2w, r.ln2b, w.h1pre[slot], w.h2pre[slot]
-    const int fm = eng->radial_fast;
-    if (planes) {
-      if (fm == 2) hipLaunchKernelGGL((k_radial_head<true, 2>), UMX_RH_ARGS, (void*)w.a2pl, ne);
-      else if (fm == 1) hipLaunchKernelGGL((k_radial_head<true, 1>), UMX_RH_ARGS, (void*)w.a2pl, ne);
-      else hipLaunchKernelGGL((k_radial_head<true, 0>), UMX_RH_ARGS, (void*)w.a2pl, ne);
-    } else {
-      if (fm == 2) hipLaunchKernelGGL((k_radial_head<false, 2>), UMX_RH_ARGS, (void*)w.ra, ne);
-      else if (fm == 1) hipLaunchKernelGGL((k_radial_head<false, 1>), UMX_RH_ARGS, (void*)w.ra, ne);
-      else hipLaunchKernelGGL((k_radial_head<false, 0>), UMX_RH_ARGS, (void*)w.ra, ne);
-    }
+#define UMX_RH_LAUNCH(Q, OUT)                                                                                           \
+    do {                                                                                                              \
+      const int fm = eng->radial_fast;                                                                                \
+      if (TR == 1) {                                                                                                  \
+        if (fm == 2) hipLaunchKernelGGL((k_radial_head<Q, 2, 1>), UMX_RH_ARGS, (void*)(OUT), ne);                      \
+        else if (fm == 1) hipLaunchKernelGGL((k_radial_head<Q, 1, 1>), UMX_RH_ARGS, (void*)(OUT), ne);                 \
+        else hipLaunchKernelGGL((k_radial_head<Q, 0, 1>), UMX_RH_ARGS, (void*)(OUT), ne);                              \
+      } else {                                                                                                        \
+        if (fm == 2) hipLaunchKernelGGL((k_radial_head<Q, 2, 2>), UMX_RH_ARGS, (void*)(OUT), ne);                      \
+        else if (fm == 1) hipLaunchKernelGGL((k_radial_head<Q, 1, 2>), UMX_RH_ARGS, (void*)(OUT), ne);                 \
+        else hipLaunchKernelGGL((k_radial_head<Q, 0, 2>), UMX_RH_ARGS, (void*)(OUT), ne);                              \
+      }                                                                                                               \
+    } while (0)
+    if (planes) UMX_RH_LAUNCH(true, w.a2pl); else UMX_RH_LAUNCH(false, w.ra);
+#undef UMX_RH_LAUNCH
 #undef UMX_RH_ARGS
     HIPCHK(eng, hipGetLastError());
     return UMX_OK;
@@ -408,12 +416,20 @@ int radial_bwd_tail(umx_engine* eng, const WS& w, const RadialW& r, int slot, lo
   hipStream_t s = eng->stream;
   if (eng->fused_radial) {
     // one persistent kernel: LN+SiLU bwd -> fc2^T -> LN+SiLU bwd -> fc1^T -> dE/dd through the gaussians (accumulated into dedd)
-    const unsigned tiles = nblk(ne, RT);
-    const dim3 grid(vgrid(eng, tiles < 512u ? tiles : 512u));
+    const int TR = eng->radial_tr;
+    const unsigned tiles = nblk(ne, 32 * TR);
+    const unsigned cap = TR == 1 ? 768u : 512u;
+    const dim3 grid(vgrid(eng, tiles < cap ? tiles : cap));
 #define UMX_RT_ARGS grid, dim3(256), 0, s, w.e128a, w.h2pre[slot], w.h1pre[slot], w.evec, eng->gcoef, eng->d_gmu, r.ln2w, r.ln2b, r.ln1w, r.ln1b, r.w2T, r.w1gT, w.dedd, ne
-    if (eng->radial_fast == 2) hipLaunchKernelGGL(k_radial_tail<2>, UMX_RT_ARGS);
-    else if (eng->radial_fast == 1) hipLaunchKernelGGL(k_radial_tail<1>, UMX_RT_ARGS);
-    else hipLaunchKernelGGL(k_radial_tail<0>, UMX_RT_ARGS);
+    if (TR == 1) {
+      if (eng->radial_fast == 2) hipLaunchKernelGGL((k_radial_tail<2, 1>), UMX_RT_ARGS);
+      else if (eng->radial_fast == 1) hipLaunchKernelGGL((k_radial_tail<1, 1>), UMX_RT_ARGS);
+      else hipLaunchKernelGGL((k_radial_tail<0, 1>), UMX_RT_ARGS);
+    } else {
+      if (eng->radial_fast == 2) hipLaunchKernelGGL((k_radial_tail<2, 2>), UMX_RT_ARGS);
+      else if (eng->radial_fast == 1) hipLaunchKernelGGL((k_radial_tail<1, 2>), UMX_RT_ARGS);
+      else hipLaunchKernelGGL((k_radial_tail<0, 2>), UMX_RT_ARGS);
+    }
 #undef UMX_RT_ARGS
     HIPCHK(eng, hipGetLastError());
     return UMX_OK;
@@ -830,6 +846,7 @@ int umx_create(umx_engine** out, int device_ordinal) {
   if (const char* ev = std::getenv("UMX_WIDE")) e->wide_tiles = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_Q3")) e->q3 = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_Q3WIDE")) e->q3_wide = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("UMX_RADIAL_TR")) e->radial_tr = std::atoi(ev) == 1 ? 1 : 2;
   if (const char* ev = std::getenv("UMX_RADIAL_FAST")) e->radial_fast = std::max(0, std::min(2, std::atoi(ev)));
   if (const char* ev = std::getenv("UMX_FUSED_RADIAL")) e->fused_radial = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_Q3S")) e->q3_stages = std::atoi(ev) == 3 ? 3 : 2;

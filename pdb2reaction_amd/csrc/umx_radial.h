@@ -19,7 +19,6 @@
 
 namespace umx {
 
-constexpr int RT = 64;         // edges per tile
 constexpr int R_LD = 132;      // padded LDS row of a 128-wide activation tile (floats)
 constexpr int R_LDG = 68;      // padded LDS row of the 64-wide gaussian tile
 
@@ -101,15 +100,15 @@ __device__ __forceinline__ float2 ln_silu_row_bwd(float2 go, float2 v, float2 ww
 }
 
 // acc[i] += A[rows i*32 + l31][k] . W[col][k] over NC chunks of 8 k-values; A in LDS (row pitch LD), W in registers
-template <int NC, int LD>
-__device__ __forceinline__ void rad_mma(const float* __restrict__ a_lds, const float4 (&wr)[NC], f32x16 (&acc)[2], int l31, int h) {
+template <int NC, int LD, int TR>
+__device__ __forceinline__ void rad_mma(const float* __restrict__ a_lds, const float4 (&wr)[NC], f32x16 (&acc)[TR], int l31, int h) {
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    float4 a[2];
+    float4 a[TR];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(a_lds + (i * 32 + l31) * LD + c * 8 + 4 * h);
+    for (int i = 0; i < TR; ++i) a[i] = *reinterpret_cast<const float4*>(a_lds + (i * 32 + l31) * LD + c * 8 + 4 * h);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TR; ++i) {
       acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, wr[c].x, acc[i], 0, 0, 0);
       acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, wr[c].y, acc[i], 0, 0, 0);
       acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, wr[c].z, acc[i], 0, 0, 0);
@@ -121,14 +120,17 @@ __device__ __forceinline__ void rad_mma(const float* __restrict__ a_lds, const f
 // ---- forward: d, Z_src, Z_dst  ->  h1pre, h2pre (kept for the reverse pass) and the fc3 operand --------------------------------
 // OUTQ3 = true: the fc3 operand as Q3 bf16 planes (umx_gemm_q.h);  false: fp32 rows (fp32 precision mode, and the edge-degree MLP
 // whose fc3 runs on the fp32 GEMM).   ts / tt: per-element tables of the embedding part of fc1 (tt includes the fc1 bias).
-template <bool OUTQ3, int FAST>
-__global__ __launch_bounds__(256, 2) void k_radial_head(const float* __restrict__ evec, const int* __restrict__ ez, float gcoef,
+// TR = 32-row MFMA tiles per workgroup tile (RT = 32 TR edges).  TR = 1 halves the LDS and accumulator footprint so that three
+// workgroups share a CU: the VALU-heavy LayerNorm passes of one overlap the MFMAs of the others (measured against TR = 2 below).
+template <bool OUTQ3, int FAST, int TR>
+__global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const float* __restrict__ evec, const int* __restrict__ ez, float gcoef,
                                                         const float* __restrict__ gmu, const float* __restrict__ w1g,
                                                         const float* __restrict__ ts, const float* __restrict__ tt,
                                                         const float* __restrict__ ln1w, const float* __restrict__ ln1b,
                                                         const float* __restrict__ w2, const float* __restrict__ b2,
                                                         const float* __restrict__ ln2w, const float* __restrict__ ln2b,
                                                         float* __restrict__ h1pre, float* __restrict__ h2pre, void* __restrict__ out, long ne) {
+  constexpr int RT = 32 * TR;
   __shared__ __attribute__((aligned(16))) float bufA[RT * R_LD];
   __shared__ __attribute__((aligned(16))) float bufB[RT * R_LD];
   __shared__ float dbuf[RT];
@@ -154,11 +156,12 @@ __global__ __launch_bounds__(256, 2) void k_radial_head(const float* __restrict_
       zbuf[tid] = ez[e];
     }
     __syncthreads();
-    {   // gaussian basis of the tile -> bufA as [64][R_LDG]
-      const int row = tid >> 2, c0 = (tid & 3) * 16;
+    {   // gaussian basis of the tile -> bufA as [RT][R_LDG]: 256 / RT threads per row, RT / 4 columns each
+      constexpr int TPR = 256 / RT;
+      const int row = tid / TPR, c0 = (tid % TPR) * (RT / 4);
       const float d = dbuf[row];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < RT / 16; ++q) {
         const float4 mu = *reinterpret_cast<const float4*>(gmu + c0 + 4 * q);
         float4 v; float t;
         t = d - mu.x; v.x = r_exp<FAST>(gcoef * t * t);
@@ -169,15 +172,15 @@ __global__ __launch_bounds__(256, 2) void k_radial_head(const float* __restrict_
       }
     }
     __syncthreads();
-    f32x16 acc[2];
+    f32x16 acc[TR];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TR; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    rad_mma<NG / 8, R_LDG>(bufA, W1, acc, l31, h);
+    rad_mma<NG / 8, R_LDG, TR>(bufA, W1, acc, l31, h);
     // epilogue 1: the raw fc1 tile to bufB; the row pass below adds the element tables, writes h1pre (whole 512-B rows) and normalises
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TR; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) bufB[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * R_LD + col] = acc[i][r];
     __syncthreads();
@@ -195,13 +198,13 @@ __global__ __launch_bounds__(256, 2) void k_radial_head(const float* __restrict_
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TR; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    rad_mma<RH / 8, R_LD>(bufB, W2, acc, l31, h);
+    rad_mma<RH / 8, R_LD, TR>(bufB, W2, acc, l31, h);
     // epilogue 2: fc2 tile + bias to bufA (the gaussian tile is dead: every wave passed the barriers behind fc1)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TR; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) bufA[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * R_LD + col] = acc[i][r] + bias2;
     __syncthreads();
@@ -222,13 +225,14 @@ __global__ __launch_bounds__(256, 2) void k_radial_head(const float* __restrict_
 
 // ---- reverse: dE/d(fc3 operand) -> dE/dd (accumulated into dedd) ------------------------------------------------------------------
 // ga2 = output of the fc3^T GEMM; w2T = W2^T ([k][j]), w1gT = W1g^T ([64 gaussians][128]).
-template <int FAST>
-__global__ __launch_bounds__(256, 2) void k_radial_tail(const float* __restrict__ ga2, const float* __restrict__ h2pre,
+template <int FAST, int TR>
+__global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_tail(const float* __restrict__ ga2, const float* __restrict__ h2pre,
                                                         const float* __restrict__ h1pre, const float* __restrict__ evec, float gcoef,
                                                         const float* __restrict__ gmu, const float* __restrict__ ln2w,
                                                         const float* __restrict__ ln2b, const float* __restrict__ ln1w,
                                                         const float* __restrict__ ln1b, const float* __restrict__ w2T,
                                                         const float* __restrict__ w1gT, float* __restrict__ dedd, long ne) {
+  constexpr int RT = 32 * TR;
   __shared__ __attribute__((aligned(16))) float bufA[RT * R_LD];
   __shared__ __attribute__((aligned(16))) float bufB[RT * R_LD];
   __shared__ float dbuf[RT];
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void k_radial_tail(const float* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int col = wave * 32 + l31;
-  const int gi = wave >> 1, gj = wave & 1;           // last linear (128 -> 64): wave -> (row tile, column tile)
+  const int gi = wave >> 1, gj = wave & 1;           // last linear (128 -> 64): wave -> (row tile, column tile); TR = 1: waves 0 and 1 only
   float4 W2T[RH / 8], W1T[RH / 8];
 #pragma unroll
   for (int c = 0; c < RH / 8; ++c) W2T[c] = *reinterpret_cast<const float4*>(w2T + col * RH + c * 8 + 4 * h);
@@ -259,14 +263,14 @@ __global__ __launch_bounds__(256, 2) void k_radial_tail(const float* __restrict_
       *reinterpret_cast<float2*>(bufA + row * R_LD + 2 * lane) = ln_silu_row_bwd<FAST>(go, x, l2w, l2b);
     }
     __syncthreads();
-    f32x16 acc[2];
+    f32x16 acc[TR];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TR; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    rad_mma<RH / 8, R_LD>(bufA, W2T, acc, l31, h);   // g_a1 = g_h2 . W2
+    rad_mma<RH / 8, R_LD, TR>(bufA, W2T, acc, l31, h);   // g_a1 = g_h2 . W2
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TR; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) bufB[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * R_LD + col] = acc[i][r];
     __syncthreads();
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void k_radial_tail(const float* __restrict_
       *reinterpret_cast<float2*>(bufA + row * R_LD + 2 * lane) = ln_silu_row_bwd<FAST>(go, x, l1w, l1b);
     }
     __syncthreads();
-    {   // g_gauss = g_h1 . W1g (128 -> 64): one 32 x 32 tile per wave, then dE/dd = sum_k g_gauss[k] d/dd exp(gcoef (d - mu_k)^2)
+    if (gi < TR) {   // g_gauss = g_h1 . W1g (128 -> 64): one 32 x 32 tile per wave (wave-uniform), then dE/dd = sum_k g_gauss[k] d/dd exp(gcoef (d - mu_k)^2)
       f32x16 a1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) a1[r] = 0.f;

@@ -179,3 +179,27 @@ def test_c2_gsm_12_images_500_atoms():
     full = [h for h in res.history if h["images"] == 12]
     assert full and full[-1]["rms_fperp"] <= full[0]["rms_fperp"]
     calc.close()
+
+
+@pytest.mark.parametrize("mode", ["split", "fp32"])
+def test_c5_energy_and_forces_against_f64_oracle(weights, mode, monkeypatch):
+    """BASELINE configs[4]: a 20 000-atom image (1.6 M directed edges; one image needs 190 GB of workspace, i.e. more than the default
+    cap -- the engine then takes the full budget).  E and F against the float64 oracle (tools/make_golden_c5.py), both precision modes."""
+    from pdb2reaction_amd.engine import Engine
+
+    g = load_golden("c5_n20000")
+    monkeypatch.setenv("UMX_PRECISION", mode)
+    eng = Engine(0)
+    try:
+        eng.load_weights(weights)
+        eng.set_system(g["z"])
+        e, f = eng.energy_forces(g["pos"][None])
+        ne, maxdeg = eng.graph_stats()
+        assert ne > 1_500_000 and maxdeg <= 300
+        de = abs(e[0] - g["energy"][0])
+        df = np.abs(f[0].astype(np.float64) - g["forces"][0])
+        print(f"[c5 {mode}] |dE| = {de:.2e} eV ({de / 20000:.1e} eV/atom), max|dF| = {df.max():.2e} eV/A, rms dF = {np.sqrt((df ** 2).mean()):.2e}")
+        assert de <= TOL_E, (mode, de)
+        assert df.max() <= TOL_F, (mode, df.max())
+    finally:
+        eng.close()

@@ -160,3 +160,22 @@ def test_oracle_c1_golden_first_image(oracle):
     e, f = oracle.energy_forces(g["z"], g["pos"][0].astype(np.float64))
     assert abs(e - g["energy"][0]) < 1e-9
     assert np.abs(f - g["forces"][0]).max() < 1e-10
+
+
+def test_float32_torch_arithmetic_deviates_per_atom(weights, oracle):
+    """Context for the energy tolerance: the same restatement run in torch float32 -- the reference's dtype and
+    op style -- deviates from float64 arithmetic by ~1e-7 eV PER ATOM (one-signed: shared quantities are rounded the same way for every
+    atom), i.e. 1e-4 eV is already exceeded near 1000 atoms by float32 arithmetic itself.  The engine is held to <= 2.5e-8 eV per atom."""
+    from oracle.escn_md_oracle import Oracle
+
+    o32 = Oracle(weights, dtype=torch.float32)
+    per_atom = []
+    for n, seed in ((90, 3), (140, 4)):
+        z, pos = synth.make_cluster(n, seed=seed)
+        p32 = pos.astype(np.float32)
+        e64, f64 = oracle.energy_forces(z, p32.astype(np.float64))
+        e32, f32 = o32.energy_forces(z, p32)
+        per_atom.append((e32 - e64) / n)
+        assert np.abs(f32 - f64).max() < 2e-5                      # forces: float32 round-off only
+    assert all(2e-8 < abs(d) < 1e-6 for d in per_atom), per_atom     # ~1e-7 eV per atom ...
+    assert np.sign(per_atom[0]) == np.sign(per_atom[1])              # ... with the same sign

@@ -31,7 +31,10 @@ enum umx_status {
   UMX_ERR_HIP = -2,      /* HIP runtime failure (text has the hipError name)  */
   UMX_ERR_WEIGHTS = -3,  /* malformed or incomplete weight blob               */
   UMX_ERR_CAPACITY = -4, /* neighbour cap exceeded / workspace cannot be sized */
-  UMX_ERR_NO_DEVICE = -5 /* no usable gfx950 device                           */
+  UMX_ERR_NO_DEVICE = -5,/* no usable gfx950 device                           */
+  UMX_ERR_RANGE = -6     /* non-finite energy: non-finite input, or an activation beyond the fp16 operand range (+-4094) of the
+                            default precision mode -- re-run with UMX_PRECISION=split-bf16 or fp32 (host-buffer entry only; the
+                            device-pointer entry cannot look: the caller sees NaN energies/forces)                            */
 };
 
 /* Version of this ABI (bumped on any signature change). */
@@ -52,7 +55,12 @@ const char* umx_last_error(const umx_engine* eng);
 
 /* Load a merged UMA-S parameter set from a host-memory UMXW0001 blob
  * (pdb2reaction_amd/weights.py documents the layout).
- * Replaces: pretrained_mlip.get_predict_unit(model, device), uma_pysis.py:246-250.             */
+ * Replaces: pretrained_mlip.get_predict_unit(model, device), uma_pysis.py:246-250.
+ * The environment variable UMX_PRECISION is read here and fixes the arithmetic of the large SO(2)/radial GEMMs:
+ *   split (default, = split-f16): forward operands as two fp16 planes (activations) x three fp16 planes (weights, exact),
+ *                4 MFMA products; reverse pass two bf16 planes, 3 products.  fp32-level accuracy; operand range +-4094.
+ *   split-bf16 : forward operands as three bf16 planes, 6 products (beyond fp32 accuracy, no range limit, ~12 % slower).
+ *   fp32       : every GEMM on the fp32 MFMA.                                                                          */
 int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes);
 
 /* Bind the chemical system shared by every image: atomic numbers, total charge, spin

@@ -40,7 +40,88 @@ __global__ void k_split_q(const float* __restrict__ src, long rows, long ld, int
   for (int q = 0; q < P; ++q) { const __bf16 hh = (__bf16)x; d[q * 16] = __builtin_bit_cast(unsigned short, hh); x -= (float)hh; }
 }
 
+// fp32 -> two IEEE-half planes in the Q2 layout: hi = RNE(x), lo = RNE(x - hi) (subnormal halves kept)
+template <int PQ>
+__global__ void k_split_q_f16(const float* __restrict__ src, long rows, long ld, int K, unsigned char* __restrict__ dst) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * K) return;
+  const long r = i / K; const int k = (int)(i % K);
+  float x = src[r * ld + k];
+  unsigned short* d = reinterpret_cast<unsigned short*>(dst + ((r / 4) * (K / 16) + k / 16) * (128 * PQ) + (r % 4) * (32 * PQ) + (k % 16) * 2);
+  for (int q = 0; q < PQ; ++q) { const _Float16 hq = (_Float16)x; d[16 * q] = __builtin_bit_cast(unsigned short, hq); x -= (float)hq; }
+}
+
+// accuracy + speed of the fp16 two-plane forms against the bf16 three-plane form, with a float64 host reference on the first rows.
+// Row r of A is scaled by 2^-(r % 28) when `ragged` to put the low planes into the half subnormal range.
+static int f16_mode(long M, int N, int K) {
+  float *A, *B, *C; unsigned char *Aq3, *Bq3, *Aq2, *Bq2;
+  const long Mp = (M + 3) / 4 * 4;
+  CK(hipMalloc(&A, M * (long)K * 4)); CK(hipMalloc(&B, (long)N * K * 4)); CK(hipMalloc(&C, M * (long)N * 4));
+  CK(hipMalloc(&Aq3, (size_t)Mp * K * 6)); CK(hipMalloc(&Bq3, (size_t)N * K * 6)); CK(hipMalloc(&Aq2, (size_t)Mp * K * 4)); CK(hipMalloc(&Bq2, (size_t)N * K * 4));
+  unsigned char* Bq3h; CK(hipMalloc(&Bq3h, (size_t)N * K * 6));
+  const int R = 256;
+  for (int ragged = 0; ragged < 2; ++ragged) {
+    std::vector<float> h((size_t)1 << 22); for (auto& v : h) v = (rand() / (float)RAND_MAX) * 2 - 1;
+    std::vector<float> ha((size_t)R * K), hb((size_t)N * K);
+    for (int r = 0; r < R; ++r) for (int k = 0; k < K; ++k) ha[(size_t)r * K + k] = h[(size_t)r * K + k] * (ragged ? std::ldexp(1.f, -(r % 28)) : 1.f);
+    for (size_t i = 0; i < hb.size(); ++i) hb[i] = 0.1f * h[(1 << 21) + i];
+    for (long o = 0; o < M * (long)K; o += h.size()) CK(hipMemcpy(A + o, h.data(), std::min<long>(h.size(), M * (long)K - o) * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(A, ha.data(), ha.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(B, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(Aq3, 0, (size_t)Mp * K * 6)); CK(hipMemset(Aq2, 0, (size_t)Mp * K * 4));
+    hipLaunchKernelGGL(k_split_q<3>, dim3((unsigned)((M * K + 255) / 256)), dim3(256), 0, 0, A, M, (long)K, K, Aq3);
+    hipLaunchKernelGGL(k_split_q<3>, dim3((unsigned)(((long)N * K + 255) / 256)), dim3(256), 0, 0, B, (long)N, (long)K, K, Bq3);
+    hipLaunchKernelGGL(k_split_q_f16<2>, dim3((unsigned)((M * K + 255) / 256)), dim3(256), 0, 0, A, M, (long)K, K, Aq2);
+    hipLaunchKernelGGL(k_split_q_f16<2>, dim3((unsigned)(((long)N * K + 255) / 256)), dim3(256), 0, 0, B, (long)N, (long)K, K, Bq2);
+    hipLaunchKernelGGL(k_split_q_f16<3>, dim3((unsigned)(((long)N * K + 255) / 256)), dim3(256), 0, 0, B, (long)N, (long)K, K, Bq3h);
+    CK(hipDeviceSynchronize());
+    std::vector<double> ref((size_t)R * N), nrm(R, 0.0);
+    for (int r = 0; r < R; ++r) for (int n = 0; n < N; ++n) {
+      double sacc = 0; for (int k = 0; k < K; ++k) sacc += (double)ha[(size_t)r * K + k] * (double)hb[(size_t)n * K + k];
+      ref[(size_t)r * N + n] = sacc; nrm[r] = std::max(nrm[r], std::fabs(sacc));
+    }
+    GemmPL g3; std::memset(&g3, 0, sizeof(g3)); g3.conj = 1.f;
+    g3.Apl = reinterpret_cast<const unsigned short*>(Aq3); g3.lda = 3L * K; g3.Bpl = reinterpret_cast<const unsigned short*>(Bq3); g3.ldb = 3L * K;
+    g3.Cp = C; g3.ldc = N; g3.M = (int)M; g3.N = N; g3.K = K;
+    g3.cscale = 1.f;
+    GemmPL g2 = g3; g2.Apl = reinterpret_cast<const unsigned short*>(Aq2); g2.lda = 2L * K; g2.Bpl = reinterpret_cast<const unsigned short*>(Bq2); g2.ldb = 2L * K;
+    GemmP pf; std::memset(&pf, 0, sizeof(pf)); pf.conj = 1.f; pf.A = A; pf.lda = K; pf.B = B; pf.ldb = K; pf.Cp = C; pf.ldc = N; pf.M = (int)M; pf.N = N; pf.K = K;
+    const long nm = (M + 255) / 256; const dim3 gw((unsigned)(((nm + 7) / 8) * 8 * ((N + 255) / 256)));
+    const long nM = (M + 127) / 128, nN = (N + 127) / 128; const dim3 gf((unsigned)(((nM + 7) / 8) * 8 * nN));
+    const double fl = 2.0 * M * N * K;
+    auto report = [&](const char* name, float ms) {
+      std::vector<float> c((size_t)R * N); CK(hipMemcpy(c.data(), C, c.size() * 4, hipMemcpyDeviceToHost));
+      double worst = 0, rms = 0, shrink = 0, wsum = 0;     // error relative to the largest entry of the row (rows differ in scale when ragged)
+      for (int r = 0; r < R; ++r) for (int n = 0; n < N; ++n) {
+        const double rf = ref[(size_t)r * N + n], d = c[(size_t)r * N + n] - rf, e = std::fabs(d) / nrm[r];
+        worst = std::max(worst, e); rms += e * e;
+        shrink += d * rf / (nrm[r] * nrm[r]); wsum += rf * rf / (nrm[r] * nrm[r]);     // least-squares fit c = (1 + s) ref
+      }
+      printf("%s %-30s %8.3f ms %7.1f alg-TF/s   max rel err %.2e  rms %.2e  fitted gain-1 %+.2e\n", ragged ? "[ragged]" : "[flat]  ", name, ms, fl / ms / 1e9, worst, std::sqrt(rms / ((double)R * N)), shrink / wsum);
+      fflush(stdout);
+    };
+    CK(hipMemset(C, 0, M * (long)N * 4));
+    report("fp32 MFMA", timeit([&] { hipLaunchKernelGGL((umx_gemm_kernel<A_PLAIN, 0, E_BIAS>), gf, dim3(256), 0, 0, pf); }));
+    CK(hipMemset(C, 0, M * (long)N * 4));
+    report("Q3 bf16 x3 planes, 6 products", timeit([&] { hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1>), gw, dim3(512), 0, 0, g3); }));
+    CK(hipMemset(C, 0, M * (long)N * 4));
+    report("Q2 f16 x2 planes, 4 products", timeit([&] { hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 2, 2, 1, 4, 2>), gw, dim3(512), 0, 0, g2); }));
+    CK(hipMemset(C, 0, M * (long)N * 4));
+    report("Q2 f16 x2 planes, 3 products", timeit([&] { hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 2, 2, 1, 3, 2>), gw, dim3(512), 0, 0, g2); }));
+    CK(hipMemset(C, 0, M * (long)N * 4));
+    { GemmPL g23 = g2; g23.Bpl = reinterpret_cast<const unsigned short*>(Bq3h); g23.ldb = 3L * K; g23.cscale = 1.f;
+      CK(hipMemset(C, 0, M * (long)N * 4));
+      report("f16 A x2 / B x3 exact, 4 products", timeit([&] { hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 2, 2, 1, 4, 3>), gw, dim3(512), 0, 0, g23); }));
+      CK(hipMemset(C, 0, M * (long)N * 4));
+      report("f16 A x2 / B x3, 5 products", timeit([&] { hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 2, 2, 1, 5, 3>), gw, dim3(512), 0, 0, g23); })); }
+    CK(hipMemset(C, 0, M * (long)N * 4));
+    report("Q2 f16 x2, 4 products, ring 3", timeit([&] { hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 2, 3, 1, 4, 2>), gw, dim3(512), 0, 0, g2); }));
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && !strcmp(argv[1], "f16")) return f16_mode(argc > 2 ? atol(argv[2]) : 569632, argc > 3 ? atoi(argv[3]) : 512, argc > 4 ? atoi(argv[4]) : 512);
   const long M = argc > 1 ? atol(argv[1]) : 569632; const int N = argc > 2 ? atoi(argv[2]) : 640, K = argc > 3 ? atoi(argv[3]) : 768;
   const long lda = 2304;
   float *A, *C, *C2, *B; unsigned short *Bp, *Ap, *Bp2, *Ap2;

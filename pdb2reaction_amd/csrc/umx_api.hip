@@ -64,6 +64,10 @@ struct umx_engine {
   int q3_stages = 2;               // UMX_Q3S: LDS ring depth of the forward Q3 GEMMs (2 or 3)
   bool q3_wide = true;             // UMX_Q3WIDE=0 (dev): 256x128 tiles for every forward GEMM
   bool q3 = true;                  // UMX_Q3=0: forward operands in the 32-column PL layout + 256x128 tiles (set before umx_load_weights)
+  int fwd_fmt = 1;                 // forward operand format (QFmt, umx_kernels_pl.h): 1 = two fp16 planes (UMX_PRECISION=split), 0 = three bf16 planes (split-bf16)
+  int f16_prod = 4;                // plane products of the fp16 form (UMX_F16_PRODUCTS): 4 = exact three-plane weights (hh, hl, lh, h.lo2),
+                                   // 3 = two-plane weights (hh, hl, lh; biases the energy by ~2.5e-8 eV/atom)
+  std::map<const float*, float> plane_scale;             // fp16 form: power-of-two scale folded into the weight planes
   bool wide_tiles = true;          // UMX_WIDE=0: 256x128 tiles for every GEMM
   int mfma16 = 1;                  // UMX_MFMA16: 0 = v_mfma_f32_32x32x16_bf16 everywhere, 1 = 16x16x32 where it measured faster, 2 = everywhere
   bool fuse_modrot = true;         // UMX_FUSE_MODROT=0: separate k_modulate_bwd_pl + k_gather_rotate_bwd (debug: exposes g_xrot)
@@ -222,7 +226,8 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
     }
     pr = &eng->prof[eng->prof_used++];
     pr->flops = cplx ? 8.0 * M * (double)N * K : 2.0 * M * (double)N * K;
-    pr->M = (int)M; pr->N = N; pr->K = K; pr->amode = 9; pr->cplx = cplx; pr->gz = 1; pr->prec = P;
+    pr->M = (int)M; pr->N = N; pr->K = K; pr->amode = 9; pr->cplx = cplx; pr->gz = 1;
+    pr->prec = (P == 3 && eng->q3 && eng->fwd_fmt == 1) ? 20 + eng->f16_prod : P;      // 23 / 24: two fp16 planes, 3 / 4 products
     HIPCHK(eng, hipEventRecord(pr->a, eng->stream));
   }
   // MFMA shape per GEMM (measured in the c3 pipeline): 16x16x32 wins 1-7 % on the complex SO(2) GEMMs and on K >= 512,
@@ -235,7 +240,21 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
     const long nNq = (N + bnq - 1) / bnq;
     dim3 gq((unsigned)(((nM + 7) / 8) * 8 * nNq));
     const int S = eng->q3_stages;             // ring depth: 2 (default) or 3 (UMX_Q3S=3: 144 KB wide / 108 KB narrow)
-    if (cplx) {
+    if (eng->fwd_fmt == 1) {
+      // two fp16 planes of 16 x (activations), three (exact) or two planes of s_w x (weights): C = (A' . B'^T) / (16 s_w)
+      q.lda = (long)a_cols * 2; q.ldb = (long)K * (eng->f16_prod == 3 ? 2 : 3);
+      q.cscale = 1.0f / (QF16_SCALE * eng->plane_scale.at(Wkey));
+#define UMX_QH(CP, WD)                                                                                                      \
+      do {                                                                                                                  \
+        if (eng->f16_prod == 3) { if (S == 3) hipLaunchKernelGGL((umx_gemm_q_kernel<CP, WD, 2, 3, 1, 3, 2>), gq, block, 0, eng->stream, q);  \
+                                  else hipLaunchKernelGGL((umx_gemm_q_kernel<CP, WD, 2, 2, 1, 3, 2>), gq, block, 0, eng->stream, q); }       \
+        else                    { if (S == 3) hipLaunchKernelGGL((umx_gemm_q_kernel<CP, WD, 2, 3, 1, 4, 3>), gq, block, 0, eng->stream, q);  \
+                                  else hipLaunchKernelGGL((umx_gemm_q_kernel<CP, WD, 2, 2, 1, 4, 3>), gq, block, 0, eng->stream, q); }       \
+      } while (0)
+      if (cplx) { if (wq) UMX_QH(1, 1); else UMX_QH(1, 0); }
+      else      { if (wq) UMX_QH(0, 1); else UMX_QH(0, 0); }
+#undef UMX_QH
+    } else if (cplx) {
       if (wq) { if (S == 3) hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1, 3, 3>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1>), gq, block, 0, eng->stream, q); }
       else    { if (S == 3) hipLaunchKernelGGL((umx_gemm_q_kernel<1, 0, 3, 3>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<1, 0>), gq, block, 0, eng->stream, q); }
     } else {
@@ -300,7 +319,10 @@ struct Bump {
   }
 };
 
-size_t carve(char* base, long nn, long ne, WS* w, bool pl) {
+inline int ws_mode(const umx_engine* eng) { return !eng->pl ? 0 : (eng->q3 && eng->fwd_fmt == 1) ? 2 : 3; }
+
+// pl: 0 = fp32 path, else the number of planes of the forward operands (3 bf16 / 2 fp16); see ws_mode()
+size_t carve(char* base, long nn, long ne, WS* w, int pl) {
   Bump b{base};
   WS t;
   t.deg = nullptr;  // deg comes from the per-call array
@@ -330,8 +352,9 @@ size_t carve(char* base, long nn, long ne, WS* w, bool pl) {
   if (pl) {
     t.gmsg = b.take<float>(ne * 3 * C);                      // only the edge-degree backward uses fp32 g_msg (E x 384)
     const long ne4 = (ne + 3) / 4 * 4;          // the quad-row (Q3) layout stores rows in groups of four
-    t.y1pl = b.take<unsigned short>(ne4 * XROT * 3); t.hidpl = b.take<unsigned short>(ne4 * ROW * 3);
-    t.a2pl = b.take<unsigned short>(ne4 * RH * 3); t.gmsgpl = b.take<unsigned short>(ne * ROW * 2);
+    const long fp = pl;                                          // planes of the forward operands
+    t.y1pl = b.take<unsigned short>(ne4 * XROT * fp); t.hidpl = b.take<unsigned short>(ne4 * ROW * fp);
+    t.a2pl = b.take<unsigned short>(ne4 * RH * fp); t.gmsgpl = b.take<unsigned short>(ne * ROW * 2);
     t.ghgpl = b.take<unsigned short>(ne * HG * 2); t.gradpl = b.take<unsigned short>(ne * RAD * 2);
   } else {
     t.xrot = b.take<float>(ne * XROT); t.gmsg = b.take<float>(ne * ROW);
@@ -377,7 +400,7 @@ int radial_fwd_head(umx_engine* eng, const WS& w, const RadialW& r, int slot, lo
         else hipLaunchKernelGGL((k_radial_head<Q, 0, 2>), UMX_RH_ARGS, (void*)(OUT), ne);                              \
       }                                                                                                               \
     } while (0)
-    if (planes) UMX_RH_LAUNCH(true, w.a2pl); else UMX_RH_LAUNCH(false, w.ra);
+    if (planes && eng->fwd_fmt == 1) UMX_RH_LAUNCH(2, w.a2pl); else if (planes) UMX_RH_LAUNCH(1, w.a2pl); else UMX_RH_LAUNCH(0, w.ra);
 #undef UMX_RH_LAUNCH
 #undef UMX_RH_ARGS
     HIPCHK(eng, hipGetLastError());
@@ -391,7 +414,8 @@ int radial_fwd_head(umx_engine* eng, const WS& w, const RadialW& r, int slot, lo
   hipLaunchKernelGGL(k_ln_silu_fwd, dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h1pre[slot], r.ln1w, r.ln1b, w.ra, ne);
   CHK(gemm_plain(eng, w.ra, RH, 0, r.w2, RH, r.b2, w.h2pre[slot], RH, 0, ne, RH, RH));
   if (eng->pl && eng->planes.count(r.w3)) {
-    if (eng->q3) hipLaunchKernelGGL((k_ln_silu_fwd_pl<3, true>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne);
+    if (eng->q3 && eng->fwd_fmt == 1) hipLaunchKernelGGL((k_ln_silu_fwd_pl<2, true>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne);
+    else if (eng->q3) hipLaunchKernelGGL((k_ln_silu_fwd_pl<3, true>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne);
     else hipLaunchKernelGGL((k_ln_silu_fwd_pl<3, false>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne);
   } else {
     hipLaunchKernelGGL(k_ln_silu_fwd, dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.ra, ne);
@@ -534,7 +558,8 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       P.matrix([=, &w]() -> int { return radial_fwd_fc3(eng, w, Lp->rad, ne, w.rad[i]); });
       P.stream([=, &w]() -> int {
         hipStream_t s = eng->stream;
-        if (eng->q3) hipLaunchKernelGGL(k_gather_rotate_mod_q3, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne);
+        if (eng->q3 && eng->fwd_fmt == 1) hipLaunchKernelGGL(k_gather_rotate_mod_q3<1>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne);
+        else if (eng->q3) hipLaunchKernelGGL(k_gather_rotate_mod_q3<0>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne);
         else hipLaunchKernelGGL((k_gather_rotate_mod_pl<3, false>), dim3((nblk(ne, 4) + 7) / 8 * 8), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne);
         HIPCHK(eng, hipGetLastError());
         return UMX_OK;
@@ -547,7 +572,8 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       });
       P.stream([=, &w]() -> int {
         hipStream_t s = eng->stream;
-        if (eng->q3) hipLaunchKernelGGL(k_gate_edge_fwd_q3, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hg[i], w.hidpl, ne);
+        if (eng->q3 && eng->fwd_fmt == 1) hipLaunchKernelGGL(k_gate_edge_fwd_q3<1>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hg[i], w.hidpl, ne);
+        else if (eng->q3) hipLaunchKernelGGL(k_gate_edge_fwd_q3<0>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hg[i], w.hidpl, ne);
         else hipLaunchKernelGGL((k_gate_edge_fwd_pl<3, false>), dim3(nblk(ne * (H / 4), 256)), B256, 0, s, w.hg[i], w.hidpl, ne);
         HIPCHK(eng, hipGetLastError());
         return UMX_OK;
@@ -1036,7 +1062,66 @@ int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes) {
   std::vector<unsigned short> bw;
   struct PlaneReq { const float* dev; size_t off; };
   std::vector<PlaneReq> preq;
+  // precision mode (read here: the weight planes below are packed in the forward operand format it selects)
+  {
+    const char* pv = std::getenv("UMX_PRECISION");
+    const std::string mode = pv ? pv : "split";
+    if (mode == "fp32") eng->pl = false;
+    else if (mode == "split" || mode == "split-f16") { eng->pl = true; eng->fwd_fmt = eng->q3 ? 1 : 0; }   // (the dev layout UMX_Q3=0 has bf16 planes only)
+    else if (mode == "split-bf16") { eng->pl = true; eng->fwd_fmt = 0; }
+    else return fail(eng, UMX_ERR_ARG, "UMX_PRECISION must be split (= split-f16), split-bf16 or fp32");
+    if (mode == "split-f16" && !eng->q3) return fail(eng, UMX_ERR_ARG, "UMX_PRECISION=split-f16 needs the quad-row operand layout (UMX_Q3=1)");
+    // a precision change alters the workspace carve-up: force a re-carve on the next call
+    eng->cap_nodes = 0; eng->cap_edges = 0;
+  }
+  if (const char* ev = std::getenv("UMX_F16_PRODUCTS")) eng->f16_prod = std::atoi(ev) == 3 ? 3 : 4;
+  eng->plane_scale.clear();
+  // IEEE binary16 <- binary32, round to nearest even, subnormals kept (what v_cvt_f16_f32 does for the activations)
+  auto to_half = [](float f) -> unsigned short {
+    uint32_t x; std::memcpy(&x, &f, 4);
+    const unsigned short sign = (unsigned short)((x >> 16) & 0x8000u);
+    x &= 0x7FFFFFFFu;
+    if (x > 0x7F800000u) return (unsigned short)(sign | 0x7E00u);
+    if (x >= 0x477FF000u) return (unsigned short)(sign | 0x7C00u);            // >= 65520 rounds to infinity
+    if (x < 0x38800000u) {                                                    // below 2^-14: a multiple of 2^-24
+      float a; std::memcpy(&a, &x, 4);
+      return (unsigned short)(sign | (unsigned short)std::lrintf(a * 16777216.0f));
+    }
+    uint32_t h = (((x >> 23) - 112u) << 10) | ((x & 0x7FFFFFu) >> 13);
+    const uint32_t rem = x & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;                   // a carry moves into the exponent as it should
+    return (unsigned short)(sign | h);
+  };
+  auto from_half = [](unsigned short h) -> float {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
+    float v;
+    if (e == 0) v = (float)m * (1.0f / 16777216.0f);
+    else { const uint32_t u = ((e + 112u) << 23) | (m << 13); std::memcpy(&v, &u, 4); }     // (weights are finite: no inf/nan case)
+    uint32_t u; std::memcpy(&u, &v, 4); u |= sign; std::memcpy(&v, &u, 4);
+    return v;
+  };
+  // fp16 quad-row copy of a forward weight: PB half planes of s * w, s = the power of two that puts max|w| into [2^14, 2^15).
+  // PB = 3: 33 significand bits -- exact for every weight above max|w| * 2^-16, an absolute 2^-39 max|w| below; PB = 2: 22 bits.
+  auto want_planes_f16 = [&](const float* host, const float* dev, int rows, int K) {
+    const int PB = eng->f16_prod == 3 ? 2 : 3;
+    PlaneReq r{dev, (bw.size() + 63) & ~size_t(63)};
+    bw.resize(r.off + (size_t)rows * K * PB);
+    float mx = 0.f;
+    for (size_t i = 0; i < (size_t)rows * K; ++i) mx = std::max(mx, std::fabs(host[i]));
+    int ex = 0;
+    if (mx > 0.f && std::isfinite(mx)) { std::frexp(mx, &ex); ex = std::max(-24, std::min(40, 15 - ex)); }   // mx = f * 2^ex', f in [0.5, 1)
+    const float sc = std::ldexp(1.0f, ex);
+    eng->plane_scale[dev] = sc;
+    for (int rr = 0; rr < rows; ++rr)
+      for (int k = 0; k < K; ++k) {
+        float x = host[(size_t)rr * K + k] * sc;
+        const size_t o = r.off + (((size_t)(rr / 4) * (K / 16) + k / 16) * (128 * PB) + (size_t)(rr % 4) * (32 * PB) + (size_t)(k % 16) * 2) / 2;
+        for (int q = 0; q < PB; ++q) { const unsigned short hq = to_half(x); bw[o + 16 * q] = hq; x -= from_half(hq); }
+      }
+    preq.push_back(r);
+  };
   auto want_planes = [&](const float* host, const float* dev, int rows, int K, int P) {
+    if (P == 3 && eng->q3 && eng->fwd_fmt == 1) { want_planes_f16(host, dev, rows, K); return; }
     PlaneReq r{dev, (bw.size() + 63) & ~size_t(63)};
     bw.resize(r.off + (size_t)rows * K * P);
     for (int rr = 0; rr < rows; ++rr)
@@ -1074,15 +1159,6 @@ int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes) {
   HIPCHK(eng, hipMemcpy(eng->d_bw, bw.data(), bw.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
   eng->planes.clear();
   for (const auto& r : preq) eng->planes[r.dev] = eng->d_bw + r.off;
-  {
-    const char* pv = std::getenv("UMX_PRECISION");
-    const std::string mode = pv ? pv : "split";
-    if (mode == "fp32") eng->pl = false;
-    else if (mode == "split") eng->pl = true;
-    else return fail(eng, UMX_ERR_ARG, "UMX_PRECISION must be fp32 or split");
-    // a precision change alters the workspace carve-up: force a re-carve on the next call
-    eng->cap_nodes = 0; eng->cap_edges = 0;
-  }
   auto fill_rad = [&](RadialW& r, const std::string& pre, int out) {
     const RadOff& o = roff[pre];
     r.w1g = D(o.w1g); r.w1gT = D(o.w1gT); r.ts = D(o.ts); r.tt = D(o.tt); r.w2T = D(o.w2T); r.w3T = D(o.w3T);
@@ -1232,7 +1308,7 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
     if (eng->ws_cap_default && budget > eng->ws_cap_default) {
       long emax = 0;
       for (long k = 0; k < K; ++k) emax = std::max(emax, (long)img_edges[k]);
-      if (carve(nullptr, N, emax, nullptr, eng->pl) <= eng->ws_cap_default) budget = eng->ws_cap_default;   // (a single image larger than the cap keeps the full budget)
+      if (carve(nullptr, N, emax, nullptr, ws_mode(eng)) <= eng->ws_cap_default) budget = eng->ws_cap_default;   // (a single image larger than the cap keeps the full budget)
     }
   }
   int lanes = (eng->n_lanes >= 2 && K >= 2 && !eng->dbg_on && !eng->gp) ? 2 : 1;      // debug captures name ONE chunk's buffers
@@ -1247,11 +1323,11 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
       long k1 = k0, e = 0;
       while (k1 < K && (k1 - k0) < cap) {
         const long e2 = e + img_edges[k1];
-        if (k1 > k0 && carve(nullptr, (k1 - k0 + 1) * N, e2, nullptr, eng->pl) > budget) break;
+        if (k1 > k0 && carve(nullptr, (k1 - k0 + 1) * N, e2, nullptr, ws_mode(eng)) > budget) break;
         e = e2; ++k1;
       }
-      if (carve(nullptr, (k1 - k0) * N, e, nullptr, eng->pl) > budget)
-        return fail(eng, UMX_ERR_CAPACITY, "one image needs " + std::to_string(carve(nullptr, N, e, nullptr, eng->pl) >> 20) + " MiB of workspace, budget is " +
+      if (carve(nullptr, (k1 - k0) * N, e, nullptr, ws_mode(eng)) > budget)
+        return fail(eng, UMX_ERR_CAPACITY, "one image needs " + std::to_string(carve(nullptr, N, e, nullptr, ws_mode(eng)) >> 20) + " MiB of workspace, budget is " +
                                                std::to_string(budget >> 20) + " MiB");
       chunks.push_back({k0, k1});
       need_nodes = std::max(need_nodes, (k1 - k0) * N);
@@ -1271,16 +1347,16 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
     HIPCHK(eng, hipStreamSynchronize(eng->stream2));
     if (eng->arena) { HIPCHK(eng, hipFree(eng->arena)); eng->arena = nullptr; eng->arena_bytes = 0; }
     const long cn = std::max(need_nodes, eng->cap_nodes), ce = std::max(need_edges + need_edges / 50 + 1024, eng->cap_edges);
-    size_t bytes = carve(nullptr, cn, ce, nullptr, eng->pl);
+    size_t bytes = carve(nullptr, cn, ce, nullptr, ws_mode(eng));
     long ce2 = ce;
-    if (bytes > budget) { ce2 = std::max(need_edges, 1L); bytes = carve(nullptr, cn, ce2, nullptr, eng->pl); }
+    if (bytes > budget) { ce2 = std::max(need_edges, 1L); bytes = carve(nullptr, cn, ce2, nullptr, ws_mode(eng)); }
     HIPCHK(eng, hipMalloc(&eng->arena, lanes * bytes));     // one workspace per lane
     eng->arena_bytes = lanes * bytes; eng->cap_nodes = cn; eng->cap_edges = ce2;
   }
   WS wl[2];
-  if (lanes == 2 && eng->arena_bytes < 2 * carve(nullptr, eng->cap_nodes, eng->cap_edges, nullptr, eng->pl)) lanes = 1;   // arena was sized for one lane
-  const size_t lane_bytes = carve(eng->arena, eng->cap_nodes, eng->cap_edges, &wl[0], eng->pl);
-  if (eng->arena_bytes >= 2 * lane_bytes) carve(eng->arena + lane_bytes, eng->cap_nodes, eng->cap_edges, &wl[1], eng->pl);
+  if (lanes == 2 && eng->arena_bytes < 2 * carve(nullptr, eng->cap_nodes, eng->cap_edges, nullptr, ws_mode(eng))) lanes = 1;   // arena was sized for one lane
+  const size_t lane_bytes = carve(eng->arena, eng->cap_nodes, eng->cap_edges, &wl[0], ws_mode(eng));
+  if (eng->arena_bytes >= 2 * lane_bytes) carve(eng->arena + lane_bytes, eng->cap_nodes, eng->cap_edges, &wl[1], ws_mode(eng));
   if (eng->dbg_on) eng->dbg.clear();
   if (lanes == 2) {          // lane 1 starts after everything enqueued so far on the primary stream (degree pass, caller's work)
     HIPCHK(eng, hipEventRecord(eng->ev_fork, s));
@@ -1417,6 +1493,11 @@ int umx_energy_forces(umx_engine* eng, int n_images, const float* pos, double* e
   HIPCHK(eng, hipMemcpyAsync(energy, eng->d_io_e, (size_t)n_images * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
   if (forces) HIPCHK(eng, hipMemcpyAsync(forces, eng->d_io_f, nt * 3 * sizeof(float), hipMemcpyDeviceToHost, eng->stream));
   HIPCHK(eng, hipStreamSynchronize(eng->stream));
+  for (int k = 0; k < n_images; ++k)
+    if (!std::isfinite(energy[k]))
+      return fail(eng, UMX_ERR_RANGE, "image " + std::to_string(k) + ": non-finite energy" +
+                  (eng->pl && eng->fwd_fmt == 1 ? " (non-finite input, or an activation beyond the fp16 operand range of UMX_PRECISION=split: try split-bf16 or fp32)"
+                                                : " (non-finite input or weights)"));
   return UMX_OK;
 }
 
@@ -1450,7 +1531,7 @@ int umx_profile_read(umx_engine* eng, umx_profile_stats* out, int reset) {
     if (out) {
       const int fam = r.prec > 0 ? 0 : 1;
       out->ms[fam] += t; out->launches[fam] += 1; out->alg_flops[fam] += r.flops;
-      out->mfma_flops[fam] += r.flops * (r.prec == 3 ? 6.0 : r.prec == 2 ? 3.0 : 1.0);
+      out->mfma_flops[fam] += r.flops * (r.prec == 3 ? 6.0 : r.prec == 2 ? 3.0 : r.prec == 24 ? 4.0 : r.prec == 23 ? 3.0 : 1.0);
     }
     if (dump) std::fprintf(dump, "%d,%d,%d,%d,%d,%d,%d,%.6f,%.6e\n", r.M, r.N, r.K, r.amode, r.cplx, r.prec, r.gz, t, r.flops);
   }

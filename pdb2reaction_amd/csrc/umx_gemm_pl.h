@@ -42,6 +42,7 @@ struct GemmPL {
   const float* bias;
   float conj;
   int M, N, K;       // CPLX: M = edges, N = channels per half
+  float cscale;      // fp16-plane kernels only (umx_gemm_q.h, F16 = 1): C = cscale * (A' . B'^T) undoes the power-of-two operand scales
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {

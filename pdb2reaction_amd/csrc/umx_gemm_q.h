@@ -24,38 +24,57 @@
 namespace umx {
 
 template <int P> __device__ __forceinline__ int q_row_off(int row) { return (row >> 2) * (128 * P) + (row & 3) * (32 * P); }
-// LDS-image swizzle: rows whose row group has bit 2 set (tile rows 16-31, 48-63, ...) hold their two 16-B k-halves swapped
-__device__ __forceinline__ int q3_swz_row(int row) { return (row >> 4) & 1; }
-__device__ __forceinline__ int q3_swz_group(int g) { return (g >> 2) & 1; }
+// LDS-image swizzle (P = 3): rows whose row group has bit 2 set (tile rows 16-31, 48-63, ...) hold their two 16-B k-halves swapped.
+// General form: the 16-B chunk index inside a row piece (plane-major, half = LSB) is XOR-ed with q_swz<P>(row group).  P = 3: the half
+// swap above.  P = 2 (256-B blocks, every row group starts on the same bank): a row piece is 4 chunks = 16 banks and the four row groups
+// one ds_read_b128 pass serves ({0,3,5,6} or {1,2,4,7} of a 32-row fragment) must land on four different chunks -> XOR with (g >> 1) & 3.
+template <int P> __device__ __forceinline__ int q_swz(int g) { return P == 3 ? ((g >> 2) & 1) : ((g >> 1) & 3); }
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
 template <int JA, int JBF, int BHALF_ROUND, int A_BYTES, int TAG>
 __device__ __forceinline__ void q3_issue(const unsigned char* A, const unsigned char* B, unsigned char* sbase, const long (&a_off)[JA],
-                                         const long (&b_off)[JBF + BHALF_ROUND], long kofs, int piece, bool b_tail) {
+                                         const long (&b_off)[JBF + BHALF_ROUND], long kofs_a, long kofs_b, int piece, bool b_tail) {
 #pragma unroll
   for (int j = 0; j < JA; ++j)
-    __builtin_amdgcn_global_load_lds(A + a_off[j] + kofs, (__attribute__((address_space(3))) void*)(sbase + piece + j * 8192), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(A + a_off[j] + kofs_a, (__attribute__((address_space(3))) void*)(sbase + piece + j * 8192), 16, 0, 0);
 #pragma unroll
   for (int j = 0; j < JBF; ++j)
-    __builtin_amdgcn_global_load_lds(B + b_off[j] + kofs, (__attribute__((address_space(3))) void*)(sbase + A_BYTES + piece + j * 8192), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(B + b_off[j] + kofs_b, (__attribute__((address_space(3))) void*)(sbase + A_BYTES + piece + j * 8192), 16, 0, 0);
   if constexpr (BHALF_ROUND != 0)
     if (b_tail)                   // wave-uniform: the first four waves fetch the last half round
-      __builtin_amdgcn_global_load_lds(B + b_off[JBF] + kofs, (__attribute__((address_space(3))) void*)(sbase + A_BYTES + piece + JBF * 8192), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(B + b_off[JBF] + kofs_b, (__attribute__((address_space(3))) void*)(sbase + A_BYTES + piece + JBF * 8192), 16, 0, 0);
 }
 
-// P = 3: the forward layout Q3 described above.  P = 2 ("Q2", 256-B blocks of 4 rows x 16 columns x 2 planes) exists for gemm_bench only.
+// which plane products A_qa . B_qb a kernel accumulates:
+//   bf16, 3 x 3 planes, 6 products: qa + qb < 3 (everything down to 2^-16 of the leading term; dropped terms are 2^-24)
+//   fp16, 2 x 3 planes, 4 products: hh, hl, lh and A_hi . B_lo2 -- the weights (B, 33 bits in three half planes) are EXACT, so their
+//         rounding cannot bias every atom the same way (two-plane weights shift the c3 energy by +2.5e-8 eV/atom);
+//         the activations keep 22 bits with unbiased per-element rounding; dropped: A_lo . B_mid (2^-22, random sign) and below
+//   fp16, 2 x 2 planes, 3 or 4 products: hh, hl, lh (+ ll)
+__host__ __device__ constexpr bool q_use_product(int PA, int PB, int NPROD, int qa, int qb) {
+  if (PA == 3 && PB == 3) return qa + qb < 3;
+  if (PA == 2 && PB == 3) return NPROD == 5 ? (qa + qb < 3) : (qa + qb < 2 || (qa == 0 && qb == 2));
+  return NPROD == 4 ? true : (qa + qb < 2);
+}
+
+// P = 3: the forward layout Q3 described above.  P = 2 ("Q2", 256-B blocks of 4 rows x 16 columns x 2 planes): the two-plane forms.
+// F16 = 1: the planes are IEEE half (11-bit significands: two planes carry 22 bits) and the products run on v_mfma_f32_32x32x16_f16.
+// NPROD = number of plane products, PB = planes of the B (weight) operand when it differs from P: see q_use_product.
 // S = ring stages (2: request tile kt+1 while tile kt is consumed; 3: two tiles in flight -- more tolerant of HBM latency when
 // other kernels load the memory system, at 144 KB of LDS for the wide tile).
-template <int CPLX, int WIDE, int P = 3, int S = 2>
+template <int CPLX, int WIDE, int P = 3, int S = 2, int F16 = 0, int NPROD = (P == 3 ? 6 : 3), int PB = P>
 __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
+  static_assert((P == 3 && PB == 3 && NPROD == 6) || (P == 2 && PB == 2 && (NPROD == 3 || NPROD == 4)) || (P == 2 && PB == 3 && (NPROD == 4 || NPROD == 5)), "plane products");
   constexpr int BM = 256, BN = WIDE ? 256 : 128;
   constexpr int BMR = CPLX ? BM / 2 : BM, BNC = CPLX ? BN / 2 : BN;
-  constexpr int RB = 32 * P, BLK = 128 * P, CPB = 8 * P;      // bytes per row per block, bytes per block, 16-B chunks per block
-  constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB, STAGE = A_BYTES + B_BYTES;
+  constexpr int BLK = 128 * P, CPB = 8 * P;               // A: bytes per block, 16-B chunks per block (32 P bytes per row per block)
+  constexpr int BLKB = 128 * PB, CPBB = 8 * PB;           // B likewise
+  constexpr int A_BYTES = BM * 32 * P, B_BYTES = BN * 32 * PB, STAGE = A_BYTES + B_BYTES;
   constexpr int TNW = WIDE ? 4 : 2;                       // 32-column MFMA tiles per wave
   constexpr int JA = A_BYTES / 8192;                      // DMA rounds of the whole block (512 lanes x 16 B)
   constexpr int JBF = B_BYTES / 8192, BHR = (B_BYTES % 8192) ? 1 : 0;
   static_assert(S * STAGE <= 160 * 1024 && A_BYTES % 8192 == 0 && (B_BYTES % 8192 == 0 || B_BYTES % 8192 == 4096), "tile geometry");
-  static_assert(P == 2 || P == 3, "two or three planes");
+  static_assert((P == 2 || P == 3) && (PB == 2 || PB == 3), "two or three planes");
   static_assert(S >= 2 && S <= 4, "ring depth");
   __shared__ __attribute__((aligned(1024))) unsigned char ring[S * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -70,7 +89,7 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
   const unsigned char* Ab = reinterpret_cast<const unsigned char*>(p.Apl);
   const unsigned char* Bb = reinterpret_cast<const unsigned char*>(p.Bpl);
   const long a_blocks = p.lda / (16 * P);                  // 16-column blocks per row of A (lda = columns * P)
-  const long b_blocks = p.K / 16;
+  const long b_blocks = p.K / 16;                          // (ldb is implied: K * PB)
   const long gA = ((long)p.M + 3) / 4;                     // row groups that exist (rows are padded to 4)
   const int gN = p.N / 4;
   long a_off[JA], b_off[JBF + BHR];
@@ -81,15 +100,15 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
     if (CPLX) { grp = (long)mt * (BMR / 4) + (g % (BMR / 4)); offA = (g / (BMR / 4)) ? p.offA1 : p.offA0; }
     else      { grp = (long)mt * (BM / 4) + g;                offA = p.offA0; }
     if (grp >= gA) grp = gA - 1;
-    a_off[j] = (grp * a_blocks + offA / 16) * BLK + (s ^ q3_swz_group(g)) * 16;      // the 16-B half is the LSB of the chunk index
+    a_off[j] = (grp * a_blocks + offA / 16) * BLK + (s ^ q_swz<P>(g)) * 16;          // the 16-B half is the LSB of the chunk index
   }
 #pragma unroll
   for (int j = 0; j < JBF + BHR; ++j) {
-    const int c = tid + 512 * j, g = (c / CPB) % (BN / 4), s = c % CPB;   // (% keeps the unused lanes of a half round in range)
+    const int c = tid + 512 * j, g = (c / CPBB) % (BN / 4), s = c % CPBB; // (% keeps the unused lanes of a half round in range)
     long grp;
     if (CPLX) { int cg = nt * (BNC / 4) + (g % (BNC / 4)); if (cg >= gN) cg = gN - 1; grp = (long)(g / (BNC / 4)) * (p.bHalf / 4) + cg; }
     else      { int cg = nt * (BN / 4) + g; if (cg >= gN) cg = gN - 1; grp = cg; }
-    b_off[j] = grp * b_blocks * BLK + (s ^ q3_swz_group(g)) * 16;
+    b_off[j] = grp * b_blocks * BLKB + (s ^ q_swz<PB>(g)) * 16;
   }
   const int piece = __builtin_amdgcn_readfirstlane(wave * 1024);
   const bool b_tail = __builtin_amdgcn_readfirstlane(wave < 4 ? 1 : 0) != 0;
@@ -102,24 +121,26 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  int a_ad[2], b_ad[TNW];
+  int a_ad[2][P], b_ad[TNW][PB];       // byte address of this lane's 16-B fragment piece, per plane (chunk = plane * 2 + half, swizzled)
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int row = CPLX ? (t * BMR + wm * 32 + l31) : (wm * 64 + t * 32 + l31);
-    a_ad[t] = q_row_off<P>(row) + (h ^ q3_swz_row(row)) * 16;
+#pragma unroll
+    for (int q = 0; q < P; ++q) a_ad[t][q] = q_row_off<P>(row) + ((q * 2 + h) ^ q_swz<P>(row >> 2)) * 16;
   }
 #pragma unroll
   for (int t = 0; t < TNW; ++t) {
     const int row = CPLX ? ((t / (TNW / 2)) * BNC + wn * (16 * TNW) + (t % (TNW / 2)) * 32 + l31) : (wn * (32 * TNW) + t * 32 + l31);
-    b_ad[t] = A_BYTES + q_row_off<P>(row) + (h ^ q3_swz_row(row)) * 16;
+#pragma unroll
+    for (int q = 0; q < PB; ++q) b_ad[t][q] = A_BYTES + q_row_off<PB>(row) + ((q * 2 + h) ^ q_swz<PB>(row >> 2)) * 16;
   }
 
   const int nk = p.K / 16;
-  constexpr int TAG = 9000 + S * 100 + P * 10 + CPLX * 2 + WIDE;
+  constexpr int TAG = 9000 + S * 100 + P * 10 + CPLX * 2 + WIDE + F16 * 1000 + NPROD * 10000 + PB * 100000;   // one q3_issue instance per kernel
   constexpr int GI = JA + JBF;                            // DMA instructions per tile per wave (+1 for the waves that fetch the half round)
 #pragma unroll
   for (int t = 0; t < S - 1; ++t)
-    if (t < nk) q3_issue<JA, JBF, BHR, A_BYTES, TAG>(Ab, Bb, ring + t * STAGE, a_off, b_off, (long)t * BLK, piece, b_tail);
+    if (t < nk) q3_issue<JA, JBF, BHR, A_BYTES, TAG>(Ab, Bb, ring + t * STAGE, a_off, b_off, (long)t * BLK, (long)t * BLKB, piece, b_tail);
   int st_cur = 0, st_nxt = S - 1;
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt has landed once at most the requests of the S-2 younger tiles are outstanding (fewer near the tail: wait for all)
@@ -127,32 +148,38 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
     else if (BHR != 0 && b_tail) wait_vmcnt<(S - 2) * (GI + 1)>();
     else wait_vmcnt<(S - 2) * GI>();
     __builtin_amdgcn_s_barrier();   // tile kt landed everywhere; everyone finished reading tile kt-1
-    if (kt + S - 1 < nk) q3_issue<JA, JBF, BHR, A_BYTES, TAG>(Ab, Bb, ring + st_nxt * STAGE, a_off, b_off, (long)(kt + S - 1) * BLK, piece, b_tail);
+    if (kt + S - 1 < nk) q3_issue<JA, JBF, BHR, A_BYTES, TAG>(Ab, Bb, ring + st_nxt * STAGE, a_off, b_off, (long)(kt + S - 1) * BLK, (long)(kt + S - 1) * BLKB, piece, b_tail);
     const unsigned char* sb = ring + st_cur * STAGE;
     st_cur = st_cur + 1 == S ? 0 : st_cur + 1;
     st_nxt = st_nxt + 1 == S ? 0 : st_nxt + 1;
-    bf16x8_t a[2][P], b[TNW][P];
+    bf16x8_t a[2][P], b[TNW][PB];
 #pragma unroll
-    for (int q = 0; q < P; ++q) {
+    for (int q = 0; q < P; ++q)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) a[t][q] = *reinterpret_cast<const bf16x8_t*>(sb + a_ad[t] + q * 32);
+      for (int t = 0; t < 2; ++t) a[t][q] = *reinterpret_cast<const bf16x8_t*>(sb + a_ad[t][q]);
 #pragma unroll
-      for (int t = 0; t < TNW; ++t) b[t][q] = *reinterpret_cast<const bf16x8_t*>(sb + b_ad[t] + q * 32);
-    }
+    for (int q = 0; q < PB; ++q)
 #pragma unroll
-    for (int ord = P - 1; ord >= 0; --ord)     // smallest terms first
+      for (int t = 0; t < TNW; ++t) b[t][q] = *reinterpret_cast<const bf16x8_t*>(sb + b_ad[t][q]);
 #pragma unroll
-      for (int qa = 0; qa <= ord; ++qa) {
+    for (int ord = P + PB - 2; ord >= 0; --ord)   // smallest terms first
+#pragma unroll
+      for (int qa = 0; qa < P; ++qa) {
         const int qb = ord - qa;
+        if (qb < 0 || qb >= PB || !q_use_product(P, PB, NPROD, qa, qb)) continue;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][qa], b[j][qb], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TNW; ++j) {
+            if constexpr (F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a[i][qa]), __builtin_bit_cast(f16x8_t, b[j][qb]), acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][qa], b[j][qb], acc[i][j], 0, 0, 0);
+          }
       }
   }
 
   // ---- epilogue (C/D map of 32x32 tiles: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)); block-uniform fast path
   const bool full = ((long)mt * BMR + BMR <= p.M) && (nt * BNC + BNC <= p.N);
+  const float cs = F16 ? p.cscale : 1.f;          // a power of two: exact (bf16 planes are unscaled, the multiply folds away)
   if (CPLX) {
 #pragma unroll
     for (int cg = 0; cg < TNW / 2; ++cg) {
@@ -163,8 +190,8 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float* cr = c + (long)((r & 3) + 8 * (r >> 2)) * p.ldc;
-          cr[p.offC] = acc[0][cg][r] - p.conj * acc[1][TNW / 2 + cg][r];
-          cr[p.offCi] = acc[1][cg][r] + p.conj * acc[0][TNW / 2 + cg][r];
+          cr[p.offC] = cs * (acc[0][cg][r] - p.conj * acc[1][TNW / 2 + cg][r]);
+          cr[p.offCi] = cs * (acc[1][cg][r] + p.conj * acc[0][TNW / 2 + cg][r]);
         }
       } else if (chan < p.N) {
 #pragma unroll
@@ -172,8 +199,8 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
           const int dr = (r & 3) + 8 * (r >> 2);
           if (e0 + dr < p.M) {
             float* cr = c + (long)dr * p.ldc;
-            cr[p.offC] = acc[0][cg][r] - p.conj * acc[1][TNW / 2 + cg][r];
-            cr[p.offCi] = acc[1][cg][r] + p.conj * acc[0][TNW / 2 + cg][r];
+            cr[p.offC] = cs * (acc[0][cg][r] - p.conj * acc[1][TNW / 2 + cg][r]);
+            cr[p.offCi] = cs * (acc[1][cg][r] + p.conj * acc[0][TNW / 2 + cg][r]);
           }
         }
       }
@@ -189,12 +216,12 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
         float* c = p.Cp + row0 * p.ldc + p.offC + col;
         if (full) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) c[(long)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[i][j][r] + bv;
+          for (int r = 0; r < 16; ++r) c[(long)((r & 3) + 8 * (r >> 2)) * p.ldc] = cs * acc[i][j][r] + bv;
         } else if (col < p.N) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int dr = (r & 3) + 8 * (r >> 2);
-            if (row0 + dr < p.M) c[(long)dr * p.ldc] = acc[i][j][r] + bv;
+            if (row0 + dr < p.M) c[(long)dr * p.ldc] = cs * acc[i][j][r] + bv;
           }
         }
       }

@@ -36,30 +36,49 @@ template <int P> __device__ __forceinline__ void pl_store4(unsigned short* row, 
   }
 }
 
-// Q3 "quad-row" layout of the FORWARD (3-plane) operands (umx_gemm_q.h): element (row, k, plane q) of a matrix with `cols` columns
-// -> byte ((row/4) * (cols/16) + k/16) * 384 + (row%4) * 96 + q * 32 + (k%16) * 2.   base = start of the matrix.
-__device__ __forceinline__ unsigned short* q3_ptr(unsigned short* base, long row, int cols, int k) {
-  return reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(base) + ((row >> 2) * (cols >> 4) + (k >> 4)) * 384 + (row & 3) * 96 + (k & 15) * 2);
-}
-__device__ __forceinline__ void q3_store2(unsigned short* base, long row, int cols, int k, float x0, float x1) {
-  unsigned short* d = q3_ptr(base, row, cols, k);
+// Quad-row layouts of the FORWARD operands (umx_gemm_q.h), two formats:
+//   FMT 0 ("Q3"):  three bf16 planes of x (exact 24-bit split), 384-B blocks of 4 rows x 16 columns x 3 planes
+//   FMT 1 ("Q2H"): two IEEE-half planes of QF16_SCALE * x (hi = RNE, lo = RNE(residual): 22 significant bits, and below
+//                  2^-14 / QF16_SCALE a fixed absolute resolution of 2^-25 / QF16_SCALE -- half subnormals are kept by the
+//                  conversion and by the MFMA), 256-B blocks.  |x| >= 65520 / QF16_SCALE converts to inf, the low plane to -inf
+//                  and the GEMM output to NaN: a range violation cannot pass silently (the energy comes out non-finite).
+// element (row, k, plane q) of a matrix with `cols` columns -> byte ((row/4) * (cols/16) + k/16) * 128 P + (row%4) * 32 P + q * 32 + (k%16) * 2.
+constexpr float QF16_SCALE = 16.f;
+template <int FMT> struct QFmt { static constexpr int P = FMT ? 2 : 3; static constexpr int BLK = 128 * P; static constexpr int ROWB = 32 * P; };
+// two adjacent values -> one packed dword per plane
+template <int FMT> __device__ __forceinline__ void q_split2(float x0, float x1, unsigned int (&out)[QFmt<FMT>::P]) {
+  if constexpr (FMT == 0) {
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
-    *reinterpret_cast<unsigned int*>(d + q * 16) = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
-    x0 -= (float)h0; x1 -= (float)h1;
+    for (int q = 0; q < 3; ++q) {
+      const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
+      out[q] = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
+      x0 -= (float)h0; x1 -= (float)h1;
+    }
+  } else {
+    x0 *= QF16_SCALE; x1 *= QF16_SCALE;
+    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+    const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
+    out[0] = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
+    out[1] = (unsigned int)__builtin_bit_cast(unsigned short, l0) | ((unsigned int)__builtin_bit_cast(unsigned short, l1) << 16);
   }
 }
-__device__ __forceinline__ void q3_store4(unsigned short* base, long row, int cols, int k, float4 v) {
-  unsigned short* d = q3_ptr(base, row, cols, k);
-  float x[4] = {v.x, v.y, v.z, v.w};
+template <int FMT> __device__ __forceinline__ unsigned short* q_ptr(unsigned short* base, long row, int cols, int k) {
+  return reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(base) + ((row >> 2) * (cols >> 4) + (k >> 4)) * QFmt<FMT>::BLK +
+                                           (row & 3) * QFmt<FMT>::ROWB + (k & 15) * 2);
+}
+template <int FMT> __device__ __forceinline__ void q_store2(unsigned short* base, long row, int cols, int k, float x0, float x1) {
+  unsigned short* d = q_ptr<FMT>(base, row, cols, k);
+  unsigned int w[QFmt<FMT>::P];
+  q_split2<FMT>(x0, x1, w);
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    unsigned short hb[4];
+  for (int q = 0; q < QFmt<FMT>::P; ++q) *reinterpret_cast<unsigned int*>(d + q * 16) = w[q];
+}
+template <int FMT> __device__ __forceinline__ void q_store4(unsigned short* base, long row, int cols, int k, float4 v) {
+  unsigned short* d = q_ptr<FMT>(base, row, cols, k);
+  unsigned int a[QFmt<FMT>::P], b[QFmt<FMT>::P];
+  q_split2<FMT>(v.x, v.y, a); q_split2<FMT>(v.z, v.w, b);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { const __bf16 h = (__bf16)x[c]; hb[c] = __builtin_bit_cast(unsigned short, h); x[c] -= (float)h; }
-    *reinterpret_cast<uint2*>(d + q * 16) = make_uint2((unsigned int)hb[0] | ((unsigned int)hb[1] << 16), (unsigned int)hb[2] | ((unsigned int)hb[3] << 16));
-  }
+  for (int q = 0; q < QFmt<FMT>::P; ++q) *reinterpret_cast<uint2*>(d + q * 16) = make_uint2(a[q], b[q]);
 }
 
 #define UMX_WAVE_ITEM_PL(idx, count)                                                  \
@@ -100,7 +119,7 @@ __global__ __launch_bounds__(256) void k_ln_silu_fwd_pl(const float* __restrict_
   const float rstd = rsqrt_f(var + LN_EPS);
   const float2 ww = *reinterpret_cast<const float2*>(w + c0), bb = *reinterpret_cast<const float2*>(b + c0);
   const float o0 = silu_f(v.x * rstd * ww.x + bb.x), o1 = silu_f(v.y * rstd * ww.y + bb.y);
-  if (Q) q3_store2(y, row, RH, c0, o0, o1);
+  if (Q) q_store2<(P == 2)>(y, row, RH, c0, o0, o1);            // Q with P = 2: the fp16 two-plane format
   else pl_store2<P>(y + row * (RH * P), c0, o0, o1);
   }
 }
@@ -129,26 +148,28 @@ __global__ __launch_bounds__(256) void k_gather_rotate_mod_pl(const float* __res
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
     const float2 m = *reinterpret_cast<const float2*>(rd + ridx[r] * 2 * C + c0);
-    if (Q) q3_store2(y1, e, XROT, r * 2 * C + c0, p[r] * m.x, q[r] * m.y);
+    if (Q) q_store2<(P == 2)>(y1, e, XROT, r * 2 * C + c0, p[r] * m.x, q[r] * m.y);
     else pl_store2<P>(out, r * 2 * C + c0, p[r] * m.x, q[r] * m.y);
   }
   rot_fwd(f, dx, p); rot_fwd(f, dy, q);
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
     const float2 m = *reinterpret_cast<const float2*>(rd + ridx[r] * 2 * C + C + c0);
-    if (Q) q3_store2(y1, e, XROT, r * 2 * C + C + c0, p[r] * m.x, q[r] * m.y);
+    if (Q) q_store2<(P == 2)>(y1, e, XROT, r * 2 * C + C + c0, p[r] * m.x, q[r] * m.y);
     else pl_store2<P>(out, r * 2 * C + C + c0, p[r] * m.x, q[r] * m.y);
   }
 }
 
-// K7a for the Q3 operand layout (umx_gemm_q.h).  A workgroup = the four edges of one Q3 row group.  Per m-primary row r the
-// four waves put their 256 modulated columns x 3 planes into LDS in exactly the byte order of the 16 consecutive 384-B blocks that
-// hold (row group, columns r*256 ... r*256+255), and the whole workgroup then writes those 6 KB with coalesced 16-B stores
+// K7a for the quad-row operand layouts (umx_gemm_q.h; FMT as QFmt).  A workgroup = the four edges of one row group.  Per m-primary
+// row r the four waves put their 256 modulated columns x P planes into LDS in exactly the byte order of the 16 consecutive blocks that
+// hold (row group, columns r*256 ... r*256+255), and the whole workgroup then writes those 6 KB (4 KB) with coalesced 16-B stores
 // (direct stores from the compute layout would be 32-B pieces at a 384-B stride: measured 60 ms instead of 42 ms per iteration).
+template <int FMT>
 __global__ __launch_bounds__(256) void k_gather_rotate_mod_q3(const float* __restrict__ xn, const int* __restrict__ esrc,
                                                               const int* __restrict__ edst, const float* __restrict__ frame,
                                                               const float* __restrict__ rad, unsigned short* __restrict__ y1, long ne) {
-  __shared__ __attribute__((aligned(16))) unsigned int stage[2][16][4][24];      // [buffer][16-column block][row in group][q*8 + pair]
+  constexpr int P = QFmt<FMT>::P, BLK = QFmt<FMT>::BLK;
+  __shared__ __attribute__((aligned(16))) unsigned int stage[2][16][4][8 * P];   // [buffer][16-column block][row in group][q*8 + pair]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long nvb = (((ne + 3) / 4 + 7) / 8) * 8;                                 // virtual blocks = row groups, padded to the 8 XCDs
   const long per = nvb >> 3;                                                     // XCD-contiguous groups (see UMX_WAVE_LOOP_PL_XCD)
@@ -176,15 +197,13 @@ __global__ __launch_bounds__(256) void k_gather_rotate_mod_q3(const float* __res
     rot_fwd(f, sx, ps); rot_fwd(f, sy, qs); rot_fwd(f, dx, pd); rot_fwd(f, dy, qd);
   }
   const int ridx[9] = {0, 1, 2, 3, 4, 3, 4, 5, 5};   // radial row of each m-primary row
-  unsigned char* gbase = reinterpret_cast<unsigned char*>(y1) + grp * (long)(XROT / 16) * 384;
+  unsigned char* gbase = reinterpret_cast<unsigned char*>(y1) + grp * (long)(XROT / 16) * BLK;
   auto put = [&](int buf, int col, float x0, float x1) {
     unsigned int* d = &stage[buf][col >> 4][wave][(col & 15) >> 1];
+    unsigned int w[P];
+    q_split2<FMT>(x0, x1, w);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
-      d[q * 8] = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
-      x0 -= (float)h0; x1 -= (float)h1;
-    }
+    for (int q = 0; q < P; ++q) d[q * 8] = w[q];
   };
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
@@ -194,11 +213,11 @@ __global__ __launch_bounds__(256) void k_gather_rotate_mod_q3(const float* __res
     put(buf, c0, ps[r] * ms.x, qs[r] * ms.y);
     put(buf, C + c0, pd[r] * md.x, qd[r] * md.y);
     __syncthreads();
-    // 16 blocks x 384 B = 6144 B = 384 chunks of 16 B: thread t copies chunk t and, for t < 128, chunk 256 + t
+    // 16 blocks x 128 P bytes = 128 P chunks of 16 B: thread t copies chunk t and (P = 3), for t < 128, chunk 256 + t
     const uint4* src = reinterpret_cast<const uint4*>(&stage[buf][0][0][0]);
-    uint4* dst = reinterpret_cast<uint4*>(gbase + (long)r * 16 * 384);
+    uint4* dst = reinterpret_cast<uint4*>(gbase + (long)r * 16 * BLK);
     dst[threadIdx.x] = src[threadIdx.x];
-    if (threadIdx.x < 128) dst[256 + threadIdx.x] = src[256 + threadIdx.x];
+    if (P == 3 && threadIdx.x < 128) dst[256 + threadIdx.x] = src[256 + threadIdx.x];
   }
   }
 }
@@ -225,16 +244,18 @@ __global__ void k_gate_edge_fwd_pl(const float* __restrict__ hg, unsigned short*
       const float4 s = l1 ? s1 : s2;
       w = make_float4(v.x * s.x, v.y * s.y, v.z * s.z, v.w * s.w);
     }
-    if (Q) q3_store4(hid, e, ROW, r * H + c, w);
+    if (Q) q_store4<(P == 2)>(hid, e, ROW, r * H + c, w);
     else pl_store4<P>(o, r * H + c, w);
   }
 }
 
-// SO(2) gate for the Q3 operand layout: a workgroup = 8 edges = two Q3 row groups; per m-primary row the gated 128 columns x 3
-// planes of the 8 edges are staged in LDS in the byte order of their 2 x 8 consecutive 384-B blocks and written with coalesced
+// SO(2) gate for the quad-row operand layouts: a workgroup = 8 edges = two row groups; per m-primary row the gated 128 columns x P
+// planes of the 8 edges are staged in LDS in the byte order of their 2 x 8 consecutive blocks and written with coalesced
 // 16-B stores (same reason as k_gather_rotate_mod_q3).
+template <int FMT>
 __global__ __launch_bounds__(256) void k_gate_edge_fwd_q3(const float* __restrict__ hg, unsigned short* __restrict__ hid, long ne) {
-  __shared__ __attribute__((aligned(16))) unsigned int stage[2][2][8][4][24];    // [buffer][row group][16-column block][row][q*8 + pair]
+  constexpr int P = QFmt<FMT>::P, BLK = QFmt<FMT>::BLK;
+  __shared__ __attribute__((aligned(16))) unsigned int stage[2][2][8][4][8 * P]; // [buffer][row group][16-column block][row][q*8 + pair]
   const long nvb = (ne + 7) / 8;
   for (long vb = blockIdx.x; vb < nvb; vb += gridDim.x) {                        // grid-stride over groups of 8 edges: any grid size works
   const long e0 = vb * 8;
@@ -246,7 +267,7 @@ __global__ __launch_bounds__(256) void k_gate_edge_fwd_q3(const float* __restric
   const float4 g1 = *reinterpret_cast<const float4*>(p + c), g2 = *reinterpret_cast<const float4*>(p + H + c);
   const float4 s1 = make_float4(sigmoid_f(g1.x), sigmoid_f(g1.y), sigmoid_f(g1.z), sigmoid_f(g1.w));
   const float4 s2 = make_float4(sigmoid_f(g2.x), sigmoid_f(g2.y), sigmoid_f(g2.z), sigmoid_f(g2.w));
-  unsigned char* gbase = reinterpret_cast<unsigned char*>(hid) + (e0 >> 2) * (long)(ROW / 16) * 384;
+  unsigned char* gbase = reinterpret_cast<unsigned char*>(hid) + (e0 >> 2) * (long)(ROW / 16) * BLK;
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
     const int buf = r & 1;
@@ -259,22 +280,20 @@ __global__ __launch_bounds__(256) void k_gate_edge_fwd_q3(const float* __restric
       x[0] = v.x * sg.x; x[1] = v.y * sg.y; x[2] = v.z * sg.z; x[3] = v.w * sg.w;
     }
     unsigned int* d = &stage[buf][le >> 2][c >> 4][le & 3][(c & 15) >> 1];
+    unsigned int wa[P], wb[P];
+    q_split2<FMT>(x[0], x[1], wa); q_split2<FMT>(x[2], x[3], wb);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      unsigned short hb[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { const __bf16 hh = (__bf16)x[k]; hb[k] = __builtin_bit_cast(unsigned short, hh); x[k] -= (float)hh; }
-      *reinterpret_cast<uint2*>(d + q * 8) = make_uint2((unsigned int)hb[0] | ((unsigned int)hb[1] << 16), (unsigned int)hb[2] | ((unsigned int)hb[3] << 16));
-    }
+    for (int q = 0; q < P; ++q) *reinterpret_cast<uint2*>(d + q * 8) = make_uint2(wa[q], wb[q]);
     __syncthreads();
-    // per row group: 8 blocks x 384 B = 3072 B = 192 chunks of 16 B; 384 chunks in all
+    // per row group: 8 blocks x 128 P bytes = 64 P chunks of 16 B; 128 P chunks in all
+    constexpr int CPG = 64 * P;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < (P == 3 ? 2 : 1); ++it) {
       const int ch = threadIdx.x + 256 * it;
-      const int g = ch / 192, o = ch % 192;
-      if (ch < 384 && e0 + 4 * g < ne) {          // the second row group may lie entirely beyond the (4-row padded) buffer
+      const int g = ch / CPG, o = ch % CPG;
+      if (ch < 2 * CPG && e0 + 4 * g < ne) {      // the second row group may lie entirely beyond the (4-row padded) buffer
         const uint4 val = reinterpret_cast<const uint4*>(&stage[buf][g][0][0][0])[o];
-        reinterpret_cast<uint4*>(gbase + (long)g * (ROW / 16) * 384 + (long)r * 8 * 384)[o] = val;
+        reinterpret_cast<uint4*>(gbase + (long)g * (ROW / 16) * BLK + (long)r * 8 * BLK)[o] = val;
       }
     }
   }

@@ -118,11 +118,11 @@ __device__ __forceinline__ void rad_mma(const float* __restrict__ a_lds, const f
 }
 
 // ---- forward: d, Z_src, Z_dst  ->  h1pre, h2pre (kept for the reverse pass) and the fc3 operand --------------------------------
-// OUTQ3 = true: the fc3 operand as Q3 bf16 planes (umx_gemm_q.h);  false: fp32 rows (fp32 precision mode, and the edge-degree MLP
-// whose fc3 runs on the fp32 GEMM).   ts / tt: per-element tables of the embedding part of fc1 (tt includes the fc1 bias).
+// OUTQ3 = 1: the fc3 operand as Q3 bf16 planes (umx_gemm_q.h), 2: as fp16 two-plane "Q2H" planes (QFmt<1>);  0: fp32 rows (fp32
+// precision mode, and the edge-degree MLP whose fc3 runs on the fp32 GEMM).   ts / tt: per-element tables of the embedding part of fc1 (tt includes the fc1 bias).
 // TR = 32-row MFMA tiles per workgroup tile (RT = 32 TR edges).  TR = 1 halves the LDS and accumulator footprint so that three
 // workgroups share a CU: the VALU-heavy LayerNorm passes of one overlap the MFMAs of the others (measured against TR = 2 below).
-template <bool OUTQ3, int FAST, int TR>
+template <int OUTQ3, int FAST, int TR>
 __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const float* __restrict__ evec, const int* __restrict__ ez, float gcoef,
                                                         const float* __restrict__ gmu, const float* __restrict__ w1g,
                                                         const float* __restrict__ ts, const float* __restrict__ tt,
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
       const float2 o = ln_silu_row<FAST>(v, l2w, l2b);
       if (e < ne) {
         *reinterpret_cast<float2*>(h2pre + e * RH + 2 * lane) = v;
-        if (OUTQ3) q3_store2(reinterpret_cast<unsigned short*>(out), e, RH, 2 * lane, o.x, o.y);
+        if (OUTQ3) q_store2<(OUTQ3 == 2)>(reinterpret_cast<unsigned short*>(out), e, RH, 2 * lane, o.x, o.y);
         else *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + e * RH + 2 * lane) = o;
       }
     }

@@ -32,9 +32,10 @@ def gold():
     return load_golden("c3c4_n2000")
 
 
-@pytest.mark.parametrize("mode", ["split", "fp32"])
+@pytest.mark.parametrize("mode", ["split", "split-bf16", "fp32"])
 def test_c3_energy_and_forces_against_f64_oracle(weights, gold, mode, monkeypatch):
-    """The headline configuration: E and F of 2000-atom images vs the float64 oracle, both precision modes."""
+    """The headline configuration: E and F of 2000-atom images vs the float64 oracle, every precision mode (split = fp16 forward
+    planes, the default; split-bf16 = three bf16 forward planes; fp32 = fp32 MFMA everywhere)."""
     from pdb2reaction_amd.engine import Engine
 
     monkeypatch.setenv("UMX_PRECISION", mode)
@@ -188,7 +189,7 @@ def test_c2_c3_gsm_driver_at_baseline_sizes(n_atoms, n_img, gold):
     calc.close()
 
 
-@pytest.mark.parametrize("mode", ["split", "fp32"])
+@pytest.mark.parametrize("mode", ["split", "split-bf16", "fp32"])
 def test_c5_energy_and_forces_against_f64_oracle(weights, mode, monkeypatch):
     """BASELINE configs[4]: a 20 000-atom image (1.6 M directed edges; one image needs 190 GB of workspace, i.e. more than the default
     cap -- the engine then takes the full budget).  E and F against the float64 oracle (tools/make_golden_c5.py), both precision modes.
@@ -196,7 +197,8 @@ def test_c5_energy_and_forces_against_f64_oracle(weights, mode, monkeypatch):
     Energy tolerance at this size: float32 ACTIVATIONS round quantities that every atom shares (system embedding, per-element rows),
     so any float32 implementation deviates from float64 arithmetic by an amount proportional to N.  Measured against this oracle: a
     plain torch-float32 restatement (the reference's dtype and op style) is off by 1.2e-7 eV per atom (-5.9e-5 eV at 500 atoms,
-    i.e. -2.4e-3 eV at this size); the engine by 4e-9 (split) / 1.4e-8 (fp32 mode) eV per atom.  The north-star's absolute 1e-4 eV
+    i.e. -2.4e-3 eV at this size); the engine by 4e-9 (split-bf16) / 1.7e-8 (split: the fp16 MFMA's adder truncates, a gain of
+    -1.8e-8 per GEMM) / 1.4e-8 (fp32 mode) eV per atom.  The north-star's absolute 1e-4 eV
     is held up to the headline size (2000 atoms, 6x margin); here the bound is 2.5e-8 eV per atom (5e-4 eV), five times tighter than
     what float32 torch arithmetic itself achieves, and the forces keep the absolute 1e-3 eV/A."""
     from pdb2reaction_amd.engine import Engine

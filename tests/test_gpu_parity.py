@@ -66,10 +66,11 @@ def test_c3_energy_golden(engine):
     assert np.abs(e - g["c3_energy"]).max() <= TOL_E
 
 
-@pytest.mark.parametrize("mode", ["fp32", "split"])
+@pytest.mark.parametrize("mode", ["fp32", "split", "split-bf16"])
 def test_precision_modes(weights, oracle, mode, monkeypatch):
-    """UMX_PRECISION: fp32-MFMA everywhere, or split-bf16 planes (6-term forward / 3-term reverse, LDS-DMA GEMM) on the large SO(2)/radial
-    GEMMs -- every mode must hold the north-star tolerances."""
+    """UMX_PRECISION: fp32-MFMA everywhere, or split planes on the large SO(2)/radial GEMMs (LDS-DMA GEMM; forward: two fp16 activation
+    planes x three exact fp16 weight planes, 4 products -- or three bf16 planes, 6 products; reverse: two bf16 planes, 3 products)
+    -- every mode must hold the north-star tolerances."""
     from pdb2reaction_amd.engine import Engine
 
     monkeypatch.setenv("UMX_PRECISION", mode)
@@ -78,6 +79,36 @@ def test_precision_modes(weights, oracle, mode, monkeypatch):
         eng.load_weights(weights)
         z, imgs, _ = synth.make_images(150, 2, seed=13)
         check(eng, oracle, z, imgs)
+    finally:
+        eng.close()
+
+
+def test_fp16_operand_range_is_guarded(weights, monkeypatch):
+    """The default mode keeps the forward GEMM operands as fp16 planes of 16 x (activation): an activation beyond +-4094 converts to
+    inf, the GEMM output to NaN and the host-buffer entry must refuse the result (UMX_ERR_RANGE) instead of returning it; the bf16-plane
+    mode has float32's range and evaluates the same (absurd) weights to finite numbers."""
+    from pdb2reaction_amd.engine import Engine
+
+    big = dict(weights)
+    key = "blocks.0.edge_wise.so2_conv_1.rad_func.fc3"
+    big[key + ".weight"] = (np.asarray(weights[key + ".weight"]) * 3e4).astype(np.float32)
+    z, imgs, _ = synth.make_images(40, 1, seed=2)
+    monkeypatch.setenv("UMX_PRECISION", "split")
+    eng = Engine(0)
+    try:
+        eng.load_weights(big)
+        eng.set_system(z)
+        with pytest.raises(RuntimeError, match="non-finite energy.*fp16 operand range"):
+            eng.energy_forces(imgs)
+    finally:
+        eng.close()
+    monkeypatch.setenv("UMX_PRECISION", "split-bf16")
+    eng = Engine(0)
+    try:
+        eng.load_weights(big)
+        eng.set_system(z)
+        e, f = eng.energy_forces(imgs)
+        assert np.isfinite(e).all() and np.isfinite(f).all()
     finally:
         eng.close()
 
@@ -205,7 +236,7 @@ def test_device_pointer_entry_is_stream_ordered(engine):
         assert np.array_equal(out[2], e_ref2) and np.array_equal(out[3], f_ref2.astype(np.float64))
 
 
-@pytest.mark.parametrize("mode", ["fp32", "split"])
+@pytest.mark.parametrize("mode", ["fp32", "split", "split-bf16"])
 def test_stage_by_stage_against_staged_oracle(weights, mode, monkeypatch):
     """Every intermediate of the forward AND of the analytic reverse pass vs oracle/staged.py, in both precision modes
     (the split-bf16 path keeps its GEMM operands as bf16 planes, so fewer fp32 intermediates exist there)."""

@@ -12,10 +12,11 @@ is fixed by BASELINE.json's workload, N=1 evaluates all 16 images on one GPU).
 
 Rank 0 prints ONE JSON line (contract in the task statement) carrying
 
-* `roofline`: the dominant kernel family = the split-bf16 LDS-DMA GEMMs (SO(2) / radial linears and their transposes),
+* `roofline`: the dominant kernel family = the split-precision LDS-DMA GEMMs (SO(2) / radial linears and their transposes),
   timed live with HIP events on the launch stream.  `achieved` / `frac` are ALGORITHMIC: 2*M*N*K per product (SURVEY.md
-  8d / Appendix D) over the measured kernel time, against the dense bf16 MFMA peak.  The 6x / 3x redundant bf16 products of
-  the 3-plane / 2-plane split are emulation overhead, reported separately as `mfma_pipe_util` (executed FLOPs / peak).
+  8d / Appendix D) over the measured kernel time, against the dense 16-bit MFMA peak (fp16 = bf16 rate).  The redundant plane
+  products of the split (forward: x4 on fp16 planes in the default mode, x6 on bf16 planes in split-bf16; reverse: x3 on bf16
+  planes) are emulation overhead, reported separately as `mfma_pipe_util` (executed FLOPs / peak).
   `traffic` (HBM bytes per launch from rocprofv3 PMC passes) is only emitted when the committed summary under profiles/
   was measured on EXACTLY this build (source digest compiled into libumx.so), else null + `traffic_source` says why;
 * `fp32_mode`: the same workload on the all-fp32-MFMA build of the engine (`UMX_PRECISION=fp32`, the strict
@@ -45,7 +46,7 @@ from pdb2reaction_amd.uma_pysis import EV2AU, F_EVAA_2_AU  # noqa: E402
 
 FLOP_PER_EDGE = 30.98e6          # algorithmic E+F work per directed edge
 PEAK_FP32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense f32 matrix peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparse headline)
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (not the 2:1-sparse headline)
 
 
 PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_hbm_traffic.json")
@@ -231,7 +232,9 @@ def main():
             "metric": "path_opt_string_iterations_per_s", "value": it_s, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "bf16x3-split (fp32-equivalent 24-bit products fwd, 16-bit reverse pass), fp32 accumulate" if split else "f32",
+            "dtype": (("fp16x2-split fwd (2 activation x 3 exact weight planes, 4 products: fp32-level), " if mode in ("split", "split-f16")
+                       else "bf16x3-split fwd (6 products: 24-bit), ") + "bf16x2-split reverse (3 products: 16-bit), fp32 accumulate") if split else "f32",
+            "precision_mode": mode,
             "data": "synthetic",
             "image_atom_steps_per_s": k * n * it_s,
             "algorithmic_tflops": FLOP_PER_EDGE * edges_iter * it_s / 1e12,
@@ -242,10 +245,10 @@ def main():
                        "parallelism": f"images sharded {k}/{world} per GPU, 1 all-gather/iteration" if world > 1 else "single GPU, all images batched"},
             "roofline": {"bound": "mfma", "achieved": alg, "peak": peak, "unit": "TFLOP/s", "frac": alg / peak,
                          "definition": "achieved = algorithmic FLOPs (2*M*N*K per product, SURVEY.md 8d) of the family / its HIP-event time; "
-                                       "mfma_pipe_util counts the bf16 products actually executed (x6 fwd, x3 reverse)",
+                                       "mfma_pipe_util counts the plane products actually executed (fwd x4 fp16 / x6 bf16, reverse x3)",
                          "mfma_pipe_util": executed / peak, "executed_tflops": executed,
                          "traffic": float(pmc["dominant_family"]["hbm_bytes_per_launch_avg"]) if pmc else None, "traffic_source": pmc_note,
-                         "kernel": ("umx_gemm_q_kernel<*> / umx_gemm_pl16_kernel<*> / umx_gemm_pl_kernel<*> (split-bf16 LDS-DMA GEMM family: SO(2)/radial linears + transposes, rank 0)" if split
+                         "kernel": ("umx_gemm_q_kernel<*> / umx_gemm_pl16_kernel<*> / umx_gemm_pl_kernel<*> (split-precision LDS-DMA GEMM family: SO(2)/radial linears + transposes, rank 0)" if split
                                     else "umx_gemm_kernel<*> (fp32-MFMA GEMM, rank 0)"),
                          "launches": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
                          "algorithmic_flops_per_launch": dom["alg_flops"] / max(dom["launches"], 1),

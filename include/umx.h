@@ -63,6 +63,11 @@ const char* umx_last_error(const umx_engine* eng);
  *   fp32       : every GEMM on the fp32 MFMA.                                                                          */
 int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes);
 
+/* Precision mode for the NEXT umx_load_weights ("split", "split-f16", "split-bf16", "fp32"); NULL or "" = back to the
+ * UMX_PRECISION environment variable.  The Python binding uses it to re-load an engine in split-bf16 when an evaluation
+ * returned UMX_ERR_RANGE (ABI v6).                                                                                   */
+int umx_set_precision(umx_engine* eng, const char* mode);
+
 /* Bind the chemical system shared by every image: atomic numbers, total charge, spin
  * multiplicity, task ("dataset") index into {oc20, omol, omat, odac, omc}; cutoff radius in
  * Angstrom (<=0: model default 6.0) and neighbour cap (<=0: model default 300).

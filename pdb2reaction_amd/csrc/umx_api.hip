@@ -65,6 +65,7 @@ struct umx_engine {
   bool q3_wide = true;             // UMX_Q3WIDE=0 (dev): 256x128 tiles for every forward GEMM
   bool q3 = true;                  // UMX_Q3=0: forward operands in the 32-column PL layout + 256x128 tiles (set before umx_load_weights)
   int fwd_fmt = 1;                 // forward operand format (QFmt, umx_kernels_pl.h): 1 = two fp16 planes (UMX_PRECISION=split), 0 = three bf16 planes (split-bf16)
+  std::string precision;           // umx_set_precision: overrides UMX_PRECISION when non-empty
   int f16_prod = 4;                // plane products of the fp16 form (UMX_F16_PRODUCTS): 4 = exact three-plane weights (hh, hl, lh, h.lo2),
                                    // 3 = two-plane weights (hh, hl, lh; biases the energy by ~2.5e-8 eV/atom)
   std::map<const float*, float> plane_scale;             // fp16 form: power-of-two scale folded into the weight planes
@@ -845,7 +846,7 @@ std::vector<float> transpose(const float* src, int rows, int cols) {
 // ================================================================================================
 extern "C" {
 
-int umx_abi_version(void) { return 5; }
+int umx_abi_version(void) { return 6; }
 
 #ifndef UMX_SRC_DIGEST
 #define UMX_SRC_DIGEST "unknown"
@@ -1065,7 +1066,7 @@ int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes) {
   // precision mode (read here: the weight planes below are packed in the forward operand format it selects)
   {
     const char* pv = std::getenv("UMX_PRECISION");
-    const std::string mode = pv ? pv : "split";
+    const std::string mode = !eng->precision.empty() ? eng->precision : (pv ? pv : "split");
     if (mode == "fp32") eng->pl = false;
     else if (mode == "split" || mode == "split-f16") { eng->pl = true; eng->fwd_fmt = eng->q3 ? 1 : 0; }   // (the dev layout UMX_Q3=0 has bf16 planes only)
     else if (mode == "split-bf16") { eng->pl = true; eng->fwd_fmt = 0; }
@@ -1488,6 +1489,8 @@ int umx_energy_forces(umx_engine* eng, int n_images, const float* pos, double* e
     HIPCHK(eng, hipMalloc(&eng->d_io_e, (size_t)n_images * sizeof(double)));
     eng->io_img_cap = n_images;
   }
+  for (long i = 0; i < nt * 3; ++i)         // a NaN coordinate would silently drop its atom from the radius graph (every comparison false)
+    if (!std::isfinite(pos[i])) return fail(eng, UMX_ERR_ARG, "umx_energy_forces: non-finite position (image " + std::to_string(i / ((long)eng->natoms * 3)) + ")");
   HIPCHK(eng, hipMemcpyAsync(eng->d_io_pos, pos, nt * 3 * sizeof(float), hipMemcpyHostToDevice, eng->stream));
   CHK(energy_forces_on(eng, eng->stream, n_images, eng->d_io_pos, eng->d_io_e, forces ? eng->d_io_f : nullptr));
   HIPCHK(eng, hipMemcpyAsync(energy, eng->d_io_e, (size_t)n_images * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
@@ -1496,8 +1499,17 @@ int umx_energy_forces(umx_engine* eng, int n_images, const float* pos, double* e
   for (int k = 0; k < n_images; ++k)
     if (!std::isfinite(energy[k]))
       return fail(eng, UMX_ERR_RANGE, "image " + std::to_string(k) + ": non-finite energy" +
-                  (eng->pl && eng->fwd_fmt == 1 ? " (non-finite input, or an activation beyond the fp16 operand range of UMX_PRECISION=split: try split-bf16 or fp32)"
-                                                : " (non-finite input or weights)"));
+                  (eng->pl && eng->fwd_fmt == 1 ? " (an activation beyond the fp16 operand range of UMX_PRECISION=split: try split-bf16 or fp32 -- or non-finite weights)"
+                                                : " (non-finite weights, or an overflow in float32)"));
+  return UMX_OK;
+}
+
+int umx_set_precision(umx_engine* eng, const char* mode) {
+  if (!eng) return UMX_ERR_ARG;
+  const std::string m = mode ? mode : "";
+  if (!m.empty() && m != "split" && m != "split-f16" && m != "split-bf16" && m != "fp32")
+    return fail(eng, UMX_ERR_ARG, "umx_set_precision: mode must be split, split-f16, split-bf16 or fp32");
+  eng->precision = m;
   return UMX_OK;
 }
 

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import warnings
 from typing import Dict, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -23,6 +24,9 @@ class ProfileStats(C.Structure):
     """Mirror of ``umx_profile_stats`` (include/umx.h): [0] split-bf16 PL GEMM family, [1] fp32-MFMA GEMM family."""
 
     _fields_ = [("ms", C.c_double * 2), ("launches", C.c_int64 * 2), ("alg_flops", C.c_double * 2), ("mfma_flops", C.c_double * 2)]
+
+
+UMX_ERR_RANGE = -6      # include/umx.h
 
 
 class UmxError(RuntimeError):
@@ -64,6 +68,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "umx_destroy": ([vp], i32),
         "umx_last_error": ([vp], C.c_char_p),
         "umx_load_weights": ([vp, vp, C.c_size_t], i32),
+        "umx_set_precision": ([vp, C.c_char_p], i32),
         "umx_set_system": ([vp, i32, C.POINTER(C.c_int32), i32, i32, i32, C.c_float, i32], i32),
         "umx_set_workspace_limit": ([vp, C.c_size_t], i32),
         "umx_energy_forces": ([vp, i32, fp, dp, fp], i32),
@@ -95,7 +100,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = (
-    "umx_abi_version", "umx_build_digest", "umx_create", "umx_destroy", "umx_last_error", "umx_load_weights", "umx_set_system",
+    "umx_abi_version", "umx_build_digest", "umx_create", "umx_destroy", "umx_last_error", "umx_load_weights", "umx_set_precision", "umx_set_system",
     "umx_set_workspace_limit", "umx_energy_forces", "umx_energy_forces_dev", "umx_gp_begin", "umx_gp_step", "umx_synchronize",
     "umx_last_graph_stats", "umx_profile_enable", "umx_profile_read", "umx_bond_changes", "umx_debug_fetch", "umx_debug_keep",
 )
@@ -104,7 +109,8 @@ EXPORTED_SYMBOLS = (
 class Engine:
     """One UMA-S engine on one GPU (one per process/rank)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, precision: Optional[str] = None):
+        """precision: None = the UMX_PRECISION environment variable (default "split"), else "split" | "split-bf16" | "fp32"."""
         self.lib = load_library()
         self._h = C.c_void_p()
         st = self.lib.umx_create(C.byref(self._h), int(device))
@@ -112,6 +118,12 @@ class Engine:
             raise UmxError(f"umx_create failed ({st}): {self.lib.umx_last_error(None).decode()}")
         self.device = int(device)
         self.natoms = 0
+        self.precision = precision
+        self.widened = False            # True once an fp16 range violation moved this engine to split-bf16
+        self._blob = None
+        self._system = None
+        if precision is not None:
+            self._chk(self.lib.umx_set_precision(self._h, precision.encode()), "umx_set_precision")
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -126,13 +138,16 @@ class Engine:
 
     def _chk(self, st: int, what: str):
         if st != 0:
-            raise UmxError(f"{what} failed ({st}): {self.lib.umx_last_error(self._h).decode()}")
+            err = UmxError(f"{what} failed ({st}): {self.lib.umx_last_error(self._h).decode()}")
+            err.status = st
+            raise err
 
     # ---- setup -----------------------------------------------------------------------------------
     def load_weights(self, weights: Union[bytes, Dict[str, np.ndarray]]):
         blob = weights if isinstance(weights, (bytes, bytearray)) else W.pack_blob(weights)
-        buf = C.create_string_buffer(bytes(blob), len(blob))
-        self._chk(self.lib.umx_load_weights(self._h, C.cast(buf, C.c_void_p), len(blob)), "umx_load_weights")
+        self._blob = bytes(blob)        # kept (~27 MB) so that a range violation can re-load the engine in split-bf16
+        buf = C.create_string_buffer(self._blob, len(self._blob))
+        self._chk(self.lib.umx_load_weights(self._h, C.cast(buf, C.c_void_p), len(self._blob)), "umx_load_weights")
 
     def set_system(self, atomic_numbers: Sequence[int], charge: int = 0, spin: int = 1, task: str = "omol",
                    radius: Optional[float] = None, max_neigh: Optional[int] = None):
@@ -143,6 +158,7 @@ class Engine:
                                           W.DATASET_LIST.index(task), float(radius or 0.0), int(max_neigh or 0)),
                   "umx_set_system")
         self.natoms = len(z)
+        self._system = (z.copy(), int(charge), int(spin), task, radius, max_neigh)
 
     def set_workspace_limit(self, nbytes: int):
         self._chk(self.lib.umx_set_workspace_limit(self._h, int(nbytes)), "umx_set_workspace_limit")
@@ -159,9 +175,32 @@ class Engine:
         e = np.empty(k, dtype=np.float64)
         f = np.empty_like(p) if forces else None
         fp = C.POINTER(C.c_float)
-        self._chk(self.lib.umx_energy_forces(self._h, k, p.ctypes.data_as(fp), e.ctypes.data_as(C.POINTER(C.c_double)),
-                                             f.ctypes.data_as(fp) if forces else None), "umx_energy_forces")
+        try:
+            self._chk(self.lib.umx_energy_forces(self._h, k, p.ctypes.data_as(fp), e.ctypes.data_as(C.POINTER(C.c_double)),
+                                                 f.ctypes.data_as(fp) if forces else None), "umx_energy_forces")
+        except UmxError as err:
+            # UMX_ERR_RANGE in the default mode (the input was finite, the entry checks): an activation left the fp16 operand range.  Same HIP path,
+            # wider operands: re-load this engine with three bf16 forward planes (float32's range) and evaluate again.
+            if getattr(err, "status", 0) != UMX_ERR_RANGE or not self._widen(str(err)):
+                raise
+            self._chk(self.lib.umx_energy_forces(self._h, k, p.ctypes.data_as(fp), e.ctypes.data_as(C.POINTER(C.c_double)),
+                                                 f.ctypes.data_as(fp) if forces else None), "umx_energy_forces")
         return e, f
+
+    def _widen(self, why: str) -> bool:
+        """Move an engine in the default mode to UMX_PRECISION=split-bf16 (once); False when that is not the mode in use."""
+        mode = self.precision or os.environ.get("UMX_PRECISION", "split")
+        if self.widened or mode not in ("split", "split-f16") or self._blob is None or self._system is None:
+            return False
+        if os.environ.get("UMX_NO_WIDEN", "0") == "1":
+            return False
+        warnings.warn(f"pdb2reaction_amd: {why} -- re-loading the engine with bf16 forward planes (UMX_PRECISION=split-bf16)", RuntimeWarning)
+        self._chk(self.lib.umx_set_precision(self._h, b"split-bf16"), "umx_set_precision")
+        self.precision, self.widened = "split-bf16", True
+        self.load_weights(self._blob)
+        z, charge, spin, task, radius, max_neigh = self._system
+        self.set_system(z, charge, spin, task, radius, max_neigh)
+        return True
 
     def energy_forces_dev(self, n_images: int, d_pos: int, d_energy: int, d_forces: Optional[int], stream: int = 0):
         """Device-pointer form (integers from e.g. ``tensor.data_ptr()``); enqueues on ``stream``, a ``hipStream_t`` handle

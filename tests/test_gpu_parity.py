@@ -85,32 +85,47 @@ def test_precision_modes(weights, oracle, mode, monkeypatch):
 
 def test_fp16_operand_range_is_guarded(weights, monkeypatch):
     """The default mode keeps the forward GEMM operands as fp16 planes of 16 x (activation): an activation beyond +-4094 converts to
-    inf, the GEMM output to NaN and the host-buffer entry must refuse the result (UMX_ERR_RANGE) instead of returning it; the bf16-plane
-    mode has float32's range and evaluates the same (absurd) weights to finite numbers."""
-    from pdb2reaction_amd.engine import Engine
+    inf, the GEMM output to NaN and the host-buffer entry refuses the result (UMX_ERR_RANGE) instead of returning it.  The binding
+    then re-loads the SAME engine with bf16 forward planes (float32's range; still the HIP path) and evaluates again -- the answer
+    is bitwise what an engine created in split-bf16 gives for the same (absurd) weights."""
+    from pdb2reaction_amd.engine import Engine, UmxError, UMX_ERR_RANGE
 
     big = dict(weights)
     key = "blocks.0.edge_wise.so2_conv_1.rad_func.fc3"
     big[key + ".weight"] = (np.asarray(weights[key + ".weight"]) * 3e4).astype(np.float32)
     z, imgs, _ = synth.make_images(40, 1, seed=2)
     monkeypatch.setenv("UMX_PRECISION", "split")
+    monkeypatch.setenv("UMX_NO_WIDEN", "1")
     eng = Engine(0)
     try:
         eng.load_weights(big)
         eng.set_system(z)
-        with pytest.raises(RuntimeError, match="non-finite energy.*fp16 operand range"):
+        with pytest.raises(UmxError, match="non-finite energy.*fp16 operand range") as ei:
             eng.energy_forces(imgs)
+        assert ei.value.status == UMX_ERR_RANGE
     finally:
         eng.close()
-    monkeypatch.setenv("UMX_PRECISION", "split-bf16")
+    monkeypatch.delenv("UMX_NO_WIDEN")
+    ref = Engine(0, precision="split-bf16")
     eng = Engine(0)
     try:
+        ref.load_weights(big)
+        ref.set_system(z)
+        e0, f0 = ref.energy_forces(imgs)
+        assert np.isfinite(e0).all() and np.isfinite(f0).all()
         eng.load_weights(big)
         eng.set_system(z)
-        e, f = eng.energy_forces(imgs)
-        assert np.isfinite(e).all() and np.isfinite(f).all()
+        with pytest.warns(RuntimeWarning, match="split-bf16"):
+            e, f = eng.energy_forces(imgs)
+        assert eng.widened and np.array_equal(e, e0) and np.array_equal(f, f0)
+        e2, f2 = eng.energy_forces(imgs)                       # stays widened, no second warning path
+        assert np.array_equal(e2, e0) and np.array_equal(f2, f0)
+        bad = imgs.copy(); bad[0, 0, 0] = np.nan
+        with pytest.raises(UmxError, match="non-finite position"):
+            eng.energy_forces(bad)                              # (a NaN coordinate would otherwise just lose its edges)
     finally:
         eng.close()
+        ref.close()
 
 
 def test_no_edges_and_isolated_atoms(engine, oracle):

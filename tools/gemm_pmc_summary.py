@@ -18,8 +18,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pdb2reaction_amd.build import source_digest  # noqa: E402
 
 M = 1139068
-SHAPES = [("conv1 m0", 0, 640, 768, 3), ("conv1 m1", 1, 256, 512, 3), ("conv1 m2", 1, 128, 256, 3), ("conv2 m0", 0, 384, 384, 3),
-          ("conv2 m1", 1, 256, 256, 3), ("conv2 m2", 1, 128, 128, 3), ("radial fc3", 0, 1536, 128, 3),
+# last column: planes code -- 24 = forward fp16 form (2 activation x 3 weight planes, 4 products); 2 = reverse bf16 form (2 x 2 planes, 3 products)
+SHAPES = [("conv1 m0", 0, 640, 768, 24), ("conv1 m1", 1, 256, 512, 24), ("conv1 m2", 1, 128, 256, 24), ("conv2 m0", 0, 384, 384, 24),
+          ("conv2 m1", 1, 256, 256, 24), ("conv2 m2", 1, 128, 128, 24), ("radial fc3", 0, 1536, 128, 24),
           ("conv2^T m0", 0, 384, 384, 2), ("conv2^T m1", 1, 256, 256, 2), ("conv2^T m2", 1, 128, 128, 2),
           ("conv1^T m0", 0, 768, 640, 2), ("conv1^T m1", 1, 512, 256, 2), ("conv1^T m2", 1, 256, 128, 2), ("radial fc3^T", 0, 128, 1536, 2)]
 
@@ -39,11 +40,11 @@ p1, p2 = load(sys.argv[1]), load(sys.argv[2])
 rows = []
 for (_, a), (_, b), (name, cplx, n, k, p) in zip(p1.items(), p2.items(), SHAPES):
     alg = (8.0 if cplx else 2.0) * M * n * k
-    ex = alg * (6 if p == 3 else 3)
+    ex = alg * {3: 6, 24: 4, 2: 3}[p]
     cyc = b["GRBM_GUI_ACTIVE"] / 8.0
     wc = a["SQ_WAVE_CYCLES"]
     rows.append({
-        "gemm": name, "kernel": a["kernel"].replace("void umx::", "").split("(")[0], "complex": bool(cplx), "N": n, "K": k, "planes": p,
+        "gemm": name, "kernel": a["kernel"].replace("void umx::", "").split("(")[0], "complex": bool(cplx), "N": n, "K": k, "planes": "2x3 fp16" if p == 24 else "2x2 bf16" if p == 2 else "3x3 bf16", "products": {3: 6, 24: 4, 2: 3}[p],
         "vgpr": a["vgpr"], "lds_bytes": a["lds"], "duration_us": a["us"], "algorithmic_tflops": alg / a["us"] / 1e6, "executed_tflops": ex / a["us"] / 1e6,
         "mfma_busy_cycles": a["SQ_VALU_MFMA_BUSY_CYCLES"], "mfma_busy_expected": ex / 32768.0 * 32.0,
         "mfma_util": a["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc), "clock_ghz": cyc / b["us"] / 1e3,
@@ -52,7 +53,7 @@ for (_, a), (_, b), (name, cplx, n, k, p) in zip(p1.items(), p2.items(), SHAPES)
         "lds_idx_active_per_cu_cycle": b["SQ_LDS_IDX_ACTIVE"] / (256.0 * cyc), "lds_bank_conflict_frac": b["SQ_LDS_BANK_CONFLICT"] / max(b["SQ_LDS_IDX_ACTIVE"], 1.0),
     })
 out = {"command": "rocprofv3 --pmc <pass counters> -- build/overlap_bench pmc 1   (two passes; csrc/overlap_bench.hip)",
-       "workload": "every large split-bf16 GEMM of one c3 layer, forward (Q3, 3 planes) and reverse (PL, 2 planes), M = 1 139 068 edges (8-image chunk), random finite bf16 planes",
+       "workload": "every large split-bf16 GEMM of one c3 layer, forward (quad-row layout, fp16: 2 activation x 3 weight planes, 4 products) and reverse (PL layout, bf16 2 x 2 planes, 3 products), M = 1 139 068 edges (8-image chunk), random finite planes",
        "csrc_sha256": source_digest(), "gemms": rows}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(f"{'gemm':14s} {'us':>7s} {'exec TF/s':>9s} {'util':>5s} {'GHz':>5s} {'wait':>5s} {'w_inst':>6s} {'w_lds':>5s} {'lds/cyc':>7s} {'conf':>5s}")

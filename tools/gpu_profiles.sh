@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd $R
 BENCH="python3 bench.py --no-cpu-baseline --no-fp32-mode"
 echo "== 2. kernel trace + stats (split)" &&
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -f csv -- $BENCH --steps 2 --warmup 1 > $O/kt.log 2>&1 &&
-( echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-mode  (MI355X, round 2, default split-bf16 build, 3 iterations incl. warm-up)"; cat $O/kt/kt_kernel_stats.csv ) > $P/r02_bench_c3_kernel_stats_split.csv &&
+( echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-mode  (MI355X, round 2, default split build (fp16 forward planes), 3 iterations incl. warm-up)"; cat $O/kt/kt_kernel_stats.csv ) > $P/r02_bench_c3_kernel_stats_split.csv &&
 echo "== 3. kernel trace + stats (fp32 mode)" &&
 UMX_PRECISION=fp32 rocprofv3 --kernel-trace --stats -d $O/kt32 -o kt -f csv -- $BENCH --steps 2 --warmup 1 > $O/kt32.log 2>&1 &&
 ( echo "# UMX_PRECISION=fp32 rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-mode  (MI355X, round 2, all-fp32-MFMA mode, 3 iterations incl. warm-up)"; cat $O/kt32/kt_kernel_stats.csv ) > $P/r02_bench_c3_kernel_stats_fp32.csv &&

@@ -181,8 +181,15 @@ class UMAcore:
         c = np.asarray(coords_ang, dtype=np.float64).reshape(-1, len(self.z), 3)
         es, fs = [], []
         for k in range(c.shape[0]):                       # images one after another, each spread over all ranks
+            if not np.isfinite(c[k]).all():
+                raise ValueError(f"non-finite position in image {k}")
             e, f = self._gp(torch.as_tensor(c[k], dtype=torch.float32, device=self.device))
             es.append(float(e[0]))
+            if not np.isfinite(es[-1]):
+                # the device-pointer entries are asynchronous and cannot refuse the result themselves (include/umx.h, UMX_ERR_RANGE);
+                # every rank sees the same energy, so every rank raises here
+                raise RuntimeError(f"image {k}: non-finite energy in graph-parallel mode (an activation beyond the fp16 operand range of "
+                                   "UMX_PRECISION=split? create the calculators with UMX_PRECISION=split-bf16)")
             fs.append(f.cpu().numpy())
         return np.asarray(es, dtype=np.float64), np.stack(fs)
 

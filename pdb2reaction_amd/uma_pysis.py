@@ -131,6 +131,7 @@ class UMAcore:
         max_neigh: Optional[int] = None,
         radius: Optional[float] = None,
         r_edges: bool = False,
+        precision: Optional[str] = None,
     ):
         from .engine import Engine  # raises ImportError loudly when libumx.so is missing
 
@@ -153,7 +154,7 @@ class UMAcore:
         weights = resolve_weights(model)                    # raises FileNotFoundError before any GPU work
         self.z = synth.symbols_to_z(self.elem)
         W.check_merged_for(weights, self.z, charge, spin, task_name)   # a MoLE merge is valid for one system only
-        self.engine = Engine(_device_index(device))
+        self.engine = Engine(_device_index(device), precision=precision)     # None: UMX_PRECISION (default "split")
         self.engine.load_weights(weights)
         self.engine.set_system(self.z, charge=charge, spin=spin, task=task_name, radius=radius, max_neigh=max_neigh)
 
@@ -244,11 +245,16 @@ class uma_pysis(Calculator):
         hessian_double: bool = CALC_KW["hessian_double"],
         **kwargs,
     ):
+        # not a reference keyword: the arithmetic of the large GEMMs ("split" | "split-bf16" | "fp32"; None = UMX_PRECISION).
+        # Taken out of **kwargs so that the reference's signature stays as it is.
+        precision = kwargs.pop("precision", None)
+        if precision not in (None, "split", "split-f16", "split-bf16", "fp32"):
+            raise ValueError(f"precision must be split, split-bf16 or fp32, got {precision!r}")
         super().__init__(charge=charge, mult=spin, **kwargs)
         self._core: Optional[UMAcore] = None
         self._core_kw = dict(
             charge=charge, spin=spin, model=model, task_name=task_name, device=device, workers=workers,
-            workers_per_node=workers_per_node, max_neigh=max_neigh, radius=radius, r_edges=r_edges,
+            workers_per_node=workers_per_node, max_neigh=max_neigh, radius=radius, r_edges=r_edges, precision=precision,
         )
         self.out_hess_torch = out_hess_torch
         self.hessian_calc_mode = hessian_calc_mode

@@ -66,6 +66,11 @@ def test_calc_kw_and_ctor_mirror_reference():
     assert c._core is None                                     # lazy model load (reference :482,502-504)
     with pytest.raises(TypeError):
         U.uma_pysis(0, 1)                                       # keyword-only, like the reference
+    # the one extra key: the GEMM arithmetic of the engine (taken out of **kwargs, validated up front, used at the lazy load)
+    c = U.uma_pysis(precision="split-bf16")
+    assert c._core_kw["precision"] == "split-bf16" and U.uma_pysis()._core_kw["precision"] is None
+    with pytest.raises(ValueError, match="precision"):
+        U.uma_pysis(precision="fp64")
 
 
 def test_missing_weights_are_loud(tmp_path, monkeypatch):

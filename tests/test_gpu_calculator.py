@@ -20,9 +20,10 @@ def setup(oracle):
     return z, elem, imgs
 
 
-def test_get_forces_matches_oracle_in_atomic_units(oracle, setup):
+@pytest.mark.parametrize("precision", [None, "split-bf16", "fp32"])
+def test_get_forces_matches_oracle_in_atomic_units(oracle, setup, precision):
     z, elem, imgs = setup
-    calc = U.uma_pysis(model="synthetic", freeze_atoms=[0, 5])
+    calc = U.uma_pysis(model="synthetic", freeze_atoms=[0, 5], **({"precision": precision} if precision else {}))
     x_bohr = (imgs[0] * U.ANG2BOHR).reshape(-1)
     r = calc.get_forces(elem, x_bohr)
     p32 = (x_bohr.reshape(-1, 3) * U.BOHR2ANG).astype(np.float32)
@@ -33,6 +34,8 @@ def test_get_forces_matches_oracle_in_atomic_units(oracle, setup):
     assert np.abs(r["forces"] - (f_ref * U.F_EVAA_2_AU).reshape(-1)).max() <= 1e-3 * U.F_EVAA_2_AU
     assert np.all(r["forces"].reshape(-1, 3)[[0, 5]] == 0.0)
     assert calc.get_energy(elem, x_bohr)["energy"] == pytest.approx(r["energy"], abs=1e-9)
+    assert calc._core.engine.precision == precision and not calc._core.engine.widened
+    calc.close()
 
 
 def test_batch_equals_serial_calls(setup):

@@ -121,7 +121,7 @@ int umx_synchronize(umx_engine* eng);
 int umx_last_graph_stats(const umx_engine* eng, int64_t* n_edges_total, int32_t* max_degree);
 
 /* Per-launch device time (HIP events on the launch stream) of the two GEMM kernel families since the last reset.
- * Family 0 = split-bf16 LDS-DMA GEMM (umx_gemm_pl_kernel: SO(2) / radial-fc3 linears and their transposes),
+ * Family 0 = split-precision LDS-DMA GEMMs (umx_gemm_q_kernel / umx_gemm_pl*_kernel: SO(2) / radial-fc3 linears and their transposes),
  * family 1 = fp32-MFMA GEMM (umx_gemm_kernel: small radial / atom-wise / readout linears; everything in fp32 mode).
  * alg_flops = 2*M*N*K per product (what the model needs); mfma_flops = FLOPs the matrix cores executed
  * (x6 for the 3-plane forward split, x3 for the 2-plane reverse split, x1 for fp32).  bench.py uses this for the

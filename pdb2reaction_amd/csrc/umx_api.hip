@@ -89,7 +89,7 @@ struct umx_engine {
   float* d_dw = nullptr;         // derived weights
   unsigned short* d_bw = nullptr; // plane-interleaved (PL) bf16 copies of the large SO(2)/radial weights
   std::map<const float*, const unsigned short*> planes;   // fp32 weight ptr -> PL planes (P=3 forward weights, P=2 transposed)
-  bool pl = true;                 // UMX_PRECISION=split (default): split-bf16 PL GEMMs; fp32: fp32-MFMA everywhere
+  bool pl = true;                 // UMX_PRECISION=split / split-bf16: split-precision plane GEMMs; fp32: fp32-MFMA everywhere
   std::map<std::string, Tensor> wt;
   std::vector<float> h_w;        // host copy of the data section (needed to build derived weights)
   RadialW rdeg{};
@@ -202,8 +202,9 @@ int gemm_cplx(umx_engine* eng, const float* A, long lda, int offRe, int offIm, c
   return launch_gemm(eng, p, R ? A_MODUL : A_PLAIN, 1, E_BIAS);
 }
 
-// split-bf16 GEMM on plane-interleaved operands (umx_gemm_pl.h).  Wkey = fp32 device pointer of the weight (its PL copy is
-// looked up); a_cols = total columns of the A matrix (row pitch = a_cols * P); offsets in columns.
+// split-precision GEMM on pre-split operands.  P = 3: a FORWARD product (quad-row kernels of umx_gemm_q.h: fp16 planes by default,
+// three bf16 planes in split-bf16 mode; PL layout with UMX_Q3=0), P = 2: a reverse-pass product (bf16 planes, umx_gemm_pl.h).
+// Wkey = fp32 device pointer of the weight (its plane copy is looked up); a_cols = total columns of the A matrix; offsets in columns.
 int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_cols, int offA0, int offA1, const float* Wkey, int bHalf,
             const float* bias, float* Cp, long ldc, int offC, int offCi, long M, int N, int K, float conj) {
   if (M <= 0) return UMX_OK;
@@ -307,7 +308,7 @@ struct WS {
   float* hg[NL];
   float* msg[NL];
   float *xrot, *hid, *gmsg, *ghg, *gy1, *grad, *e128a, *e128b, *ggauss;
-  unsigned short *y1pl, *hidpl, *a2pl, *gmsgpl, *ghgpl, *gradpl;   // split-bf16 path: PL operands
+  unsigned short *y1pl, *hidpl, *a2pl, *gmsgpl, *ghgpl, *gradpl;   // split path: pre-split GEMM operands (forward: quad-row planes, reverse: PL)
 };
 
 struct Bump {
@@ -483,7 +484,7 @@ int so3_linear(umx_engine* eng, const float* A, const float* Wl, const float* bi
 
 // ---- one chunk: nn nodes (= images * natoms), edges counted on the fly --------------------------
 // The chunk's launch sequence is recorded as a PLAN of segments instead of being issued directly.  A segment is either
-// "matrix" (a group of the large split-bf16 GEMMs: MFMA-bound, one LDS-filling workgroup per CU) or "stream" (everything
+// "matrix" (a group of the large split-precision GEMMs: MFMA-bound, one LDS-filling workgroup per CU) or "stream" (everything
 // else: the HBM-bound gather / rotate / gate / reduce kernels and the small fp32 GEMMs).  With one lane the executor simply
 // issues the segments in order.  With two lanes (UMX_STREAMS=2) it issues the plans of two chunks alternately and hands a
 // TOKEN from matrix segment to matrix segment across the lanes (events), so that at any time at most one lane occupies the

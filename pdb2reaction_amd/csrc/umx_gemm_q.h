@@ -1,22 +1,28 @@
-// umx_gemm_q.h -- forward (3-plane) split-bf16 GEMM on the "quad-row" operand layout Q3, which lets a 256 x 256 tile fit the LDS.
+// umx_gemm_q.h -- forward split-precision GEMM on the "quad-row" operand layouts, which let a 256 x 256 tile fit the LDS.
 //
-//   C[M x N] (fp32) = sum_{i+j<3} A_i[M x K] . B_j[N x K]^T ,   A_i, B_j bf16 planes
+//   C[M x N] (fp32) = cscale * sum_{(i,j) in products} A_i[M x K] . B_j[N x K]^T ,   A_i, B_j 16-bit planes (q_use_product below)
 //
-// LAYOUT Q3 of a matrix X[rows][cols]: blocks of 4 rows x 16 columns x 3 planes = 384 B = three whole 128-B lines,
-//   element (r, k, plane q) -> byte ((r/4) * (cols/16) + k/16) * 384 + (r%4) * 96 + q * 32 + (k%16) * 2
-// (rows padded to a multiple of 4).  A 16-column k-tile of a 256-row operand tile is 64 contiguous-by-block pieces = 24 KB, so
-// BOTH operands of a 256 x 256 tile times two ring stages take 96 KB -- with the 32-column plane-interleaved rows of the PL layout
-// (umx_gemm_pl.h) one stage of that tile is already 98 KB and the forward GEMMs were stuck at 256 x 128.  A wider tile needs a third
-// less L2->LDS fill per FLOP, which co-limits these kernels: measured -8...10 % against the PL kernels.
-// Every DMA instruction still fetches whole lines (24 consecutive lanes cover one 384-B block).  Fragment reads: lane = row, 16 B at
-// (row/4)*384 + (row%4)*96 + q*32 + h*16.  A ds_read_b128 is served in the lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} (+32),
-// and the bank base of a row group is 32*(group & 1) dwords -- so in the plain image row groups 0/6 and 3/5 of a 32-row fragment
-// collide (SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE, profiles/r02_gemm_pmc_*).  Fix without touching the HBM layout: the two
-// 16-B halves (k 0-7 / 8-15) of every plane piece are swapped in LDS for the row groups with bit 2 set, by swapping the SOURCE chunk
-// of the DMA lane (q3_swz) and XOR-ing h in the fragment address -- conflict-free for every plane and fragment base.
+// Two operand formats (producers: umx_kernels_pl.h QFmt; weights: umx_api.hip):
+//   default : IEEE-half planes -- A = 2 planes of 16 x activation (256-B blocks), B = 3 planes of s x weight (exact; 384-B blocks),
+//             4 products on v_mfma_f32_32x32x16_f16
+//   "Q3"    : bf16 planes, 3 x 3 (384-B blocks both sides), 6 products on v_mfma_f32_32x32x16_bf16 (UMX_PRECISION=split-bf16)
+//
+// LAYOUT of a P-plane matrix X[rows][cols]: blocks of 4 rows x 16 columns x P planes = 128 P bytes = P whole 128-B lines,
+//   element (r, k, plane q) -> byte ((r/4) * (cols/16) + k/16) * 128 P + (r%4) * 32 P + q * 32 + (k%16) * 2
+// (rows padded to a multiple of 4).  A 16-column k-tile of a 256-row operand tile is 64 contiguous-by-block pieces = 8 P KB, so
+// BOTH operands of a 256 x 256 tile times two ring stages take 80 KB (fp16 form) / 96 KB (Q3) -- with the 32-column plane-interleaved
+// rows of the PL layout (umx_gemm_pl.h) one 3-plane stage of that tile is already 98 KB and the forward GEMMs were stuck at 256 x 128.
+// A wider tile needs a third less L2->LDS fill per FLOP, which co-limits these kernels: measured -8...10 %
+// against the PL kernels.  Every DMA instruction still fetches whole lines (8 P consecutive lanes cover one block).
+// Fragment reads: lane = row, 16 B (8 k-values of one plane) per ds_read_b128, which is served in the lane groups
+// {0-3,12-15,20-27} / {4-11,16-19,28-31} (+32).  In the plain P = 3 image the bank base of a row group is 32*(group & 1) dwords,
+// so row groups 0/6 and 3/5 of a 32-row fragment collide (SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE before the fix); in the
+// plain P = 2 image every row group starts on the same bank (4-way).  Fix without touching the HBM layout: the 16-B chunk index
+// (plane * 2 + k-half) of a row piece is XOR-ed with q_swz<P>(row group) in LDS -- by swapping the SOURCE chunk of the DMA lane and
+// XOR-ing the chunk in the fragment address: conflict-free for every plane and fragment base (profiles/r02_gemm_pmc_counters.json).
 //
 // Structure as umx_gemm_pl.h: LDS-DMA ring (2 stages, BK = 16), one raw s_barrier per k-tile, 8 waves (4 x 2), each wave owning
-// 64 rows x (BN/2) columns of v_mfma_f32_32x32x16_bf16 tiles; CPLX as there (rows = (re/im, edge), weight rows = (A/B half, channel)).
+// 64 rows x (BN/2) columns of 32x32x16 MFMA tiles; CPLX as there (rows = (re/im, edge), weight rows = (A/B half, channel)).
 // WIDE = 1: 256 x 256 tile (N must fill whole tiles); WIDE = 0: 256 x 128.
 #pragma once
 #include "umx_gemm_pl.h"
@@ -24,10 +30,10 @@
 namespace umx {
 
 template <int P> __device__ __forceinline__ int q_row_off(int row) { return (row >> 2) * (128 * P) + (row & 3) * (32 * P); }
-// LDS-image swizzle (P = 3): rows whose row group has bit 2 set (tile rows 16-31, 48-63, ...) hold their two 16-B k-halves swapped.
-// General form: the 16-B chunk index inside a row piece (plane-major, half = LSB) is XOR-ed with q_swz<P>(row group).  P = 3: the half
-// swap above.  P = 2 (256-B blocks, every row group starts on the same bank): a row piece is 4 chunks = 16 banks and the four row groups
-// one ds_read_b128 pass serves ({0,3,5,6} or {1,2,4,7} of a 32-row fragment) must land on four different chunks -> XOR with (g >> 1) & 3.
+// LDS-image swizzle: the 16-B chunk index inside a row piece (plane-major, k-half = LSB) is XOR-ed with q_swz<P>(row group).
+// P = 3: rows whose row group has bit 2 set (tile rows 16-31, 48-63, ...) hold their two k-halves swapped.  P = 2: a row piece is
+// 4 chunks = 16 banks and the four row groups one ds_read_b128 pass serves ({0,3,5,6} or {1,2,4,7} of a 32-row fragment) must land
+// on four different chunks -> XOR with (g >> 1) & 3.
 template <int P> __device__ __forceinline__ int q_swz(int g) { return P == 3 ? ((g >> 2) & 1) : ((g >> 1) & 3); }
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
@@ -57,9 +63,9 @@ __host__ __device__ constexpr bool q_use_product(int PA, int PB, int NPROD, int 
   return NPROD == 4 ? true : (qa + qb < 2);
 }
 
-// P = 3: the forward layout Q3 described above.  P = 2 ("Q2", 256-B blocks of 4 rows x 16 columns x 2 planes): the two-plane forms.
-// F16 = 1: the planes are IEEE half (11-bit significands: two planes carry 22 bits) and the products run on v_mfma_f32_32x32x16_f16.
-// NPROD = number of plane products, PB = planes of the B (weight) operand when it differs from P: see q_use_product.
+// P / PB = planes of the A / B operand (PB defaults to P).  F16 = 1: the planes are IEEE half (11-bit significands) and the products
+// run on v_mfma_f32_32x32x16_f16, else bf16.  NPROD = number of plane products (q_use_product).  The engine uses <.., 2, S, 1, 4, 3>
+// (default mode), <.., 3, S> (split-bf16) and <.., 2, S, 1, 3, 2> (dev: two-plane weights); the bf16 P = 2 form is gemm_bench's.
 // S = ring stages (2: request tile kt+1 while tile kt is consumed; 3: two tiles in flight -- more tolerant of HBM latency when
 // other kernels load the memory system, at 144 KB of LDS for the wide tile).
 template <int CPLX, int WIDE, int P = 3, int S = 2, int F16 = 0, int NPROD = (P == 3 ? 6 : 3), int PB = P>

@@ -1,7 +1,8 @@
-// umx_kernels_pl.h -- producer kernels of the split-bf16 path: every A operand of the large SO(2)/radial GEMMs is
-// written ONCE, already split into bf16 planes, in the plane-interleaved row layout of umx_gemm_pl.h:
-//   element (row, k, plane q) -> row * (K*P) + (k / 32) * (32*P) + q * 32 + (k % 32)
-// P = 3 for forward operands (exact 24-bit split), P = 2 for reverse-pass operands.
+// umx_kernels_pl.h -- producer kernels of the split-precision path: every A operand of the large SO(2)/radial GEMMs is
+// written ONCE, already split into 16-bit planes.  Reverse-pass operands (and the dev layout UMX_Q3=0) use the plane-interleaved
+// row layout of umx_gemm_pl.h:
+//   element (row, k, plane q) -> row * (K*P) + (k / 32) * (32*P) + q * 32 + (k % 32)        P = 2 bf16 planes (P = 3 forward, dev)
+// forward operands the quad-row layouts of umx_gemm_q.h (QFmt below: two fp16 planes by default, three bf16 planes in split-bf16 mode).
 // Fusions relative to the fp32 path: the radial modulation is applied by the gather/rotate producer (the conv-1 GEMM
 // no longer reads `rad`), and the reverse pass re-derives the rotated message inside the modulation-backward kernel
 // instead of round-tripping a 9 KB/edge buffer through HBM.

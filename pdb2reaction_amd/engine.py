@@ -21,7 +21,7 @@ _lib = None
 
 
 class ProfileStats(C.Structure):
-    """Mirror of ``umx_profile_stats`` (include/umx.h): [0] split-bf16 PL GEMM family, [1] fp32-MFMA GEMM family."""
+    """Mirror of ``umx_profile_stats`` (include/umx.h): [0] split-precision plane GEMM family, [1] fp32-MFMA GEMM family."""
 
     _fields_ = [("ms", C.c_double * 2), ("launches", C.c_int64 * 2), ("alg_flops", C.c_double * 2), ("mfma_flops", C.c_double * 2)]
 

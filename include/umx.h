@@ -124,7 +124,7 @@ int umx_last_graph_stats(const umx_engine* eng, int64_t* n_edges_total, int32_t*
  * Family 0 = split-precision LDS-DMA GEMMs (umx_gemm_q_kernel / umx_gemm_pl*_kernel: SO(2) / radial-fc3 linears and their transposes),
  * family 1 = fp32-MFMA GEMM (umx_gemm_kernel: small radial / atom-wise / readout linears; everything in fp32 mode).
  * alg_flops = 2*M*N*K per product (what the model needs); mfma_flops = FLOPs the matrix cores executed
- * (x6 for the 3-plane forward split, x3 for the 2-plane reverse split, x1 for fp32).  bench.py uses this for the
+ * (forward: x4 on fp16 planes / x6 on bf16 planes; x3 for the 2-plane reverse split; x1 for fp32).  bench.py uses this for the
  * live roofline figure.                                                                                      */
 typedef struct umx_profile_stats {
   double ms[2];

@@ -83,6 +83,42 @@ def test_precision_modes(weights, oracle, mode, monkeypatch):
         eng.close()
 
 
+@pytest.fixture(scope="module")
+def switch_case(oracle):
+    z, imgs, _ = synth.make_images(150, 2, seed=13)
+    p32 = np.asarray(imgs, dtype=np.float32)
+    ref = [oracle.energy_forces(z, p32[k].astype(np.float64)) for k in range(len(p32))]
+    return z, p32, np.array([r[0] for r in ref]), np.stack([r[1] for r in ref])
+
+
+@pytest.mark.parametrize("env", [
+    {"UMX_FUSED_RADIAL": "0"},                                   # separate radial launches; fc3 operand written by k_ln_silu_fwd_pl<2, true>
+    {"UMX_FUSED_RADIAL": "0", "UMX_PRECISION": "split-bf16"},
+    {"UMX_Q3": "0"},                                             # dev layout: bf16 PL planes + 256x128 tiles ("split" falls back to bf16 there)
+    {"UMX_Q3WIDE": "0"},
+    {"UMX_Q3S": "3"},
+    {"UMX_Q3S": "3", "UMX_PRECISION": "split-bf16"},
+    {"UMX_F16_PRODUCTS": "3"},                                   # two-plane fp16 weights
+    {"UMX_MFMA16": "0"}, {"UMX_MFMA16": "2"}, {"UMX_WIDE": "0"},
+    {"UMX_RADIAL_TR": "1"}, {"UMX_RADIAL_FAST": "2"}, {"UMX_FUSE_MODROT": "0"},
+], ids=lambda e: ",".join(f"{k[4:]}={v}" for k, v in e.items()))
+def test_documented_switches_hold_the_tolerances(weights, switch_case, env, monkeypatch):
+    """Every run-time switch of README.md selects other kernels or tilings; each combination must stay inside the north-star tolerances."""
+    from pdb2reaction_amd.engine import Engine
+
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    z, p32, e_ref, f_ref = switch_case
+    eng = Engine(0)
+    try:
+        eng.load_weights(weights)
+        eng.set_system(z)
+        e, f = eng.energy_forces(p32)
+        assert np.abs(e - e_ref).max() <= TOL_E and np.abs(f - f_ref).max() <= TOL_F
+    finally:
+        eng.close()
+
+
 def test_fp16_operand_range_is_guarded(weights, monkeypatch):
     """The default mode keeps the forward GEMM operands as fp16 planes of 16 x (activation): an activation beyond +-4094 converts to
     inf, the GEMM output to NaN and the host-buffer entry refuses the result (UMX_ERR_RANGE) instead of returning it.  The binding

@@ -245,7 +245,9 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
     if (eng->fwd_fmt == 1) {
       // two fp16 planes of 16 x (activations), three (exact) or two planes of s_w x (weights): C = (A' . B'^T) / (16 s_w)
       q.lda = (long)a_cols * 2; q.ldb = (long)K * (eng->f16_prod == 3 ? 2 : 3);
-      q.cscale = 1.0f / (QF16_SCALE * eng->plane_scale.at(Wkey));
+      const auto sc = eng->plane_scale.find(Wkey);
+      if (sc == eng->plane_scale.end()) return fail(eng, UMX_ERR_ARG, "gemm_pl: weight has no fp16 plane copy");
+      q.cscale = 1.0f / (QF16_SCALE * sc->second);
 #define UMX_QH(CP, WD)                                                                                                      \
       do {                                                                                                                  \
         if (eng->f16_prod == 3) { if (S == 3) hipLaunchKernelGGL((umx_gemm_q_kernel<CP, WD, 2, 3, 1, 3, 2>), gq, block, 0, eng->stream, q);  \
@@ -949,6 +951,9 @@ int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes) {
   const size_t data0 = (pos + 63) & ~size_t(63);
   if (nbytes < data0 + max_end) return fail(eng, UMX_ERR_WEIGHTS, "weight blob: truncated data");
   eng->h_w.assign(reinterpret_cast<const float*>(b + data0), reinterpret_cast<const float*>(b + data0) + (max_end + 3) / 4);
+  for (const auto& kv : eng->wt)            // a non-finite parameter would only show up later as a non-finite energy
+    for (size_t i = 0; i < kv.second.count; ++i)
+      if (!std::isfinite(eng->h_w[kv.second.off + i])) return fail(eng, UMX_ERR_WEIGHTS, "weight blob: non-finite value in " + kv.first);
 
   auto need = [&](const std::string& nm, std::vector<int> shape) -> const Tensor* {
     auto it = eng->wt.find(nm);
@@ -1500,8 +1505,8 @@ int umx_energy_forces(umx_engine* eng, int n_images, const float* pos, double* e
   for (int k = 0; k < n_images; ++k)
     if (!std::isfinite(energy[k]))
       return fail(eng, UMX_ERR_RANGE, "image " + std::to_string(k) + ": non-finite energy" +
-                  (eng->pl && eng->fwd_fmt == 1 ? " (an activation beyond the fp16 operand range of UMX_PRECISION=split: try split-bf16 or fp32 -- or non-finite weights)"
-                                                : " (non-finite weights, or an overflow in float32)"));
+                  (eng->pl && eng->fwd_fmt == 1 ? " (an activation beyond the fp16 operand range of UMX_PRECISION=split: try split-bf16 or fp32)"
+                                                : " (an overflow in float32)"));
   return UMX_OK;
 }
 

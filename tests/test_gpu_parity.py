@@ -156,6 +156,12 @@ def test_fp16_operand_range_is_guarded(weights, monkeypatch):
         assert eng.widened and np.array_equal(e, e0) and np.array_equal(f, f0)
         e2, f2 = eng.energy_forces(imgs)                       # stays widened, no second warning path
         assert np.array_equal(e2, e0) and np.array_equal(f2, f0)
+        nanw = dict(weights)
+        nanw[key + ".bias"] = np.full_like(np.asarray(weights[key + ".bias"]), np.nan)
+        with pytest.raises(UmxError, match="non-finite value in " + key.replace(".", r"\.") + r"\.bias"):
+            ref.load_weights(nanw)                              # refused at load, not discovered as a NaN energy later
+        ref.load_weights(big)
+        ref.set_system(z)
         bad = imgs.copy(); bad[0, 0, 0] = np.nan
         with pytest.raises(UmxError, match="non-finite position"):
             eng.energy_forces(bad)                              # (a NaN coordinate would otherwise just lose its edges)

@@ -232,8 +232,11 @@ def main():
             "metric": "path_opt_string_iterations_per_s", "value": it_s, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": (("fp16x2-split fwd (2 activation x 3 exact weight planes, 4 products: fp32-level), " if mode in ("split", "split-f16")
-                       else "bf16x3-split fwd (6 products: 24-bit), ") + "bf16x2-split reverse (3 products: 16-bit), fp32 accumulate") if split else "f32",
+            "dtype": ("f16-split" if mode in ("split", "split-f16") else "bf16-split") if split else "f32",
+            "dtype_detail": ((("forward GEMMs: 2 fp16 activation planes x 3 exact fp16 weight planes, 4 MFMA products (fp32-level); " if mode in ("split", "split-f16")
+                               else "forward GEMMs: 3 x 3 bf16 planes, 6 MFMA products (24-bit); ")
+                              + "reverse GEMMs: 2 x 2 bf16 planes, 3 products (16-bit); fp32 accumulate; everything else fp32") if split
+                             else "every GEMM on v_mfma_f32_32x32x2_f32"),
             "precision_mode": mode,
             "data": "synthetic",
             "image_atom_steps_per_s": k * n * it_s,

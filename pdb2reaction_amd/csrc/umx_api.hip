@@ -764,9 +764,13 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
   P.stream([=, &w]() -> int {
     hipStream_t s = eng->stream;
     if (ne > 0) {
-      hipLaunchKernelGGL(k_rotate_back_bwd<3>, dim3(nblk(ne, 4)), B256, 0, s, w.G0, w.rad_deg, w.frame, w.edst, w.gmsg, w.dedd, w.tau, ne,
-                         1.0f / DEG_RESCALE);
-      CHK(radial_bwd(eng, w, eng->rdeg, NL, ne, w.gmsg));
+      // split path: the gradient of the edge-degree radial output goes straight into the PL planes of the fc3^T GEMM (gmsgpl is free here)
+      const bool dpl = eng->pl && eng->planes.count(eng->rdeg.w3T) != 0;
+      if (dpl) hipLaunchKernelGGL((k_rotate_back_bwd<3, true>), dim3(nblk(ne, 4)), B256, 0, s, w.G0, w.rad_deg, w.frame, w.edst,
+                                  reinterpret_cast<float*>(w.gmsgpl), w.dedd, w.tau, ne, 1.0f / DEG_RESCALE);
+      else hipLaunchKernelGGL(k_rotate_back_bwd<3>, dim3(nblk(ne, 4)), B256, 0, s, w.G0, w.rad_deg, w.frame, w.edst, w.gmsg, w.dedd, w.tau, ne,
+                              1.0f / DEG_RESCALE);
+      CHK(radial_bwd(eng, w, eng->rdeg, NL, ne, w.gmsg, dpl ? w.gmsgpl : nullptr));
       if (eng->pl && eng->fuse_modrot) hipLaunchKernelGGL(k_add4, dim3(nblk(ne, 256)), B256, 0, s, w.tau, w.tau2, ne);
       hipLaunchKernelGGL(k_force_edge, dim3(nblk(ne, 256)), B256, 0, s, w.dedd, w.tau, w.frame, w.evec, w.gvec, ne);
     }
@@ -1160,6 +1164,12 @@ int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes) {
     want_planes(hd + loff[i].c1m2T, D(loff[i].c1m2T), 2 * 256, 128, 2); want_planes(hd + loff[i].c2m0T, D(loff[i].c2m0T), 384, 384, 2);
     want_planes(hd + loff[i].c2m1T, D(loff[i].c2m1T), 2 * 256, 256, 2); want_planes(hd + loff[i].c2m2T, D(loff[i].c2m2T), 2 * 128, 128, 2);
     want_planes(hd + roff[c1 + ".rad_func"].w3T, D(roff[c1 + ".rad_func"].w3T), RH, RAD, 2);
+  }
+  {   // the edge-degree radial MLP's fc3 (128 -> 384) and its transpose run on the split path too
+    const std::string nm = "edge_degree_embedding.rad_func.fc3.weight";
+    want_planes(hw + eng->wt[nm].off, W(nm), 3 * C, RH, 3);
+    const size_t t = roff["edge_degree_embedding.rad_func"].w3T;
+    want_planes(hd + t, D(t), RH, 3 * C, 2);
   }
   if (eng->d_bw) { HIPCHK(eng, hipFree(eng->d_bw)); eng->d_bw = nullptr; }
   HIPCHK(eng, hipMalloc(&eng->d_bw, bw.size() * sizeof(unsigned short)));

@@ -13,7 +13,7 @@ for line in open(sys.argv[1]):
         continue
     M, N, K, amode, cplx, prec, gz = map(int, p[:7])
     ms, fl = float(p[7]), float(p[8])
-    if M < 100000:
+    if M < (int(sys.argv[2]) if len(sys.argv) > 2 else 100000):
         continue
     k = (M, N, K, amode, cplx, prec, gz)
     r = rows.setdefault(k, [0, 0.0, 0.0])
@@ -22,5 +22,5 @@ tot = sum(r[1] for r in rows.values())
 print(f"{'M':>8} {'N':>5} {'K':>5} am cx P gz  calls   ms/call  alg TF/s  exec TF/s  share")
 for k, (n, ms, fl) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
     M, N, K, amode, cplx, prec, gz = k
-    mult = 6 if prec == 3 else 3 if prec == 2 else 1
-    print(f"{M:8d} {N:5d} {K:5d} {amode:2d} {cplx:2d} {prec} {gz:2d} {n:6d} {ms/n:9.3f} {fl/ms/1e9:9.1f} {mult*fl/ms/1e9:10.1f} {100*ms/tot:6.1f}%")
+    mult = {3: 6, 2: 3, 24: 4, 23: 3}.get(prec, 1)
+    print(f"{M:8d} {N:5d} {K:5d} {amode:2d} {cplx:2d} {prec:2d} {gz:2d} {n:6d} {ms/n:9.3f} {fl/ms/1e9:9.1f} {mult*fl/ms/1e9:10.1f} {100*ms/tot:6.1f}%")

@@ -106,6 +106,27 @@ def fd_hessian(batch_forces: Callable[[np.ndarray], np.ndarray], coord_ang: np.n
     return hess.view(n, 3, n, 3)
 
 
+def active_trim(hess, frozen: Sequence[int], *, partial: bool):
+    """Freeze semantics for a Hessian that was NOT built column by column (an analytical one handed over by a core that
+    exposes it; reference ``:569-592``): (n,3,n,3) eV/A^2 -> the active block (`partial`) or the full matrix with the
+    COLUMNS of frozen DOF zeroed -- the same shape of result the finite-difference route gives.  No frozen atoms: unchanged."""
+    import torch
+
+    n = hess.size(0)
+    fz = sorted(set(int(i) for i in frozen))
+    if not fz:
+        return hess
+    active, dead = dof_partition(n, fz)
+    h2 = hess.reshape(3 * n, 3 * n)
+    if partial:
+        idx = torch.as_tensor(active, device=h2.device, dtype=torch.long)
+        m = len(active) // 3
+        return h2.index_select(0, idx).index_select(1, idx).view(m, 3, m, 3)
+    h2 = h2.clone()
+    h2[:, torch.as_tensor(dead, device=h2.device, dtype=torch.long)] = 0.0
+    return h2.view(n, 3, n, 3)
+
+
 def hessian_to_au(hess, *, double: bool, as_torch: bool):
     """(n,3,n,3) eV/A^2 -> symmetrised (3n,3n) Hartree/Bohr^2 (torch on device or NumPy)."""
     import torch

@@ -341,17 +341,23 @@ class uma_pysis(Calculator):
         return {"energy": np.asarray(res["energy"], dtype=np.float64) * EV2AU}
 
     def get_hessian(self, elem, coords):
-        """Hessian per ``hessian_calc_mode``.  The engine exposes no differentiable torch model, so -- exactly like the
-        reference with ``workers > 1`` (``:736-737``) -- every mode resolves to FiniteDifference."""
+        """Hessian per ``hessian_calc_mode`` with the reference's dispatch (``:708-780``): "Analytical" only when the core
+        exposes a differentiable model and is not a parallel predictor, anything else (falsy, unknown, FiniteDifference) is
+        the central-difference route.  The HIP engine exposes no such model (``UMAcore.has_torch_model`` is False), so on
+        the engine every mode resolves to FiniteDifference -- exactly like the reference with ``workers > 1`` (``:736-737``)."""
         core = self._ensure_core(elem)
         coord_ang = _bohr_to_ang(coords)
+        force_fd = core.parallel_predict or (not core.has_torch_model)
         mode = (self.hessian_calc_mode or "FiniteDifference").strip().lower()
-        if mode in ("analytical", "analytic") and not (core.parallel_predict or not core.has_torch_model):
-            core.compute(coord_ang, forces=True, hessian=True)           # unreachable: raises the reference's RuntimeError
-        res = self._fd_hessian_ev(elem, coord_ang)
+        if (not force_fd) and mode in ("analytical", "analytic"):
+            res = core.compute(coord_ang, forces=True, hessian=True)
+            hess = H.active_trim(res["hessian"], self.freeze_atoms, partial=self.return_partial_hessian)
+        else:
+            res = self._fd_hessian_ev(elem, coord_ang)
+            hess = res["hessian"]
         f_ev = H.mask_frozen(res["forces"], self.freeze_atoms)
         return {"energy": res["energy"] * EV2AU, "forces": (np.asarray(f_ev, dtype=np.float64) * F_EVAA_2_AU).reshape(-1),
-                "hessian": H.hessian_to_au(res["hessian"], double=self.hessian_double, as_torch=self.out_hess_torch)}
+                "hessian": H.hessian_to_au(hess, double=self.hessian_double, as_torch=self.out_hess_torch)}
 
 
 def _bohr_to_ang(coords) -> np.ndarray:

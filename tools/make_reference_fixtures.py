@@ -20,6 +20,16 @@ stored.  tests/test_reference_fixtures.py then holds this repo's restatements to
   pdb2reaction/utils.py               deep_update, apply_yaml_overrides,
                                       load_yaml_dict                            -> pdb2reaction_amd.formats.*
 
+and, into tests/golden/ref_uma_pysis_methods.json (round 3: the file that IS the drop-in boundary):
+
+  pdb2reaction/uma_pysis.py           uma_pysis._au_energy, _au_forces, _au_hessian, _active_and_frozen_dof_idx,
+                                      _zero_frozen_forces_ev, _apply_analytical_active_trim, _build_fd_hessian_gpu,
+                                      get_energy, get_forces, get_hessian (:502-780), run on tests/toy_core.ToyPairCore
+                                                                                -> pdb2reaction_amd.uma_pysis.uma_pysis, hessian.*
+  pdb2reaction/bond_changes.py        compare_structures (:142-187; CR injected)-> pdb2reaction_amd.bond_changes.compare_structures
+                                                                                   (HIP kernel k_bond_changes), oracle/bond_changes_oracle
+  pdb2reaction/path_opt.py            _write_ase_trj_with_energy (:276-290)     -> pdb2reaction_amd.formats.write_trj_with_energy
+
 Unit constants the reference takes from pysisyphus.constants are passed in from scipy and recorded
 in the fixture.
 """
@@ -211,6 +221,177 @@ def main():
     OUT.parent.mkdir(parents=True, exist_ok=True)
     OUT.write_text(json.dumps(fx, indent=1) + "\n")          # insertion order matters (YAML key order of dict-valued inputs)
     print(f"wrote {OUT} ({OUT.stat().st_size} bytes): " + ", ".join(f"{k}={len(v)}" for k, v in fx.items() if isinstance(v, list)))
+    boundary_fixtures()
+
+OUT_BOUNDARY = ROOT / "tests" / "golden" / "ref_uma_pysis_methods.json"
+UMA_METHODS = ["_ensure_core", "_au_energy", "_au_forces", "_au_hessian", "_active_and_frozen_dof_idx", "_zero_frozen_forces_ev",
+               "_apply_analytical_active_trim", "_build_fd_hessian_gpu", "get_energy", "get_forces", "get_hessian"]
+
+
+def _hess_record(h) -> Dict[str, Any]:
+    import torch
+
+    if isinstance(h, torch.Tensor):
+        return {"container": "torch", "dtype": str(h.dtype).replace("torch.", ""), "shape": list(h.shape),
+                "values": h.detach().cpu().to(torch.float64).numpy().tolist()}
+    return {"container": "numpy", "dtype": str(h.dtype), "shape": list(h.shape), "values": np.asarray(h, dtype=np.float64).tolist()}
+
+
+def boundary_fixtures():
+    """uma_pysis.py:502-780 (the calculator boundary itself), bond_changes.compare_structures, the ASE .trj writer."""
+    import torch
+
+    sys.path.insert(0, str(ROOT / "tests"))
+    from toy_core import ToyPairCore, toy_geometry  # the committed toy analytic core both sides run on
+
+    EV2AU = 1.0 / AU2EV
+    F_EVAA_2_AU = EV2AU / ANG2BOHR
+    ns = grab(REF / "uma_pysis.py", UMA_METHODS, cls="uma_pysis",
+              extra={"torch": torch, "EV2AU": EV2AU, "F_EVAA_2_AU": F_EVAA_2_AU, "H_EVAA_2_AU": H_EVAA_2_AU})
+    # the reference class body without its constructor: the methods exactly as compiled from the reference file; the instance
+    # attributes are set the way uma_pysis.__init__ sets them (:482-499), `_core` is the toy core (so _ensure_core never loads UMA)
+    RefCalc = type("RefCalc", (), {m: ns[m] for m in UMA_METHODS})
+
+    def ref_calc(core, *, freeze_atoms=None, out_hess_torch=True, hessian_calc_mode="FiniteDifference",
+                 return_partial_hessian=False, hessian_double=True):
+        me = RefCalc()
+        me._core = core
+        me.out_hess_torch = out_hess_torch
+        me.hessian_calc_mode = hessian_calc_mode
+        me.freeze_atoms = sorted(set(int(i) for i in (freeze_atoms or [])))          # reference :497
+        me.return_partial_hessian = bool(return_partial_hessian)
+        me.hessian_double = bool(hessian_double)
+        return me
+
+    rng = np.random.default_rng(20261005)
+    fx: Dict[str, Any] = {"generated_by": "tools/make_reference_fixtures.py:boundary_fixtures",
+                          "reference": "t-0hmura/pdb2reaction (local checkout): pdb2reaction/uma_pysis.py:502-780, bond_changes.py:142-187, path_opt.py:276-290",
+                          "core": "tests/toy_core.ToyPairCore (float32 positions and forces, scalar IEEE arithmetic)",
+                          "constants": {"ANG2BOHR": ANG2BOHR, "BOHR2ANG": BOHR2ANG, "EV2AU": EV2AU, "F_EVAA_2_AU": F_EVAA_2_AU,
+                                        "H_EVAA_2_AU": H_EVAA_2_AU}}
+
+    # ---- helpers on their own
+    me = ref_calc(None, freeze_atoms=[4, 1, 4])
+    fx["au_energy"] = [{"e_ev": e, "e_au": me._au_energy(e)} for e in (-1234.56789, 0.0, 3.25e-7)]
+    fx["au_forces"] = []
+    for dt in (np.float32, np.float64):
+        f = (rng.normal(size=(5, 3)) * 2.0).astype(dt)
+        r = me._au_forces(f)
+        fx["au_forces"].append({"dtype": np.dtype(dt).name, "f_ev": f.astype(np.float64).tolist(), "f_au": r.tolist(),
+                                "out_dtype": str(r.dtype), "out_shape": list(r.shape)})
+    fx["dof_idx"] = []
+    for n, fz in ((6, [4, 1, 4]), (3, []), (4, [0, 1, 2, 3]), (5, [2])):
+        m2 = ref_calc(None, freeze_atoms=fz)
+        a, ad, fd = m2._active_and_frozen_dof_idx(n)
+        fx["dof_idx"].append({"n_atoms": n, "freeze_atoms": fz, "normalised": m2.freeze_atoms, "active_atoms": a, "active_dof": ad, "frozen_dof": fd})
+    fx["zero_frozen"] = []
+    for fz in ([], [3, 0]):
+        m2 = ref_calc(None, freeze_atoms=fz)
+        f = rng.normal(size=(5, 3)).astype(np.float32)
+        out = m2._zero_frozen_forces_ev(f)
+        fx["zero_frozen"].append({"freeze_atoms": fz, "f": f.astype(np.float64).tolist(), "out": out.astype(np.float64).tolist(),
+                                  "same_object": out is f, "none_passthrough": m2._zero_frozen_forces_ev(None) is None})
+    fx["au_hessian"] = []
+    for dt, dbl, as_torch in ((torch.float32, True, True), (torch.float32, False, True), (torch.float64, True, False), (torch.float32, False, False)):
+        h = torch.as_tensor(rng.normal(size=(4, 3, 4, 3)), dtype=dt)
+        m2 = ref_calc(None, hessian_double=dbl, out_hess_torch=as_torch)
+        fx["au_hessian"].append({"in_dtype": str(dt).replace("torch.", ""), "hessian_double": dbl, "out_hess_torch": as_torch,
+                                 "h": h.to(torch.float64).numpy().tolist(), "out": _hess_record(m2._au_hessian(h.clone()))})
+    fx["analytical_trim"] = []
+    for fz, part in (([], False), ([], True), ([2, 0], False), ([2, 0], True), ([1], False)):
+        h = torch.as_tensor(rng.normal(size=(4, 3, 4, 3)), dtype=torch.float32)
+        m2 = ref_calc(None, freeze_atoms=fz, return_partial_hessian=part)
+        fx["analytical_trim"].append({"freeze_atoms": fz, "return_partial_hessian": part, "h": h.to(torch.float64).numpy().tolist(),
+                                      "out": _hess_record(m2._apply_analytical_active_trim(h.clone()))})
+
+    # ---- the three API methods end to end on the toy core
+    fx["api"] = []
+    n = 6
+    elem = ["c", "H", "o", "N", "h", "S"]
+    variants = []
+    for fz in ([], [4, 1, 4]):
+        for part in (False, True):
+            for dbl in (True, False):
+                for as_torch in (True, False):
+                    variants.append(dict(freeze_atoms=fz, return_partial_hessian=part, hessian_double=dbl, out_hess_torch=as_torch,
+                                         hessian_calc_mode="FiniteDifference", workers=1, has_torch_model=False))
+    for mode in (None, "", "bogus", " finitedifference "):
+        variants.append(dict(freeze_atoms=[2], return_partial_hessian=False, hessian_double=True, out_hess_torch=False,
+                             hessian_calc_mode=mode, workers=1, has_torch_model=True))
+    for mode, workers, has_model in (("Analytical", 1, True), (" analytic ", 1, True), ("Analytical", 4, True), ("Analytical", 1, False)):
+        for fz, part in (([], False), ([3, 0], False), ([3, 0], True)):
+            variants.append(dict(freeze_atoms=fz, return_partial_hessian=part, hessian_double=True, out_hess_torch=False,
+                                 hessian_calc_mode=mode, workers=workers, has_torch_model=has_model))
+    for vi, v in enumerate(variants):
+        x_ang = toy_geometry(n, seed=vi % 3)
+        flat = (vi % 2 == 0)
+        coords_bohr = (x_ang * ANG2BOHR).reshape(-1) if flat else (x_ang * ANG2BOHR)
+        core = ToyPairCore(n, seed=7, parallel_predict=v["workers"] > 1, has_torch_model=v["has_torch_model"])
+        kw = {k: v[k] for k in ("freeze_atoms", "return_partial_hessian", "hessian_double", "out_hess_torch", "hessian_calc_mode")}
+        me = ref_calc(core, **kw)
+        r_e = me.get_energy(elem, coords_bohr.tolist())
+        r_f = me.get_forces(elem, coords_bohr)
+        calls0 = core.calls
+        r_h = me.get_hessian(elem, coords_bohr)
+        fx["api"].append({**v, "n_atoms": n, "elem": elem, "core_seed": 7, "geometry_seed": vi % 3, "coords_flat": flat,
+                          "coords_bohr": np.asarray(coords_bohr).tolist(),
+                          "get_energy": {"energy": r_e["energy"], "keys": sorted(r_e)},
+                          "get_forces": {"energy": r_f["energy"], "forces": r_f["forces"].tolist(), "dtype": str(r_f["forces"].dtype),
+                                         "shape": list(r_f["forces"].shape), "keys": sorted(r_f)},
+                          "get_hessian": {"energy": r_h["energy"], "forces": r_h["forces"].tolist(), "hessian": _hess_record(r_h["hessian"]),
+                                          "keys": sorted(r_h), "reference_core_calls": core.calls - calls0}})
+
+    # ---- compare_structures (bond_changes.py:142-187); CR = injected radii in the unit of the coordinates
+    radii = {"h": 0.6, "c": 1.45, "n": 1.35, "o": 1.25, "s": 2.0}
+    bc = grab(REF / "bond_changes.py", ["BondChangeResult", "_upper_pairs_from_mask", "_element_arrays", "_resolve_device", "compare_structures"],
+              extra={"Pair": Tuple[int, int], "torch": torch, "CR": radii, "warnings": __import__("warnings")})
+    fx["compare_structures"] = []
+    for n_at, kw in ((6, {}), (12, {"bond_factor": 1.3, "margin_fraction": 0.02, "delta_fraction": 0.1}), (40, {}), (2, {}), (1, {})):
+        atoms = [str(a) for a in rng.choice(["H", "c", "N", "o", "S"], size=n_at)]
+        g = max(2, int(np.ceil(n_at ** (1.0 / 3.0))))
+        grid = np.array([(i, j, k) for i in range(g) for j in range(g) for k in range(g)], dtype=np.float64)[:n_at] * 2.6
+        r1 = grid + rng.uniform(-0.45, 0.45, size=(n_at, 3))
+        r2 = r1 + rng.normal(scale=0.45, size=(n_at, 3))
+        g1, g2 = types.SimpleNamespace(atoms=atoms, coords3d=r1), types.SimpleNamespace(atoms=list(atoms), coords3d=r2)
+        res = bc["compare_structures"](g1, g2, device="cpu", **kw)
+        fx["compare_structures"].append({"atoms": atoms, "radii": radii, "r1": r1.tolist(), "r2": r2.tolist(), "kwargs": kw,
+                                         "formed": sorted(map(list, ((int(i), int(j)) for i, j in res.formed_covalent))),
+                                         "broken": sorted(map(list, ((int(i), int(j)) for i, j in res.broken_covalent))),
+                                         "d1": res.distances_1.tolist(), "d2": res.distances_2.tolist()})
+    try:
+        bc["compare_structures"](types.SimpleNamespace(atoms=["H", "C"], coords3d=np.zeros((2, 3))),
+                                 types.SimpleNamespace(atoms=["C", "H"], coords3d=np.zeros((2, 3))), device="cpu")
+        fx["compare_structures_mismatch"] = None
+    except AssertionError as exc:
+        fx["compare_structures_mismatch"] = {"raises": "AssertionError", "message": str(exc)}
+
+    # ---- ASE .trj writer of the DMF path (path_opt.py:276-290); `images` only need the two ASE accessors it calls
+    wr = grab(REF / "path_opt.py", ["_write_ase_trj_with_energy"])["_write_ase_trj_with_energy"]
+
+    class _Img:
+        def __init__(self, sym, pos):
+            self._s, self._p = list(sym), np.asarray(pos, dtype=np.float64)
+
+        def get_chemical_symbols(self):
+            return list(self._s)
+
+        def get_positions(self):
+            return self._p.copy()
+
+    fx["write_ase_trj"] = []
+    with tempfile.TemporaryDirectory() as td:
+        for n_at, k in ((3, 2), (5, 4), (1, 1)):
+            sym = [str(a) for a in rng.choice(["H", "C", "N", "O", "Cl"], size=n_at)]
+            imgs = [rng.normal(size=(n_at, 3)) * 4.0 for _ in range(k)]
+            imgs[0][0] = [0.0, -0.0, 1e-17]
+            en = list((rng.normal(size=k) * 100.0).tolist())
+            en[0] = -228.1234567890123456
+            p = Path(td) / "dmf.trj"
+            wr([_Img(sym, x) for x in imgs], en, p)
+            fx["write_ase_trj"].append({"symbols": sym, "images_ang": [x.tolist() for x in imgs], "energies_hartree": en, "text": p.read_text()})
+
+    OUT_BOUNDARY.write_text(json.dumps(fx, separators=(",", ":")) + "\n")
+    print(f"wrote {OUT_BOUNDARY} ({OUT_BOUNDARY.stat().st_size} bytes): " + ", ".join(f"{k}={len(v)}" for k, v in fx.items() if isinstance(v, list)))
 
 
 if __name__ == "__main__":

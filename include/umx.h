@@ -33,8 +33,11 @@ enum umx_status {
   UMX_ERR_CAPACITY = -4, /* neighbour cap exceeded / workspace cannot be sized */
   UMX_ERR_NO_DEVICE = -5,/* no usable gfx950 device                           */
   UMX_ERR_RANGE = -6     /* non-finite energy: non-finite input, or an activation beyond the fp16 operand range (+-4094) of the
-                            default precision mode -- re-run with UMX_PRECISION=split-bf16 or fp32 (host-buffer entry only; the
-                            device-pointer entry cannot look: the caller sees NaN energies/forces)                            */
+                            split-f16 forward planes -- re-run with UMX_PRECISION=split-bf16 or fp32.  The host-buffer entry returns
+                            it for the evaluation at hand.  The device-pointer entries (umx_energy_forces_dev, umx_gp_*) are
+                            asynchronous: the kernel that writes the energies sets a sticky device flag, and the status comes back
+                            from the NEXT call that synchronises with the device -- umx_synchronize, or the next evaluation on the
+                            engine (which then does not run) -- ABI v7                                                        */
 };
 
 /* Version of this ABI (bumped on any signature change). */
@@ -57,16 +60,26 @@ const char* umx_last_error(const umx_engine* eng);
  * (pdb2reaction_amd/weights.py documents the layout).
  * Replaces: pretrained_mlip.get_predict_unit(model, device), uma_pysis.py:246-250.
  * The environment variable UMX_PRECISION is read here and fixes the arithmetic of the large SO(2)/radial GEMMs:
- *   split (default, = split-f16): forward operands as two fp16 planes (activations) x three fp16 planes (weights, exact),
+ *   auto (default, ABI v7): the engine's choice for the bound system, decided (and the weight planes re-packed if need be) at
+ *                umx_set_system.  Today that is split-f16 at every size: measured against the float64 oracle both split forms carry
+ *                the same systematic energy error of <= 1e-8 eV per atom (20 000 atoms: -1.3e-4 eV split-f16, -2.0e-4 eV
+ *                split-bf16), so the wider form buys range, not accuracy.  UMX_AUTO_BF16_ATOMS=<n> makes "auto" take split-bf16
+ *                above n atoms per image.  ENERGY ERROR BOUND of every mode: max(1e-4 eV, 1e-8 eV x atoms) against float64
+ *                arithmetic on the same weights (a plain float32 evaluation in the reference's style: 1.2e-7 eV per atom).
+ *   split (= split-f16): forward operands as two fp16 planes (activations) x three fp16 planes (weights, exact),
  *                4 MFMA products; reverse pass two bf16 planes, 3 products.  fp32-level accuracy; operand range +-4094.
  *   split-bf16 : forward operands as three bf16 planes, 6 products (beyond fp32 accuracy, no range limit, ~12 % slower).
  *   fp32       : every GEMM on the fp32 MFMA.                                                                          */
 int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes);
 
-/* Precision mode for the NEXT umx_load_weights ("split", "split-f16", "split-bf16", "fp32"); NULL or "" = back to the
- * UMX_PRECISION environment variable.  The Python binding uses it to re-load an engine in split-bf16 when an evaluation
+/* Precision mode for the NEXT umx_load_weights ("auto", "split", "split-f16", "split-bf16", "fp32"); NULL or "" = back to
+ * the UMX_PRECISION environment variable.  The Python binding uses it to re-load an engine in split-bf16 when an evaluation
  * returned UMX_ERR_RANGE (ABI v6).                                                                                   */
 int umx_set_precision(umx_engine* eng, const char* mode);
+
+/* The arithmetic the engine is in NOW: "split-f16", "split-bf16" or "fp32" ("" before weights are loaded) -- what "auto"
+ * resolved to for the bound system (ABI v7).  The returned string is static.                                         */
+const char* umx_precision_mode(const umx_engine* eng);
 
 /* Bind the chemical system shared by every image: atomic numbers, total charge, spin
  * multiplicity, task ("dataset") index into {oc20, omol, omat, odac, omc}; cutoff radius in
@@ -94,7 +107,9 @@ int umx_energy_forces(umx_engine* eng, int n_images, const float* pos_ang, doubl
  * everything already enqueued on that stream (the producer of d_pos_ang) and before anything
  * enqueued on it afterwards (the consumer of d_energy_ev / d_forces_ev_ang).  The call returns
  * after enqueueing the final kernels (one small device-to-host read of per-image edge counts
- * happens inside for workspace planning, so the host does wait for the caller's earlier work).  */
+ * happens inside for workspace planning, so the host does wait for the caller's earlier work).
+ * The stream only has to live until this call returns: umx_synchronize waits on an event the engine
+ * owns, not on the handle.  A non-finite energy is reported late, see UMX_ERR_RANGE.             */
 int umx_energy_forces_dev(umx_engine* eng, int n_images, const float* d_pos_ang,
                           double* d_energy_ev, float* d_forces_ev_ang, void* hip_stream);
 
@@ -107,30 +122,35 @@ int umx_energy_forces_dev(umx_engine* eng, int n_images, const float* d_pos_ang,
  * (RCCL all-reduce on the same stream, or any other collective) and calls umx_gp_step again, until *done = 1.  Exchange points:
  * the edge-degree aggregate, one node aggregate per layer (forward), one node gradient per layer (reverse) and the forces --
  * 9 all-reduces of n_atoms*1152 floats and one of n_atoms*3.  Energies are complete on every rank (node-level work is replicated);
- * forces are complete after the last all-reduce.  Default split-precision path only.                                          */
+ * forces are complete after the last all-reduce.  Split-precision modes only (auto / split / split-bf16); `hip_stream` must stay
+ * alive until umx_gp_step has reported *done.  A rank without edges (node_lo == node_hi, or isolated targets) takes part with
+ * all-zero partial sums.                                                                                                      */
 int umx_gp_begin(umx_engine* eng, const float* d_pos_ang, int node_lo, int node_hi, double* d_energy_ev,
                  float* d_forces_ev_ang, void* hip_stream);
 int umx_gp_step(umx_engine* eng, float** d_buf, size_t* count, int* done);
 
 /* Block until all work enqueued by this engine has finished (including work it put on a
- * caller's stream through umx_energy_forces_dev).                                              */
+ * caller's stream through umx_energy_forces_dev).  Returns UMX_ERR_RANGE (and clears the flag) when a
+ * device-pointer evaluation since the last check produced a non-finite energy.                 */
 int umx_synchronize(umx_engine* eng);
 
 /* Graph statistics of the most recent evaluation: total directed edges over all images, and
  * the maximum in-degree.  (Diagnostics for roofline accounting)         */
 int umx_last_graph_stats(const umx_engine* eng, int64_t* n_edges_total, int32_t* max_degree);
 
-/* Per-launch device time (HIP events on the launch stream) of the two GEMM kernel families since the last reset.
+/* Per-launch device time (HIP events on the launch stream) of three kernel families since the last reset.
  * Family 0 = split-precision LDS-DMA GEMMs (umx_gemm_q_kernel / umx_gemm_pl*_kernel: SO(2) / radial-fc3 linears and their transposes),
- * family 1 = fp32-MFMA GEMM (umx_gemm_kernel: small radial / atom-wise / readout linears; everything in fp32 mode).
+ * family 1 = fp32-MFMA GEMM (umx_gemm_kernel: small radial / atom-wise / readout linears; everything in fp32 mode),
+ * family 2 = the fused radial-MLP kernels (k_radial_head / k_radial_tail: VALU / fp32-MFMA bound, ABI v7) -- so that the time of the
+ * HBM-bound edge kernels can be separated from them (bench.py: roofline.hbm_regime).
  * alg_flops = 2*M*N*K per product (what the model needs); mfma_flops = FLOPs the matrix cores executed
  * (forward: x4 on fp16 planes / x6 on bf16 planes; x3 for the 2-plane reverse split; x1 for fp32).  bench.py uses this for the
  * live roofline figure.                                                                                      */
 typedef struct umx_profile_stats {
-  double ms[2];
-  int64_t launches[2];
-  double alg_flops[2];
-  double mfma_flops[2];
+  double ms[3];
+  int64_t launches[3];
+  double alg_flops[3];
+  double mfma_flops[3];
 } umx_profile_stats;
 int umx_profile_enable(umx_engine* eng, int on);
 int umx_profile_read(umx_engine* eng, umx_profile_stats* out, int reset);

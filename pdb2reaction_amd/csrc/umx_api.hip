@@ -36,6 +36,7 @@ struct Tensor { size_t off = 0; std::vector<int> shape; size_t count = 0; };
 
 struct RadialW {          // one RadialMLP (forward + transposed copies)
   const float *w1g, *w1gT, *ts, *tt, *ln1w, *ln1b, *w2, *w2T, *b2, *ln2w, *ln2b, *w3, *w3T, *b3;
+  const double *tsd, *ttd;     // the element tables of fc1 in double (fused radial head)
   int out;
 };
 struct LayerW {
@@ -53,11 +54,19 @@ struct ProfRec { hipEvent_t a, b; double flops; int M, N, K, amode, cplx, prec, 
 struct umx_engine {
   int dev = 0;
   hipStream_t stream = nullptr;
-  hipStream_t last_run = nullptr;  // stream of the most recent evaluation (the caller's for the device-pointer entry)
+  hipEvent_t ev_done = nullptr;    // recorded at the end of every evaluation on the stream it ran on: umx_synchronize waits on THIS, never
+                                   // on a caller's stream handle kept from an earlier call (the caller may have destroyed that stream since)
   bool ran_on_caller = false;
+  int* d_flags = nullptr;          // [0]: sticky range flag -- an image's energy was not finite (set by k_energy, read at the next host sync)
   hipStream_t stream2 = nullptr;   // second lane: half-chunks alternate streams so HBM-bound producers overlap the other lane's GEMMs
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev_tok[2] = {nullptr, nullptr};   // matrix-pipe token of the two lanes (run_plans_alternating)
+  // side stream (round 3): the fused radial-MLP kernels are VALU-bound and depend on the edge geometry only (forward) / feed only the
+  // scalar dE/dd (reverse), so they are issued on stream2 NEXT TO an HBM-bound edge kernel of the main stream (fork / join by events)
+  bool side = false;               // UMX_SIDE=1 enables it.  Measured on c3 (A/B, one box): 401.4 -> 399.8 ms.  The overlap happens, but beside the main
+                                   // stream's edge kernel (whose small workgroups keep refilling every CU) the side kernels run 3x longer and spill into
+                                   // the next GEMM, which slows down by as much as was hidden; stream priorities change nothing on this pool.  Off by default.
+  hipEvent_t ev_sf = nullptr, ev_shead = nullptr, ev_stail = nullptr;
   int radial_tr = 2;               // UMX_RADIAL_TR: 32-row MFMA tiles per workgroup tile of the fused radial kernels (1: 3 workgroups per CU, 2: 2)
   int radial_fast = 0;             // UMX_RADIAL_FAST: transcendentals inside the fused radial kernels: 0 libm, 1 raw hardware, 2 refined hardware (umx_radial.h)
   bool fused_radial = true;        // UMX_FUSED_RADIAL=0: the radial MLP's small layers as separate GEMM / LayerNorm launches (umx_radial.h fuses them)
@@ -66,6 +75,14 @@ struct umx_engine {
   bool q3 = true;                  // UMX_Q3=0: forward operands in the 32-column PL layout + 256x128 tiles (set before umx_load_weights)
   int fwd_fmt = 1;                 // forward operand format (QFmt, umx_kernels_pl.h): 1 = two fp16 planes (UMX_PRECISION=split), 0 = three bf16 planes (split-bf16)
   std::string precision;           // umx_set_precision: overrides UMX_PRECISION when non-empty
+  bool node_ctx = false;           // set around the node-level launches (NodeCtx): only those take the float64-accumulating kernel
+  bool node_f64_on = true;         // UMX_NODE_F64=0: node-level linears (atom-wise SO(3) linears, scalar MLP, readout and their transposes) on the
+                                   // fp32 MFMA instead of the float64-accumulating kernel (k_gemm_f64acc).  Measured (round 3): the fp32-MFMA form of
+                                   // these 14 chained GEMMs shifts the energy by a one-signed -2e-8 eV per atom; the double form costs +1 % at c3
+  bool deg_split = true;           // UMX_DEG_SPLIT=0 (dev): edge-degree fc3 / fc3^T on the fp32-MFMA GEMM instead of the split path
+  bool auto_fmt = false;           // precision mode "auto": the forward plane format follows the system size (umx_set_system)
+  int auto_atoms = 0;              // UMX_AUTO_BF16_ATOMS (0 = never): above this many atoms per image "auto" takes three bf16 forward planes
+  std::vector<char> blob;          // the weight blob as handed in (re-packed when "auto" changes the forward plane format)
   int f16_prod = 4;                // plane products of the fp16 form (UMX_F16_PRODUCTS): 4 = exact three-plane weights (hh, hl, lh, h.lo2),
                                    // 3 = two-plane weights (hh, hl, lh; biases the energy by ~2.5e-8 eV/atom)
   std::map<const float*, float> plane_scale;             // fp16 form: power-of-two scale folded into the weight planes
@@ -87,6 +104,7 @@ struct umx_engine {
   bool have_weights = false;
   float* d_w = nullptr;          // raw blob data section
   float* d_dw = nullptr;         // derived weights
+  double* d_dtab = nullptr;      // derived double tables (per-element fc1 contributions of every radial MLP)
   unsigned short* d_bw = nullptr; // plane-interleaved (PL) bf16 copies of the large SO(2)/radial weights
   std::map<const float*, const unsigned short*> planes;   // fp32 weight ptr -> PL planes (P=3 forward weights, P=2 transposed)
   bool pl = true;                 // UMX_PRECISION=split / split-bf16: split-precision plane GEMMs; fp32: fp32-MFMA everywhere
@@ -104,9 +122,9 @@ struct umx_engine {
   float cutoff = 6.0f;
   int max_neigh = 300;
   int* d_z = nullptr;
-  float* d_sysemb = nullptr;
-  float* d_gmu = nullptr;        // gaussian centres mu_k = k * cutoff/63, each rounded from double
-  float gcoef = 0.f;
+  double* d_sysemb = nullptr;    // system embedding in DOUBLE (added to every atom: a float32 copy's error would be shared by all atoms)
+  double* d_gmu = nullptr;       // gaussian centres mu_k = k * cutoff/63 in double
+  double gcoef = 0.0;
   double refsum = 0.0;
   // workspace
   size_t ws_limit = 0;
@@ -143,6 +161,21 @@ namespace {
 int fail(umx_engine* e, int code, const std::string& msg) { e->err = msg; return code; }
 
 inline unsigned nblk(long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+// HIP-event bracket around one launch for umx_profile_read (prec: > 0 split-precision GEMM family, 0 fp32 GEMM, < 0 fused radial kernels)
+ProfRec* prof_open(umx_engine* eng, double flops, int prec, long M, int N, int K) {
+  if (!eng->prof_on) return nullptr;
+  if (eng->prof_used == eng->prof.size()) {
+    ProfRec r;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return nullptr;
+    r.flops = 0; eng->prof.push_back(r);
+  }
+  ProfRec* pr = &eng->prof[eng->prof_used++];
+  pr->flops = flops; pr->M = (int)M; pr->N = N; pr->K = K; pr->amode = 0; pr->cplx = 0; pr->gz = 1; pr->prec = prec;
+  (void)hipEventRecord(pr->a, eng->stream);
+  return pr;
+}
+inline void prof_close(umx_engine* eng, ProfRec* pr) { if (pr) (void)hipEventRecord(pr->b, eng->stream); }
 // grid of a grid-stride ("virtual block") kernel: all blocks normally, capped in throttled two-lane mode
 inline unsigned vgrid(const umx_engine* eng, unsigned blocks) {
   return (eng->throttle && eng->stream_cap > 0 && blocks > (unsigned)eng->stream_cap) ? (unsigned)eng->stream_cap : blocks;
@@ -168,6 +201,14 @@ int launch_gemm(umx_engine* eng, const GemmP& p, int amode, int cplx, int epi, i
     pr->M = p.M; pr->N = p.N; pr->K = p.K; pr->amode = amode; pr->cplx = cplx; pr->gz = gz; pr->prec = 0;
     HIPCHK(eng, hipEventRecord(pr->a, eng->stream));
   }
+  if (eng->node_f64_on && eng->node_ctx && !cplx && epi == E_BIAS && (amode == A_PLAIN || amode == A_SILU)) {
+    const dim3 g64((unsigned)(((p.M + 63) / 64) * ((p.N + 63) / 64)), 1, (unsigned)gz);
+    if (amode == A_SILU) hipLaunchKernelGGL(k_gemm_f64acc<A_SILU>, g64, block, 0, eng->stream, p);
+    else hipLaunchKernelGGL(k_gemm_f64acc<A_PLAIN>, g64, block, 0, eng->stream, p);
+    HIPCHK(eng, hipGetLastError());
+    if (pr) HIPCHK(eng, hipEventRecord(pr->b, eng->stream));
+    return UMX_OK;
+  }
   const int key = amode * 100 + cplx * 10 + epi;
   switch (key) {
     case A_PLAIN * 100 + 0 + E_BIAS: hipLaunchKernelGGL((umx_gemm_kernel<A_PLAIN, 0, E_BIAS>), grid, block, 0, eng->stream, p); break;
@@ -183,6 +224,8 @@ int launch_gemm(umx_engine* eng, const GemmP& p, int amode, int cplx, int epi, i
   return UMX_OK;
 }
 
+struct NodeCtx { umx_engine* e; explicit NodeCtx(umx_engine* eng) : e(eng) { e->node_ctx = true; } ~NodeCtx() { e->node_ctx = false; } };
+
 // plain C = A . B^T (+bias, +resid)
 int gemm_plain(umx_engine* eng, const float* A, long lda, int offA, const float* B, long ldb, const float* bias, float* Cp,
                long ldc, int offC, long M, int N, int K, int amode = A_PLAIN, int gz = 1, long zA = 0, long zC = 0,
@@ -191,6 +234,12 @@ int gemm_plain(umx_engine* eng, const float* A, long lda, int offA, const float*
   p.A = A; p.lda = lda; p.offA0 = offA; p.B = B; p.ldb = ldb; p.bias = bias; p.Cp = Cp; p.ldc = ldc; p.offC = offC;
   p.M = (int)M; p.N = N; p.K = K; p.zA = zA; p.zC = zC; p.resid = resid; p.ldres = ldres; p.offRes = offRes; p.zRes = zRes;
   return launch_gemm(eng, p, amode, 0, E_BIAS, gz);
+}
+
+// the same for a NODE-level linear (rows = atoms): float64 accumulation when the engine asks for it (umx_engine::node_f64_on)
+template <class... Args> int gemm_node(umx_engine* eng, Args... args) {
+  NodeCtx node(eng);
+  return gemm_plain(eng, args...);
 }
 
 // SO(2) complex linear on (edge, re/im) rows
@@ -302,7 +351,7 @@ struct WS {
   float *G0, *G1, *G2, *ggs, *n128a, *n128b;
   // edge level
   int *esrc, *edst, *ez, *out_ptr, *out_cur, *out_edge;
-  float *evec, *frame, *dedd, *tau, *tau2, *gvec;
+  float *evec, *frame, *dedd, *dedd_rad, *tau, *tau2, *gvec;
   float* h1pre[NL + 1];
   float* h2pre[NL + 1];
   float *ra, *rad_deg;
@@ -341,7 +390,7 @@ size_t carve(char* base, long nn, long ne, WS* w, int pl) {
   t.ggs = b.take<float>(nn * 2 * H); t.n128a = b.take<float>(nn * H); t.n128b = b.take<float>(nn * H);
   t.esrc = b.take<int>(ne); t.edst = b.take<int>(ne); t.ez = b.take<int>(ne); t.out_edge = b.take<int>(ne);
   t.out_ptr = b.take<int>(nn + 1); t.out_cur = b.take<int>(nn + 1);
-  t.evec = b.take<float>(ne * 4); t.frame = b.take<float>(ne * FRAME); t.dedd = b.take<float>(ne);
+  t.evec = b.take<float>(ne * 4); t.frame = b.take<float>(ne * FRAME); t.dedd = b.take<float>(ne); t.dedd_rad = b.take<float>(ne);
   t.tau = b.take<float>(ne * 4); t.tau2 = b.take<float>(ne * 4); t.gvec = b.take<float>(ne * 4);
   for (auto& x : t.h1pre) x = b.take<float>(ne * RH);
   for (auto& x : t.h2pre) x = b.take<float>(ne * RH);
@@ -390,7 +439,7 @@ int radial_fwd_head(umx_engine* eng, const WS& w, const RadialW& r, int slot, lo
     const unsigned tiles = nblk(ne, 32 * TR);
     const unsigned cap = TR == 1 ? 768u : 512u;          // persistent: three / two workgroups per CU
     const dim3 grid(vgrid(eng, tiles < cap ? tiles : cap));
-#define UMX_RH_ARGS grid, dim3(256), 0, s, w.evec, w.ez, eng->gcoef, eng->d_gmu, r.w1g, r.ts, r.tt, r.ln1w, r.ln1b, r.w2, r.b2, r.ln2w, r.ln2b, w.h1pre[slot], w.h2pre[slot]
+#define UMX_RH_ARGS grid, dim3(256), 0, s, w.evec, w.ez, eng->gcoef, eng->d_gmu, r.w1g, r.tsd, r.ttd, r.ln1w, r.ln1b, r.w2, r.b2, r.ln2w, r.ln2b, w.h1pre[slot], w.h2pre[slot]
 #define UMX_RH_LAUNCH(Q, OUT)                                                                                           \
     do {                                                                                                              \
       const int fm = eng->radial_fast;                                                                                \
@@ -404,9 +453,11 @@ int radial_fwd_head(umx_engine* eng, const WS& w, const RadialW& r, int slot, lo
         else hipLaunchKernelGGL((k_radial_head<Q, 0, 2>), UMX_RH_ARGS, (void*)(OUT), ne);                              \
       }                                                                                                               \
     } while (0)
+    ProfRec* pr = prof_open(eng, 2.0 * ne * ((double)NG * RH + (double)RH * RH), -1, ne, RH, NG + RH);
     if (planes && eng->fwd_fmt == 1) UMX_RH_LAUNCH(2, w.a2pl); else if (planes) UMX_RH_LAUNCH(1, w.a2pl); else UMX_RH_LAUNCH(0, w.ra);
 #undef UMX_RH_LAUNCH
 #undef UMX_RH_ARGS
+    prof_close(eng, pr);
     HIPCHK(eng, hipGetLastError());
     return UMX_OK;
   }
@@ -448,7 +499,8 @@ int radial_bwd_tail(umx_engine* eng, const WS& w, const RadialW& r, int slot, lo
     const unsigned tiles = nblk(ne, 32 * TR);
     const unsigned cap = TR == 1 ? 768u : 512u;
     const dim3 grid(vgrid(eng, tiles < cap ? tiles : cap));
-#define UMX_RT_ARGS grid, dim3(256), 0, s, w.e128a, w.h2pre[slot], w.h1pre[slot], w.evec, eng->gcoef, eng->d_gmu, r.ln2w, r.ln2b, r.ln1w, r.ln1b, r.w2T, r.w1gT, w.dedd, ne
+#define UMX_RT_ARGS grid, dim3(256), 0, s, w.e128a, w.h2pre[slot], w.h1pre[slot], w.evec, eng->gcoef, eng->d_gmu, r.ln2w, r.ln2b, r.ln1w, r.ln1b, r.w2T, r.w1gT, w.dedd_rad, ne
+    ProfRec* pr = prof_open(eng, 2.0 * ne * ((double)NG * RH + (double)RH * RH), -1, ne, RH, NG + RH);
     if (TR == 1) {
       if (eng->radial_fast == 2) hipLaunchKernelGGL((k_radial_tail<2, 1>), UMX_RT_ARGS);
       else if (eng->radial_fast == 1) hipLaunchKernelGGL((k_radial_tail<1, 1>), UMX_RT_ARGS);
@@ -459,6 +511,7 @@ int radial_bwd_tail(umx_engine* eng, const WS& w, const RadialW& r, int slot, lo
       else hipLaunchKernelGGL((k_radial_tail<0, 2>), UMX_RT_ARGS);
     }
 #undef UMX_RT_ARGS
+    prof_close(eng, pr);
     HIPCHK(eng, hipGetLastError());
     return UMX_OK;
   }
@@ -466,7 +519,7 @@ int radial_bwd_tail(umx_engine* eng, const WS& w, const RadialW& r, int slot, lo
   CHK(gemm_plain(eng, w.e128b, RH, 0, r.w2T, RH, nullptr, w.e128a, RH, 0, ne, RH, RH));
   hipLaunchKernelGGL(k_ln_silu_bwd, dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.e128a, w.h1pre[slot], r.ln1w, r.ln1b, w.e128b, ne);
   CHK(gemm_plain(eng, w.e128b, RH, 0, r.w1gT, RH, nullptr, w.ggauss, NG, 0, ne, NG, RH));
-  hipLaunchKernelGGL(k_radial_dd, dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.ggauss, w.evec, eng->gcoef, eng->d_gmu, w.dedd, ne);
+  hipLaunchKernelGGL(k_radial_dd, dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.ggauss, w.evec, eng->gcoef, eng->d_gmu, w.dedd_rad, ne);
   HIPCHK(eng, hipGetLastError());
   return UMX_OK;
 }
@@ -481,6 +534,7 @@ int so3_linear(umx_engine* eng, const float* A, const float* Wl, const float* bi
   GemmP p = gp_zero();
   p.A = A; p.lda = ROW; p.offA0 = 0; p.B = Wl; p.ldb = C; p.bias = bias; p.Cp = Cp; p.ldc = ROW; p.offC = 0;
   p.M = (int)nn; p.N = C; p.K = C; p.zA = C; p.zC = C; p.resid = resid; p.ldres = ROW; p.offRes = 0; p.zRes = C; p.zBl = (long)C * C;
+  NodeCtx node(eng);
   return launch_gemm(eng, p, A_PLAIN, 0, E_BIAS, S);
 }
 
@@ -511,6 +565,19 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
   const bool pl = eng->pl;
   const bool gp = eng->gp;                                       // graph-parallel: partial sums over this rank's edges + exchange points
   const long g_lo = gp ? eng->gp_lo : 0, g_hi = gp ? eng->gp_hi : nn;
+  // side-stream issue of the fused radial kernels (see umx_engine::side); the plan is the same, only WHERE two of its kernels run changes
+  const bool side = eng->side && eng->n_lanes == 1 && !eng->dbg_on && !gp && pl && ne > 0 && eng->fused_radial && eng->q3;
+  auto side_launch = [eng](hipEvent_t done, const std::function<int()>& fn) -> int {
+    hipStream_t main_s = eng->stream;
+    HIPCHK(eng, hipEventRecord(eng->ev_sf, main_s));                   // fork: after everything issued on the main stream so far
+    HIPCHK(eng, hipStreamWaitEvent(eng->stream2, eng->ev_sf, 0));
+    eng->stream = eng->stream2;
+    const int st = fn();
+    eng->stream = main_s;
+    if (st != UMX_OK) return st;
+    HIPCHK(eng, hipEventRecord(done, eng->stream2));                   // join point: the consumer waits on `done`
+    return UMX_OK;
+  };
   // every closure reads eng->stream when it RUNS (the executor points it at the lane's stream)
   // K1 graph, K4 + K5
   P.stream([=, &w]() -> int {
@@ -530,11 +597,13 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
     HIPCHK(eng, hipGetLastError());
     DBG("row_ptr", w.row_ptr, nn + 1); DBG("src", w.esrc, ne); DBG("dst", w.edst, ne); DBG("out_ptr", w.out_ptr, nn + 1); DBG("out_edge", w.out_edge, ne);
     DBG("evec", w.evec, ne * 4); DBG("frame", w.frame, ne * FRAME);
-    hipLaunchKernelGGL(k_node_init, dim3(nblk(nn * ROW, 256)), B256, 0, s, eng->d_z, N, nn, eng->emb_sphere, eng->d_sysemb, w.xs[0]);
     if (ne > 0) CHK(radial_fwd(eng, w, eng->rdeg, NL, ne, w.rad_deg));
-    // x0 = node init + sum over incoming edges; graph-parallel: the bare partial sum goes to G1 and is all-reduced first
-    hipLaunchKernelGGL(k_rotate_back_reduce<3>, dim3(nblk(nn, 4)), B256, 0, s, w.rad_deg, w.frame, w.row_ptr, gp ? (const float*)nullptr : w.xs[0],
-                       gp ? w.G1 : w.xs[0], nn, 1.0f / DEG_RESCALE);
+    // x0 = node init + sum over incoming edges (one kernel, the base added in double); graph-parallel: the bare partial sum goes to G1 and is
+    // all-reduced first, the base is added by k_node_init_add behind the exchange point
+    if (gp) hipLaunchKernelGGL(k_rotate_back_reduce<3>, dim3(nblk(nn, 4)), B256, 0, s, w.rad_deg, w.frame, w.row_ptr, (const float*)nullptr, w.G1, nn, DEG_RESCALE,
+                               (const int*)nullptr, 0, (const float*)nullptr, (const double*)nullptr);
+    else hipLaunchKernelGGL(k_rotate_back_reduce<3>, dim3(nblk(nn, 4)), B256, 0, s, w.rad_deg, w.frame, w.row_ptr, (const float*)nullptr, w.xs[0], nn, DEG_RESCALE,
+                            (const int*)eng->d_z, N, eng->emb_sphere, (const double*)eng->d_sysemb);
     HIPCHK(eng, hipGetLastError());
     if (!gp) { DBG("rad.deg", w.rad_deg, ne * 3 * C); DBG("x0", w.xs[0], nn * ROW); }
     return UMX_OK;
@@ -542,7 +611,7 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
   if (gp) {
     P.sync(w.G1, (size_t)nn * ROW);
     P.stream([=, &w]() -> int {
-      hipLaunchKernelGGL(k_add_rows, dim3(nblk(nn * ROW / 4, 256)), B256, 0, eng->stream, w.xs[0], w.xs[0], w.G1, nn * ROW / 4);
+      hipLaunchKernelGGL(k_node_init_add, dim3(nblk(nn * ROW, 256)), B256, 0, eng->stream, eng->d_z, N, nn, eng->emb_sphere, eng->d_sysemb, w.G1, w.xs[0]);
       HIPCHK(eng, hipGetLastError());
       return UMX_OK;
     });
@@ -557,11 +626,17 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       P.stream([=, &w]() -> int {
         hipStream_t s = eng->stream;
         hipLaunchKernelGGL(k_norm_fwd, dim3(nblk(nn, 4)), B256, 0, s, xin, Lp->n1w, Lp->n1b, eng->d_sysemb, w.xn[i], nn);
+        if (side && i > 0) return UMX_OK;               // head(i) was issued on the side stream next to layer i-1's gather kernel
         return radial_fwd_head(eng, w, Lp->rad, i, ne);
       });
-      P.matrix([=, &w]() -> int { return radial_fwd_fc3(eng, w, Lp->rad, ne, w.rad[i]); });
+      P.matrix([=, &w]() -> int {
+        if (side && i > 0) HIPCHK(eng, hipStreamWaitEvent(eng->stream, eng->ev_shead, 0));
+        return radial_fwd_fc3(eng, w, Lp->rad, ne, w.rad[i]);
+      });
       P.stream([=, &w]() -> int {
         hipStream_t s = eng->stream;
+        // the NEXT layer's radial head (geometry only; a2pl is free: this layer's fc3 has consumed it) beside this HBM-bound kernel
+        if (side && i + 1 < NL) CHK(side_launch(eng->ev_shead, [=, &w]() -> int { return radial_fwd_head(eng, w, eng->lw[i + 1].rad, i + 1, ne); }));
         if (eng->q3 && eng->fwd_fmt == 1) hipLaunchKernelGGL(k_gather_rotate_mod_q3<1>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne);
         else if (eng->q3) hipLaunchKernelGGL(k_gather_rotate_mod_q3<0>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne);
         else hipLaunchKernelGGL((k_gather_rotate_mod_pl<3, false>), dim3((nblk(ne, 4) + 7) / 8 * 8), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne);
@@ -616,7 +691,8 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
     }
     if (gp) {      // partial aggregate of this rank's edges -> xn2 (free until the norm below), all-reduce, xmid = xin + sum
       P.stream([=, &w]() -> int {
-        hipLaunchKernelGGL(k_rotate_back_reduce<9>, dim3(nblk(nn, 4)), B256, 0, eng->stream, w.msg[i], w.frame, w.row_ptr, (const float*)nullptr, w.xn2, nn, 1.0f);
+        hipLaunchKernelGGL(k_rotate_back_reduce<9>, dim3(nblk(nn, 4)), B256, 0, eng->stream, w.msg[i], w.frame, w.row_ptr, (const float*)nullptr, w.xn2, nn, 1.0f,
+                           (const int*)nullptr, 0, (const float*)nullptr, (const double*)nullptr);
         HIPCHK(eng, hipGetLastError());
         return UMX_OK;
       });
@@ -627,14 +703,15 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       const LayerW& L = *Lp;
       const std::string t = "." + std::to_string(i);
       if (gp) hipLaunchKernelGGL(k_add_rows, dim3(nblk(nn * ROW / 4, 256)), B256, 0, s, xmid, xin, w.xn2, nn * ROW / 4);
-      else hipLaunchKernelGGL(k_rotate_back_reduce<9>, dim3(vgrid(eng, nblk(nn, 4))), B256, 0, s, w.msg[i], w.frame, w.row_ptr, xin, xmid, nn, 1.0f);
+      else hipLaunchKernelGGL(k_rotate_back_reduce<9>, dim3(vgrid(eng, nblk(nn, 4))), B256, 0, s, w.msg[i], w.frame, w.row_ptr, xin, xmid, nn, 1.0f,
+                              (const int*)nullptr, 0, (const float*)nullptr, (const double*)nullptr);
       HIPCHK(eng, hipGetLastError());
       DBG("xn" + t, w.xn[i], nn * ROW); DBG("rad" + t, w.rad[i], ne * RAD);
       if (!eng->pl) { DBG("xrot" + t, w.xrot, ne * XROT); DBG("hid" + t, w.hid, ne * ROW); }
       DBG("hg" + t, w.hg[i], ne * HG); DBG("msg" + t, w.msg[i], ne * ROW); DBG("xmid" + t, xmid, nn * ROW);
       // K8 atom-wise
-      hipLaunchKernelGGL(k_norm_fwd, dim3(nblk(nn, 4)), B256, 0, s, xmid, L.n2w, L.n2b, (const float*)nullptr, w.xn2, nn);
-      CHK(gemm_plain(eng, w.xn2, ROW, 0, L.smlp, C, L.smlpb, w.gspre[i], 2 * H, 0, nn, 2 * H, C));
+      hipLaunchKernelGGL(k_norm_fwd, dim3(nblk(nn, 4)), B256, 0, s, xmid, L.n2w, L.n2b, (const double*)nullptr, w.xn2, nn);
+      CHK(gemm_node(eng, w.xn2, ROW, 0, L.smlp, C, L.smlpb, w.gspre[i], 2 * H, 0, nn, 2 * H, C));
       CHK(so3_linear(eng, w.xn2, L.l1w, L.l1b, w.ffh[i], nn, nullptr));
       hipLaunchKernelGGL(k_gate_node_fwd, dim3(nblk(nn * H, 256)), B256, 0, s, w.ffh[i], w.gspre[i], w.ffhg, nn);
       CHK(so3_linear(eng, w.ffhg, L.l2w, L.l2b, xout, nn, xmid));
@@ -647,25 +724,26 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
   float* xlast = w.xs[2 * NL];
   P.stream([=, &w]() -> int {
     hipStream_t s = eng->stream;
-    hipLaunchKernelGGL(k_norm_fwd, dim3(nblk(nn, 4)), B256, 0, s, xlast, eng->normw, eng->normb, (const float*)nullptr, w.xf, nn);
-    CHK(gemm_plain(eng, w.xf, ROW, 0, eng->e0, C, eng->e0b, w.pre1, H, 0, nn, H, C));
-    CHK(gemm_plain(eng, w.pre1, H, 0, eng->e2, H, eng->e2b, w.pre2, H, 0, nn, H, H, A_SILU));
+    hipLaunchKernelGGL(k_norm_fwd, dim3(nblk(nn, 4)), B256, 0, s, xlast, eng->normw, eng->normb, (const double*)nullptr, w.xf, nn);
+    CHK(gemm_node(eng, w.xf, ROW, 0, eng->e0, C, eng->e0b, w.pre1, H, 0, nn, H, C));
+    CHK(gemm_node(eng, w.pre1, H, 0, eng->e2, H, eng->e2b, w.pre2, H, 0, nn, H, H, A_SILU));
     hipLaunchKernelGGL(k_energy_node, dim3(nblk(nn, 4)), B256, 0, s, w.pre2, eng->e4, eng->e4b, w.enode, nn);
-    hipLaunchKernelGGL(k_energy, dim3((unsigned)nimg), B256, 0, s, w.enode, N, eng->rmsd, eng->refsum, d_energy);
+    hipLaunchKernelGGL(k_energy, dim3((unsigned)nimg), B256, 0, s, w.enode, N, eng->rmsd, eng->refsum, d_energy, eng->d_flags);
     HIPCHK(eng, hipGetLastError());
     DBG("e_node", w.enode, nn); DBG("pre1", w.pre1, nn * H); DBG("pre2", w.pre2, nn * H);
     if (!d_forces) return UMX_OK;
     // ---------------- K10: analytic reverse pass ----------------
     if (ne > 0) {
       HIPCHK(eng, hipMemsetAsync(w.dedd, 0, ne * sizeof(float), s));
+      HIPCHK(eng, hipMemsetAsync(w.dedd_rad, 0, ne * sizeof(float), s));
       HIPCHK(eng, hipMemsetAsync(w.tau, 0, ne * 4 * sizeof(float), s));
       HIPCHK(eng, hipMemsetAsync(w.tau2, 0, ne * 4 * sizeof(float), s));
     }
     hipLaunchKernelGGL(k_silu_bwd, dim3(nblk(nn * H, 256)), B256, 0, s, eng->e4, 0L, w.pre2, w.n128a, nn, H);
-    CHK(gemm_plain(eng, w.n128a, H, 0, eng->e2T, H, nullptr, w.n128b, H, 0, nn, H, H));
+    CHK(gemm_node(eng, w.n128a, H, 0, eng->e2T, H, nullptr, w.n128b, H, 0, nn, H, H));
     hipLaunchKernelGGL(k_silu_bwd, dim3(nblk(nn * H, 256)), B256, 0, s, w.n128b, (long)H, w.pre1, w.n128a, nn, H);
     HIPCHK(eng, hipMemsetAsync(w.G1, 0, nn * ROW * sizeof(float), s));
-    CHK(gemm_plain(eng, w.n128a, H, 0, eng->e0T, H, nullptr, w.G1, ROW, 0, nn, C, H));
+    CHK(gemm_node(eng, w.n128a, H, 0, eng->e0T, H, nullptr, w.G1, ROW, 0, nn, C, H));
     hipLaunchKernelGGL(k_norm_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.G1, xlast, eng->normw, (const float*)nullptr, w.G0, nn);
     HIPCHK(eng, hipGetLastError());
     DBG("g_xfinal", w.G0, nn * ROW);
@@ -685,7 +763,7 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       CHK(so3_linear(eng, w.G0, L.l2T, nullptr, w.G1, nn, nullptr));                         // G1 = g_ffhg
       hipLaunchKernelGGL(k_gate_node_bwd, dim3(nblk(nn * H, 256)), B256, 0, s, w.G1, w.ffh[i], w.gspre[i], w.G2, w.ggs, nn);
       CHK(so3_linear(eng, w.G2, L.l1T, nullptr, w.G1, nn, nullptr));                         // G1 = g_xn2
-      CHK(gemm_plain(eng, w.ggs, 2 * H, 0, L.smlpT, 2 * H, nullptr, w.G1, ROW, 0, nn, C, 2 * H, A_PLAIN, 1, 0, 0, w.G1, ROW, 0, 0));
+      CHK(gemm_node(eng, w.ggs, 2 * H, 0, L.smlpT, 2 * H, nullptr, w.G1, ROW, 0, nn, C, 2 * H, A_PLAIN, 1, 0, 0, w.G1, ROW, 0, 0));
       hipLaunchKernelGGL(k_norm_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.G1, xmid, L.n2w, w.G0, w.G2, nn);   // G2 = g_xmid
       HIPCHK(eng, hipGetLastError());
       DBG("g_xmid" + t, w.G2, nn * ROW);
@@ -703,6 +781,9 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       P.stream([=, &w]() -> int {
         hipStream_t s = eng->stream;
         DBG("g_hid." + std::to_string(i), w.hid, ne * ROW);
+        // the radial tail of the layer ABOVE (it feeds only dE/dd) beside this HBM-bound kernel -- not right behind its fc3^T GEMM, where
+        // it would run next to the node-level and SO(2) GEMMs and slow those down by as much as it hides (measured)
+        if (side && i + 1 < NL) CHK(side_launch(eng->ev_stail, [=, &w]() -> int { return radial_bwd_tail(eng, w, eng->lw[i + 1].rad, i + 1, ne); }));
         hipLaunchKernelGGL(k_gate_edge_bwd_pl<2>, dim3(vgrid(eng, nblk(ne * (H / 4), 256))), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne);
         HIPCHK(eng, hipGetLastError());
         return UMX_OK;
@@ -726,8 +807,13 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
         HIPCHK(eng, hipGetLastError());
         return UMX_OK;
       });
-      P.matrix([=, &w]() -> int { return radial_bwd_fc3(eng, w, Lp->rad, ne, nullptr, w.gradpl); });
-      P.stream([=, &w]() -> int { return radial_bwd_tail(eng, w, Lp->rad, i, ne); });
+      P.matrix([=, &w]() -> int {
+        if (side && i + 1 < NL) HIPCHK(eng, hipStreamWaitEvent(eng->stream, eng->ev_stail, 0));      // e128a: the previous layer's tail has read it
+        return radial_bwd_fc3(eng, w, Lp->rad, ne, nullptr, w.gradpl);
+      });
+      // the tail feeds only the scalar dE/dd (own accumulator dedd_rad).  Side mode: layers 3..1 defer it to the next layer's gate kernel
+      // (above); layer 0 has no layer below and runs it here
+      if (!(side && i > 0)) P.stream([=, &w]() -> int { return radial_bwd_tail(eng, w, Lp->rad, i, ne); });
     } else if (ne > 0) {
       P.stream([=, &w]() -> int {
         hipStream_t s = eng->stream;
@@ -749,11 +835,16 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
         return radial_bwd(eng, w, L.rad, i, ne, w.grad);
       });
     }
-    if (gp) P.sync(w.G1, (size_t)nn * ROW);           // g_xn: every rank holds the contributions of its own edges only
+    if (gp) {
+      // g_xn: every rank holds the contributions of its own edges only.  A rank WITHOUT edges (fewer atoms than ranks, or only isolated
+      // targets) has run no edge kernel: G1 still holds g_xn2 of the atom-wise backward and must not enter the sum
+      if (ne == 0) P.stream([=, &w]() -> int { HIPCHK(eng, hipMemsetAsync(w.G1, 0, (size_t)nn * ROW * sizeof(float), eng->stream)); return UMX_OK; });
+      P.sync(w.G1, (size_t)nn * ROW);
+    }
     P.stream([=, &w]() -> int {
       hipStream_t s = eng->stream;
       const std::string t = "." + std::to_string(i);
-      if (!(ne > 0 && eng->pl && eng->fuse_modrot))
+      if (!(ne > 0 && eng->pl && eng->fuse_modrot) && !(gp && ne == 0))
         hipLaunchKernelGGL(k_gather_rotate_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.gy1, w.frame, w.row_ptr, w.out_ptr, w.out_edge, w.G1, nn);   // G1 = g_xn
       hipLaunchKernelGGL(k_norm_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.G1, xin, Lp->n1w, w.G2, w.G0, nn);                      // G0 = g_xin
       HIPCHK(eng, hipGetLastError());
@@ -767,12 +858,13 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       // split path: the gradient of the edge-degree radial output goes straight into the PL planes of the fc3^T GEMM (gmsgpl is free here)
       const bool dpl = eng->pl && eng->planes.count(eng->rdeg.w3T) != 0;
       if (dpl) hipLaunchKernelGGL((k_rotate_back_bwd<3, true>), dim3(nblk(ne, 4)), B256, 0, s, w.G0, w.rad_deg, w.frame, w.edst,
-                                  reinterpret_cast<float*>(w.gmsgpl), w.dedd, w.tau, ne, 1.0f / DEG_RESCALE);
+                                  reinterpret_cast<float*>(w.gmsgpl), w.dedd, w.tau, ne, DEG_RESCALE);
       else hipLaunchKernelGGL(k_rotate_back_bwd<3>, dim3(nblk(ne, 4)), B256, 0, s, w.G0, w.rad_deg, w.frame, w.edst, w.gmsg, w.dedd, w.tau, ne,
-                              1.0f / DEG_RESCALE);
+                              DEG_RESCALE);
+      if (side) HIPCHK(eng, hipStreamWaitEvent(s, eng->ev_stail, 0));        // join: layer 1's tail, the last one issued on the side stream (e128a, dedd_rad)
       CHK(radial_bwd(eng, w, eng->rdeg, NL, ne, w.gmsg, dpl ? w.gmsgpl : nullptr));
       if (eng->pl && eng->fuse_modrot) hipLaunchKernelGGL(k_add4, dim3(nblk(ne, 256)), B256, 0, s, w.tau, w.tau2, ne);
-      hipLaunchKernelGGL(k_force_edge, dim3(nblk(ne, 256)), B256, 0, s, w.dedd, w.tau, w.frame, w.evec, w.gvec, ne);
+      hipLaunchKernelGGL(k_force_edge, dim3(nblk(ne, 256)), B256, 0, s, w.dedd, w.dedd_rad, w.tau, w.frame, w.evec, w.gvec, ne);
     }
     hipLaunchKernelGGL(k_force_node, dim3(nblk(nn, 4)), B256, 0, s, w.gvec, w.row_ptr, w.out_ptr, w.out_edge, (float)eng->rmsd, d_forces, nn);
     HIPCHK(eng, hipGetLastError());
@@ -853,7 +945,7 @@ std::vector<float> transpose(const float* src, int rows, int cols) {
 // ================================================================================================
 extern "C" {
 
-int umx_abi_version(void) { return 6; }
+int umx_abi_version(void) { return 7; }
 
 #ifndef UMX_SRC_DIGEST
 #define UMX_SRC_DIGEST "unknown"
@@ -886,13 +978,25 @@ int umx_create(umx_engine** out, int device_ordinal) {
   if (const char* ev = std::getenv("UMX_Q3S")) e->q3_stages = std::atoi(ev) == 3 ? 3 : 2;
   if (const char* ev = std::getenv("UMX_FUSE_MODROT")) e->fuse_modrot = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_STREAMS")) e->n_lanes = std::atoi(ev) >= 2 ? 2 : 1;
+  if (const char* ev = std::getenv("UMX_SIDE")) e->side = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_WS_GB")) e->ws_cap_default = (size_t)std::max(0L, std::atol(ev)) << 30;
+  if (const char* ev = std::getenv("UMX_AUTO_BF16_ATOMS")) e->auto_atoms = std::max(0, std::atoi(ev));
+  if (const char* ev = std::getenv("UMX_NODE_F64")) e->node_f64_on = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("UMX_DEG_SPLIT")) e->deg_split = std::atoi(ev) != 0;
   e->stream_cap = 512;
   if (const char* ev = std::getenv("UMX_STREAM_BLOCKS")) e->stream_cap = std::max(0, std::atoi(ev)) / 8 * 8;
-  if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess ||
+  // stream2 gets the HIGHEST priority: the side kernels (two LDS-heavy workgroups per CU) are placed first and the main stream's
+  // edge kernel fills the rest of every CU; at equal priority the edge kernel's endless small workgroups keep the side kernel out
+  // (measured: it then ran 3x longer and spilled into the next GEMM)
+  int prio_lo = 0, prio_hi = 0;
+  if (hipSetDevice(device_ordinal) != hipSuccess || hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
+      hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, std::getenv("UMX_SIDE_PRIO") ? std::atoi(std::getenv("UMX_SIDE_PRIO")) : prio_hi) != hipSuccess ||
       hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&e->ev_tok[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_tok[1], hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&e->ev_tok[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_tok[1], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_sf, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_shead, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_stail, hipEventDisableTiming) != hipSuccess || hipMalloc(&e->d_flags, 4 * sizeof(int)) != hipSuccess ||
+      hipMemset(e->d_flags, 0, 4 * sizeof(int)) != hipSuccess) {
     g_create_err = "umx_create: hipSetDevice/hipStreamCreate failed";
     delete e;
     return UMX_ERR_HIP;
@@ -909,11 +1013,13 @@ int umx_destroy(umx_engine* eng) {
   (void)hipSetDevice(eng->dev);
   (void)hipStreamSynchronize(eng->stream);
   for (auto& r : eng->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-  void* ptrs[] = {eng->d_w, eng->d_dw, eng->d_bw, eng->d_gmu, eng->d_z, eng->d_sysemb, eng->arena, eng->d_deg_all, eng->d_cand_all, eng->d_img_edges, eng->d_io_pos, eng->d_io_e, eng->d_io_f};
+  void* ptrs[] = {eng->d_w, eng->d_dw, eng->d_bw, eng->d_gmu, eng->d_z, eng->d_sysemb, eng->arena, eng->d_deg_all, eng->d_cand_all, eng->d_img_edges, eng->d_io_pos, eng->d_io_e, eng->d_io_f, eng->d_flags, eng->d_dtab};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   (void)hipStreamSynchronize(eng->stream2);
   (void)hipEventDestroy(eng->ev_fork); (void)hipEventDestroy(eng->ev_join);
   (void)hipEventDestroy(eng->ev_tok[0]); (void)hipEventDestroy(eng->ev_tok[1]);
+  if (eng->ev_done) (void)hipEventDestroy(eng->ev_done);
+  for (hipEvent_t ev : {eng->ev_sf, eng->ev_shead, eng->ev_stail}) if (ev) (void)hipEventDestroy(ev);
   (void)hipStreamDestroy(eng->stream2);
   (void)hipStreamDestroy(eng->stream);
   delete eng;
@@ -926,8 +1032,9 @@ int umx_set_workspace_limit(umx_engine* eng, size_t bytes) {
   return UMX_OK;
 }
 
-int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes) {
-  if (!eng || !blob) return UMX_ERR_ARG;
+// force_fmt: -1 = the forward plane format of the precision mode; 0 / 1 = re-pack for three bf16 / two fp16 forward planes
+// (umx_set_system in "auto" mode, when the system size asks for the other format than the one loaded)
+static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes, int force_fmt) {
   HIPCHK(eng, hipSetDevice(eng->dev));
   const char* b = static_cast<const char*>(blob);
   if (nbytes < 16 || std::memcmp(b, "UMXW0001", 8) != 0) return fail(eng, UMX_ERR_WEIGHTS, "weight blob: bad magic");
@@ -973,7 +1080,8 @@ int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes) {
     return o;
   };
   const float* hw = eng->h_w.data();
-  struct RadOff { size_t w1g, w1gT, ts, tt, w2T, w3T; };
+  struct RadOff { size_t w1g, w1gT, ts, tt, w2T, w3T, tsd, ttd; };
+  std::vector<double> dtab;
   std::map<std::string, RadOff> roff;
   const Tensor* tsrc = need("source_embedding.weight", {NZ, 128});
   const Tensor* ttgt = need("target_embedding.weight", {NZ, 128});
@@ -988,6 +1096,9 @@ int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes) {
     if (!w1 || !b1 || !w2 || !w3 || !need(pre + ".fc3.bias", {out})) return UMX_ERR_WEIGHTS;
     const float* W1 = hw + w1->off;
     std::vector<float> w1g((size_t)RH * NG), ts((size_t)NZ * RH), tt((size_t)NZ * RH);
+    RadOff o;
+    o.tsd = dtab.size(); dtab.resize(dtab.size() + (size_t)NZ * RH);
+    o.ttd = dtab.size(); dtab.resize(dtab.size() + (size_t)NZ * RH);
     for (int h = 0; h < RH; ++h)
       for (int k = 0; k < NG; ++k) w1g[(size_t)h * NG + k] = W1[(size_t)h * (NG + 256) + k];
     for (int z = 0; z < NZ; ++z)
@@ -999,8 +1110,9 @@ int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes) {
         }
         ts[(size_t)z * RH + h] = (float)a;
         tt[(size_t)z * RH + h] = (float)c;
+        dtab[o.tsd + (size_t)z * RH + h] = a;
+        dtab[o.ttd + (size_t)z * RH + h] = c;
       }
-    RadOff o;
     o.w1g = push(w1g); o.w1gT = push(transpose(w1g.data(), RH, NG)); o.ts = push(ts); o.tt = push(tt);
     o.w2T = push(transpose(hw + w2->off, RH, RH)); o.w3T = push(transpose(hw + w3->off, out, RH));
     roff[pre] = o;
@@ -1066,6 +1178,9 @@ int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes) {
   HIPCHK(eng, hipMemcpy(eng->d_w, eng->h_w.data(), eng->h_w.size() * sizeof(float), hipMemcpyHostToDevice));
   HIPCHK(eng, hipMalloc(&eng->d_dw, dw.size() * sizeof(float)));
   HIPCHK(eng, hipMemcpy(eng->d_dw, dw.data(), dw.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (eng->d_dtab) { HIPCHK(eng, hipFree(eng->d_dtab)); eng->d_dtab = nullptr; }
+  HIPCHK(eng, hipMalloc(&eng->d_dtab, dtab.size() * sizeof(double)));
+  HIPCHK(eng, hipMemcpy(eng->d_dtab, dtab.data(), dtab.size() * sizeof(double), hipMemcpyHostToDevice));
   auto W = [&](const std::string& nm) -> const float* { return eng->d_w + eng->wt[nm].off; };
   auto D = [&](size_t o) -> const float* { return eng->d_dw + o; };
   // ---- plane-interleaved bf16 copies (umx_gemm_pl.h "PL" layout) of the large weights: P=3 for the forward
@@ -1076,12 +1191,15 @@ int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes) {
   // precision mode (read here: the weight planes below are packed in the forward operand format it selects)
   {
     const char* pv = std::getenv("UMX_PRECISION");
-    const std::string mode = !eng->precision.empty() ? eng->precision : (pv ? pv : "split");
+    const std::string mode = !eng->precision.empty() ? eng->precision : (pv && *pv ? pv : "auto");
+    eng->auto_fmt = false;
     if (mode == "fp32") eng->pl = false;
+    else if (mode == "auto") { eng->pl = true; eng->fwd_fmt = eng->q3 ? 1 : 0; eng->auto_fmt = eng->q3; }   // fp16 planes until a bound system says otherwise
     else if (mode == "split" || mode == "split-f16") { eng->pl = true; eng->fwd_fmt = eng->q3 ? 1 : 0; }   // (the dev layout UMX_Q3=0 has bf16 planes only)
     else if (mode == "split-bf16") { eng->pl = true; eng->fwd_fmt = 0; }
-    else return fail(eng, UMX_ERR_ARG, "UMX_PRECISION must be split (= split-f16), split-bf16 or fp32");
+    else return fail(eng, UMX_ERR_ARG, "UMX_PRECISION must be auto, split (= split-f16), split-bf16 or fp32");
     if (mode == "split-f16" && !eng->q3) return fail(eng, UMX_ERR_ARG, "UMX_PRECISION=split-f16 needs the quad-row operand layout (UMX_Q3=1)");
+    if (force_fmt >= 0 && eng->pl) eng->fwd_fmt = force_fmt;
     // a precision change alters the workspace carve-up: force a re-carve on the next call
     eng->cap_nodes = 0; eng->cap_edges = 0;
   }
@@ -1165,7 +1283,7 @@ int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes) {
     want_planes(hd + loff[i].c2m1T, D(loff[i].c2m1T), 2 * 256, 256, 2); want_planes(hd + loff[i].c2m2T, D(loff[i].c2m2T), 2 * 128, 128, 2);
     want_planes(hd + roff[c1 + ".rad_func"].w3T, D(roff[c1 + ".rad_func"].w3T), RH, RAD, 2);
   }
-  {   // the edge-degree radial MLP's fc3 (128 -> 384) and its transpose run on the split path too
+  if (eng->deg_split) {   // the edge-degree radial MLP's fc3 (128 -> 384) and its transpose run on the split path too
     const std::string nm = "edge_degree_embedding.rad_func.fc3.weight";
     want_planes(hw + eng->wt[nm].off, W(nm), 3 * C, RH, 3);
     const size_t t = roff["edge_degree_embedding.rad_func"].w3T;
@@ -1179,6 +1297,7 @@ int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes) {
   auto fill_rad = [&](RadialW& r, const std::string& pre, int out) {
     const RadOff& o = roff[pre];
     r.w1g = D(o.w1g); r.w1gT = D(o.w1gT); r.ts = D(o.ts); r.tt = D(o.tt); r.w2T = D(o.w2T); r.w3T = D(o.w3T);
+    r.tsd = eng->d_dtab + o.tsd; r.ttd = eng->d_dtab + o.ttd;
     r.ln1w = W(pre + ".ln1.weight"); r.ln1b = W(pre + ".ln1.bias"); r.w2 = W(pre + ".fc2.weight"); r.b2 = W(pre + ".fc2.bias");
     r.ln2w = W(pre + ".ln2.weight"); r.ln2b = W(pre + ".ln2.bias"); r.w3 = W(pre + ".fc3.weight"); r.b3 = W(pre + ".fc3.bias");
     r.out = out;
@@ -1214,6 +1333,20 @@ int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes) {
   return UMX_OK;
 }
 
+int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes) {
+  if (!eng || !blob) return UMX_ERR_ARG;
+  const int st = load_weights_impl(eng, blob, nbytes, -1);
+  if (st != UMX_OK) return st;
+  if (eng->auto_fmt) eng->blob.assign(static_cast<const char*>(blob), static_cast<const char*>(blob) + nbytes);   // kept for a re-pack at umx_set_system
+  else { eng->blob.clear(); eng->blob.shrink_to_fit(); }
+  return UMX_OK;
+}
+
+const char* umx_precision_mode(const umx_engine* eng) {
+  if (!eng || !eng->have_weights) return "";
+  return !eng->pl ? "fp32" : (eng->q3 && eng->fwd_fmt == 1) ? "split-f16" : "split-bf16";
+}
+
 int umx_set_system(umx_engine* eng, int n_atoms, const int32_t* z, int charge, int spin, int task_index, float radius, int max_neigh) {
   if (!eng) return UMX_ERR_ARG;
   if (!eng->have_weights) return fail(eng, UMX_ERR_ARG, "umx_set_system: load weights first");
@@ -1228,10 +1361,21 @@ int umx_set_system(umx_engine* eng, int n_atoms, const int32_t* z, int charge, i
     rs += eng->elem_refs[z[i]];
   }
   HIPCHK(eng, hipStreamSynchronize(eng->stream));
+  if (eng->auto_fmt && !eng->blob.empty()) {
+    // "auto": the engine's choice of the forward plane format for the bound system.  Round 3 measured (after the shared-constant
+    // errors were removed, DESIGN.md section 5 "Energy error vs N") that the fp16-plane form is no less accurate than the bf16 form at
+    // any size (c5: -6.4e-9 against -9.8e-9 eV per atom), so by default auto = split-f16 everywhere; UMX_AUTO_BF16_ATOMS=<n> makes it
+    // take three bf16 planes above n atoms per image (wider operand range at ~12 % of the time); the weight planes are re-packed here.
+    const int want = (eng->auto_atoms > 0 && n_atoms > eng->auto_atoms) ? 0 : 1;
+    if (want != eng->fwd_fmt) {
+      const std::vector<char> keep = eng->blob;
+      CHK(load_weights_impl(eng, keep.data(), keep.size(), want));       // (element references, hence `rs`, are unchanged by a re-pack)
+    }
+  }
   if (eng->d_z) { HIPCHK(eng, hipFree(eng->d_z)); eng->d_z = nullptr; }
   HIPCHK(eng, hipMalloc(&eng->d_z, n_atoms * sizeof(int)));
   HIPCHK(eng, hipMemcpy(eng->d_z, z, n_atoms * sizeof(int), hipMemcpyHostToDevice));
-  if (!eng->d_sysemb) HIPCHK(eng, hipMalloc(&eng->d_sysemb, C * sizeof(float)));
+  if (!eng->d_sysemb) HIPCHK(eng, hipMalloc(&eng->d_sysemb, C * sizeof(double)));
   {
     // system embedding silu(mix_csd [chg | spin | dataset]) in double on the host (setup, once per system): it is
     // added to EVERY atom in every layer, so any error in it is a same-sign energy bias that grows with N.
@@ -1242,13 +1386,13 @@ int umx_set_system(umx_engine* eng, int n_atoms, const int32_t* z, int charge, i
     const float* dst = HW("dataset_embedding.weight") + (size_t)task_index * C;
     const float* mw = HW("mix_csd.weight");
     const float* mb = HW("mix_csd.bias");
-    float se[C];
+    double se[C];
     for (int o = 0; o < C; ++o) {
       double acc = mb[o];
       for (int k = 0; k < C; ++k)
         acc += (double)mw[(size_t)o * 3 * C + k] * chg[k] + (double)mw[(size_t)o * 3 * C + C + k] * spn[k] +
                (double)mw[(size_t)o * 3 * C + 2 * C + k] * dst[k];
-      se[o] = (float)(acc / (1.0 + std::exp(-acc)));
+      se[o] = acc / (1.0 + std::exp(-acc));
     }
     HIPCHK(eng, hipMemcpy(eng->d_sysemb, se, sizeof(se), hipMemcpyHostToDevice));
   }
@@ -1257,10 +1401,10 @@ int umx_set_system(umx_engine* eng, int n_atoms, const int32_t* z, int charge, i
   eng->cutoff = radius > 0.f ? radius : 6.0f;
   {
     const double delta = (double)eng->cutoff / (NG - 1);
-    float mu[NG];
-    for (int k = 0; k < NG; ++k) mu[k] = (float)(k * delta);
-    eng->gcoef = (float)(-0.5 / ((2.0 * delta) * (2.0 * delta)));
-    if (!eng->d_gmu) HIPCHK(eng, hipMalloc(&eng->d_gmu, NG * sizeof(float)));
+    double mu[NG];
+    for (int k = 0; k < NG; ++k) mu[k] = k * delta;
+    eng->gcoef = -0.5 / ((2.0 * delta) * (2.0 * delta));
+    if (!eng->d_gmu) HIPCHK(eng, hipMalloc(&eng->d_gmu, NG * sizeof(double)));
     HIPCHK(eng, hipMemcpy(eng->d_gmu, mu, sizeof(mu), hipMemcpyHostToDevice));
   }
   eng->max_neigh = max_neigh > 0 ? max_neigh : 300;
@@ -1272,7 +1416,16 @@ int umx_synchronize(umx_engine* eng) {
   if (!eng) return UMX_ERR_ARG;
   HIPCHK(eng, hipSetDevice(eng->dev));
   HIPCHK(eng, hipStreamSynchronize(eng->stream));
-  if (eng->ran_on_caller) HIPCHK(eng, hipStreamSynchronize(eng->last_run));   // stream 0 included
+  if (eng->ran_on_caller) HIPCHK(eng, hipEventSynchronize(eng->ev_done));     // the engine's own event, not the caller's stream handle
+  // the device-pointer entries cannot look at their results: a non-finite energy left the sticky flag behind
+  int flag = 0;
+  HIPCHK(eng, hipMemcpy(&flag, eng->d_flags, sizeof(int), hipMemcpyDeviceToHost));
+  if (flag) {
+    HIPCHK(eng, hipMemset(eng->d_flags, 0, sizeof(int)));
+    return fail(eng, UMX_ERR_RANGE, std::string("a device-pointer evaluation produced a non-finite energy") +
+                (eng->pl && eng->fwd_fmt == 1 ? " (an activation beyond the fp16 operand range of the split-f16 forward planes: re-load with UMX_PRECISION=split-bf16 or fp32)"
+                                              : " (non-finite input or an overflow in float32)"));
+  }
   return UMX_OK;
 }
 
@@ -1281,7 +1434,7 @@ int umx_synchronize(umx_engine* eng) {
 static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_images, const float* d_pos, double* d_energy, float* d_forces) {
   hipStream_t own = eng->stream;
   eng->stream = run_stream;
-  eng->last_run = run_stream; eng->ran_on_caller = (run_stream != own);
+  eng->ran_on_caller = (run_stream != own);
   struct Restore { umx_engine* e; hipStream_t s; ~Restore() { e->stream = s; } } restore{eng, own};
   hipStream_t s = eng->stream;
   const int N = eng->natoms;
@@ -1309,8 +1462,18 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
   hipLaunchKernelGGL(k_image_edges, dim3((unsigned)K), dim3(256), 0, s, eng->d_deg_all, N, eng->d_img_edges, eng->d_img_edges + K);
   HIPCHK(eng, hipGetLastError());
   std::vector<int> img_edges(K + 1);
+  int range_flag = 0;
   HIPCHK(eng, hipMemcpyAsync(img_edges.data(), eng->d_img_edges, (K + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(eng, hipMemcpyAsync(&range_flag, eng->d_flags, sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(eng, hipStreamSynchronize(s));
+  if (range_flag) {
+    // set by an EARLIER evaluation through a device-pointer entry (this one has not computed an energy yet; on this stream that
+    // evaluation is complete): its caller got NaN energies / forces and, most likely, derived these positions from them
+    HIPCHK(eng, hipMemsetAsync(eng->d_flags, 0, sizeof(int), s));
+    return fail(eng, UMX_ERR_RANGE, std::string("the previous device-pointer evaluation produced a non-finite energy") +
+                (eng->pl && eng->fwd_fmt == 1 ? " (an activation beyond the fp16 operand range of the split-f16 forward planes: re-load with UMX_PRECISION=split-bf16 or fp32)"
+                                              : " (non-finite input or an overflow in float32)"));
+  }
   eng->last_maxdeg = img_edges[K];
   eng->last_edges = 0;
   for (long k = 0; k < K; ++k) eng->last_edges += img_edges[k];
@@ -1344,8 +1507,10 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
         e = e2; ++k1;
       }
       if (carve(nullptr, (k1 - k0) * N, e, nullptr, ws_mode(eng)) > budget)
-        return fail(eng, UMX_ERR_CAPACITY, "one image needs " + std::to_string(carve(nullptr, N, e, nullptr, ws_mode(eng)) >> 20) + " MiB of workspace, budget is " +
-                                               std::to_string(budget >> 20) + " MiB");
+        return fail(eng, UMX_ERR_CAPACITY, "one image (" + std::to_string(N) + " atoms, " + std::to_string(e) + " directed edges) needs " +
+                                               std::to_string(carve(nullptr, N, e, nullptr, ws_mode(eng)) >> 20) + " MiB of workspace, budget is " +
+                                               std::to_string(budget >> 20) + " MiB: a structure of this size has to be evaluated in the graph-parallel mode, its edges "
+                                               "partitioned over several GPUs (umx_gp_begin / umx_gp_step; uma_pysis(workers=<ranks>) under torch.distributed, one rank per GPU)");
       chunks.push_back({k0, k1});
       need_nodes = std::max(need_nodes, (k1 - k0) * N);
       need_edges = std::max(need_edges, e);
@@ -1426,6 +1591,7 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
     HIPCHK(eng, hipStreamWaitEvent(s, eng->ev_join, 0));
   }
   if (st != UMX_OK) return st;
+  HIPCHK(eng, hipEventRecord(eng->ev_done, s));
   return UMX_OK;
 }
 
@@ -1477,7 +1643,12 @@ int umx_gp_step(umx_engine* eng, float** d_buf, size_t* count, int* done) {
     if (st != UMX_OK) break;
   }
   eng->stream = own;
-  if (st == UMX_OK) *done = 1;
+  if (st == UMX_OK) {
+    *done = 1;
+    eng->ran_on_caller = true;
+    hipError_t e = hipEventRecord(eng->ev_done, eng->gp_stream);
+    if (e != hipSuccess) st = fail(eng, UMX_ERR_HIP, std::string("umx_gp_step: ") + hipGetErrorName(e));
+  }
   gp_clear(eng);
   return st;
 }
@@ -1513,18 +1684,20 @@ int umx_energy_forces(umx_engine* eng, int n_images, const float* pos, double* e
   if (forces) HIPCHK(eng, hipMemcpyAsync(forces, eng->d_io_f, nt * 3 * sizeof(float), hipMemcpyDeviceToHost, eng->stream));
   HIPCHK(eng, hipStreamSynchronize(eng->stream));
   for (int k = 0; k < n_images; ++k)
-    if (!std::isfinite(energy[k]))
+    if (!std::isfinite(energy[k])) {
+      (void)hipMemset(eng->d_flags, 0, sizeof(int));         // reported right here: do not fail the NEXT call for it as well
       return fail(eng, UMX_ERR_RANGE, "image " + std::to_string(k) + ": non-finite energy" +
                   (eng->pl && eng->fwd_fmt == 1 ? " (an activation beyond the fp16 operand range of UMX_PRECISION=split: try split-bf16 or fp32)"
                                                 : " (an overflow in float32)"));
+    }
   return UMX_OK;
 }
 
 int umx_set_precision(umx_engine* eng, const char* mode) {
   if (!eng) return UMX_ERR_ARG;
   const std::string m = mode ? mode : "";
-  if (!m.empty() && m != "split" && m != "split-f16" && m != "split-bf16" && m != "fp32")
-    return fail(eng, UMX_ERR_ARG, "umx_set_precision: mode must be split, split-f16, split-bf16 or fp32");
+  if (!m.empty() && m != "auto" && m != "split" && m != "split-f16" && m != "split-bf16" && m != "fp32")
+    return fail(eng, UMX_ERR_ARG, "umx_set_precision: mode must be auto, split, split-f16, split-bf16 or fp32");
   eng->precision = m;
   return UMX_OK;
 }
@@ -1557,7 +1730,7 @@ int umx_profile_read(umx_engine* eng, umx_profile_stats* out, int reset) {
     ms += t; fl += eng->prof[i].flops;
     const ProfRec& r = eng->prof[i];
     if (out) {
-      const int fam = r.prec > 0 ? 0 : 1;
+      const int fam = r.prec > 0 ? 0 : (r.prec < 0 ? 2 : 1);
       out->ms[fam] += t; out->launches[fam] += 1; out->alg_flops[fam] += r.flops;
       out->mfma_flops[fam] += r.flops * (r.prec == 3 ? 6.0 : r.prec == 2 ? 3.0 : r.prec == 24 ? 4.0 : r.prec == 23 ? 3.0 : 1.0);
     }

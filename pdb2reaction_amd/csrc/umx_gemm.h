@@ -32,7 +32,7 @@ struct GemmP {
   // A operand: row r at A + r*lda + offA{0,1} (+ blockIdx.z * zA); offA1 = imaginary rows (CPLX)
   const float* A; long lda; int offA0, offA1;
   const float* R; long ldr; int offR;            // A_MODUL: A .* R
-  const float* evec; float gcoef; const float* gmu;   // A_GAUSS: exp(gcoef (d - mu_k)^2), d = evec[4r+3], mu = 64-entry table
+  const float* evec; double gcoef; const double* gmu;  // A_GAUSS: exp(gcoef (d - mu_k)^2), d = evec[4r+3], mu = 64-entry table (double: umx_radial.h)
   // B operand: weights [rows][ldb]; CPLX row of kind ab: ab*bHalf + n
   const float* B; long ldb; int bHalf;
   const unsigned short* Bpl; long bplane;        // split-bf16 kernels: plane q of the weights at Bpl + q*bplane (same [row][ldb] layout)
@@ -164,13 +164,12 @@ __global__ __launch_bounds__(256, 2) void umx_gemm_kernel(const GemmP p) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (grow < p.M) {
         if (AMODE == A_GAUSS) {
-          const float d = p.evec[grow * 4 + 3];
-          const float4 mu = *reinterpret_cast<const float4*>(p.gmu + k0);
-          float t;
-          t = d - mu.x; v.x = exp_f(p.gcoef * t * t);
-          t = d - mu.y; v.y = exp_f(p.gcoef * t * t);
-          t = d - mu.z; v.z = exp_f(p.gcoef * t * t);
-          t = d - mu.w; v.w = exp_f(p.gcoef * t * t);
+          const double d = (double)p.evec[grow * 4 + 3];
+          double t;
+          t = d - p.gmu[k0 + 0]; v.x = exp_f((float)(p.gcoef * t * t));
+          t = d - p.gmu[k0 + 1]; v.y = exp_f((float)(p.gcoef * t * t));
+          t = d - p.gmu[k0 + 2]; v.z = exp_f((float)(p.gcoef * t * t));
+          t = d - p.gmu[k0 + 3]; v.w = exp_f((float)(p.gcoef * t * t));
         } else {
           v = *reinterpret_cast<const float4*>(p.A + grow * p.lda + offA + zoffA + k0);
           if (AMODE == A_MODUL) {
@@ -241,6 +240,68 @@ __global__ __launch_bounds__(256, 2) void umx_gemm_kernel(const GemmP p) {
   }
 
   gemm_epilogue<CPLX, EPI>(p, acc, mt, nt, wm, wn, l31, h);
+}
+
+
+// ---- float64-accumulate variant for the NODE-level linears (atom-wise SO(3) linears, scalar MLP, readout and their transposes) ----
+// Same operands and epilogue as umx_gemm_kernel<A_PLAIN|A_SILU, 0, E_BIAS>, but every product and the whole k-sum are carried in
+// double and rounded to float32 ONCE (after bias and residual).  Node-level GEMMs are < 1 % of the work, so this costs nothing
+// measurable, while it removes their share of the one-signed energy drift that grows with the number of atoms (a float32 dot
+// product of 128 terms errs by ~3e-8 relative; rounded once the error is 3e-8 of the RESULT only and unbiased).  Used when the
+// engine runs large systems ("energy error vs N").  64 x 64 tile, 16 x 16 threads, 4 x 4 outputs per thread.
+template <int AMODE>
+__global__ __launch_bounds__(256) void k_gemm_f64acc(const GemmP p) {
+  __shared__ float As[32][65];
+  __shared__ float Bs[32][65];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int nN = (p.N + 63) / 64;
+  const int mt = blockIdx.x / nN, nt = blockIdx.x % nN;
+  const long zoffA = (long)blockIdx.z * p.zA;
+  const float* Bz = p.B + (p.zBl ? (blockIdx.z == 0 ? 0 : blockIdx.z < 4 ? 1 : 2) * p.zBl : 0);
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+  for (int k0 = 0; k0 < p.K; k0 += 32) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i, r = idx >> 5, kk = idx & 31;
+      const long grow = (long)mt * 64 + r;
+      float v = grow < p.M ? p.A[grow * p.lda + p.offA0 + zoffA + k0 + kk] : 0.f;
+      if (AMODE == A_SILU) v = silu_f(v);
+      As[kk][r] = v;
+      const int brow = nt * 64 + r;
+      Bs[kk][r] = brow < p.N ? Bz[(long)brow * p.ldb + k0 + kk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int kk = 0; kk < 32; ++kk) {
+      double a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = (double)As[kk][ty * 4 + i]; b[i] = (double)Bs[kk][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  const long zoffC = (long)blockIdx.z * p.zC, zoffR = (long)blockIdx.z * p.zRes;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long row = (long)mt * 64 + ty * 4 + i;
+    if (row >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = nt * 64 + tx * 4 + j;
+      if (col >= p.N) continue;
+      double v = acc[i][j];
+      if (p.bias && (p.zBl == 0 || blockIdx.z == 0)) v += (double)p.bias[col];
+      if (p.resid) v += (double)p.resid[row * p.ldres + p.offRes + zoffR + col];
+      p.Cp[row * p.ldc + p.offC + zoffC + col] = (float)v;
+    }
+  }
 }
 
 }  // namespace umx

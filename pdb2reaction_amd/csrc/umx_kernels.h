@@ -161,71 +161,90 @@ __global__ __launch_bounds__(256) void k_out_sort(const int* __restrict__ out_pt
   }
 }
 
-// K2 edge frames: R (R nhat = +y, minimal rotation, flipped branch for nhat_y < -0.9), D2, envelope
+// K2 edge frames: R (R nhat = +y, minimal rotation, flipped branch for nhat_y < -0.9), D2, envelope.
+// Carried in DOUBLE from the float32 unit vector and rounded to float32 once per entry (round 3): the frame formulas are full of
+// constants that float32 cannot hold (sqrt 3, 2/3, 1/sqrt 3); a float32 evaluation puts the SAME relative error of a few 1e-8 on the
+// same D2 entries of EVERY edge -- a systematic gain on the l = 2 message components, i.e. an energy error that grows with the number
+// of atoms instead of averaging out.  0.3 kFLOP per edge, once per evaluation: free.
 __global__ void k_edge_geom(const float* __restrict__ evec, long ne, float cutoff, float* __restrict__ frame) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= ne) return;
   const float4 v = *reinterpret_cast<const float4*>(evec + e * 4);
-  const float sg = (v.y < -0.9f) ? -1.0f : 1.0f;
-  const float nx = v.x, ny = v.y * sg, nz = v.z * sg;
-  const float k = 1.0f / (1.0f + ny);
-  float R[9] = {1.0f - k * nx * nx, -nx * sg, -k * nx * nz * sg,
-                nx,                 ny * sg,  nz * sg,
-                -k * nx * nz,       -nz * sg, (1.0f - k * nz * nz) * sg};
+  const double sg = (v.y < -0.9f) ? -1.0 : 1.0;
+  const double nx = v.x, ny = (double)v.y * sg, nz = (double)v.z * sg;
+  const double k = 1.0 / (1.0 + ny);
+  const double R[9] = {1.0 - k * nx * nx, -nx * sg, -k * nx * nz * sg,
+                       nx,                ny * sg,  nz * sg,
+                       -k * nx * nz,      -nz * sg, (1.0 - k * nz * nz) * sg};
   float* f = frame + e * FRAME;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) f[i] = R[i];
+  for (int i = 0; i < 9; ++i) f[i] = (float)R[i];
   // D2[a][b] = (2/3) <A_a, R A_b R^T>; columns c_k = R e_k
-  const float c0[3] = {R[0], R[3], R[6]}, c1[3] = {R[1], R[4], R[7]}, c2[3] = {R[2], R[5], R[8]};
-  const float hs3 = 0.5f * SQRT3;
+  const double c0[3] = {R[0], R[3], R[6]}, c1[3] = {R[1], R[4], R[7]}, c2[3] = {R[2], R[5], R[8]};
+  const double s3 = 1.7320508075688772935, hs3 = 0.5 * s3;
 #pragma unroll
   for (int b = 0; b < 5; ++b) {
-    float M[3][3];
+    double M[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        float m;
+        double m;
         if (b == 0) m = hs3 * (c0[i] * c2[j] + c2[i] * c0[j]);
         else if (b == 1) m = hs3 * (c0[i] * c1[j] + c1[i] * c0[j]);
-        else if (b == 2) m = -0.5f * c0[i] * c0[j] + c1[i] * c1[j] - 0.5f * c2[i] * c2[j];
+        else if (b == 2) m = -0.5 * c0[i] * c0[j] + c1[i] * c1[j] - 0.5 * c2[i] * c2[j];
         else if (b == 3) m = hs3 * (c1[i] * c2[j] + c2[i] * c1[j]);
         else m = hs3 * (c2[i] * c2[j] - c0[i] * c0[j]);
         M[i][j] = m;
       }
-    const float t23 = 2.0f / 3.0f;
-    f[9 + 0 * 5 + b] = t23 * SQRT3 * M[0][2];
-    f[9 + 1 * 5 + b] = t23 * SQRT3 * M[0][1];
-    f[9 + 2 * 5 + b] = t23 * (-0.5f * M[0][0] + M[1][1] - 0.5f * M[2][2]);
-    f[9 + 3 * 5 + b] = t23 * SQRT3 * M[1][2];
-    f[9 + 4 * 5 + b] = t23 * hs3 * (M[2][2] - M[0][0]);
+    const double t23 = 2.0 / 3.0;
+    f[9 + 0 * 5 + b] = (float)(t23 * s3 * M[0][2]);
+    f[9 + 1 * 5 + b] = (float)(t23 * s3 * M[0][1]);
+    f[9 + 2 * 5 + b] = (float)(t23 * (-0.5 * M[0][0] + M[1][1] - 0.5 * M[2][2]));
+    f[9 + 3 * 5 + b] = (float)(t23 * s3 * M[1][2]);
+    f[9 + 4 * 5 + b] = (float)(t23 * hs3 * (M[2][2] - M[0][0]));
   }
-  const float u = v.w / cutoff;
-  float env = 0.f, denv = 0.f;
-  if (u < 1.0f) {
-    const float u2 = u * u, u4 = u2 * u2, u5 = u4 * u;
-    env = 1.0f + u5 * (-21.0f + u * (35.0f - 15.0f * u));
-    denv = u4 * (-105.0f + u * (210.0f - 105.0f * u)) / cutoff;
+  const double u = (double)v.w / (double)cutoff;
+  double env = 0.0, denv = 0.0;
+  if (u < 1.0) {
+    const double u2 = u * u, u4 = u2 * u2, u5 = u4 * u;
+    env = 1.0 + u5 * (-21.0 + u * (35.0 - 15.0 * u));
+    denv = u4 * (-105.0 + u * (210.0 - 105.0 * u)) / (double)cutoff;
   }
-  f[34] = env;
-  f[35] = denv;
+  f[34] = (float)env;
+  f[35] = (float)denv;
 }
 
 // ------------------------------------------------------------------------------------------------
 // node-level kernels
 // ------------------------------------------------------------------------------------------------
+// sysemb is DOUBLE (round 3): the system embedding is added to every atom, here and in every layer's norm -- held in float32 its
+// representation error (the same few 1e-8 for every atom) is a systematic energy error proportional to N; added in double and
+// rounded once, what is left is the rounding of each atom's own sum.
 __global__ void k_node_init(const int* __restrict__ znode, int natoms, long nt, const float* __restrict__ emb,
-                            const float* __restrict__ sysemb, float* __restrict__ x) {
+                            const double* __restrict__ sysemb, float* __restrict__ x) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nt * ROW) return;
   const long node = i / ROW;
   const int r = (int)(i % ROW);
-  x[i] = (r < C) ? emb[znode[node % natoms] * C + r] + sysemb[r] : 0.f;
+  x[i] = (r < C) ? (float)((double)emb[znode[node % natoms] * C + r] + sysemb[r]) : 0.f;
+}
+// graph-parallel mode: x0 = node init + the all-reduced edge-degree aggregate, the l = 0 row in the SAME expression as the fused
+// k_rotate_back_reduce<3> of the ordinary path (with all edges on one rank the two paths stay bitwise equal)
+__global__ void k_node_init_add(const int* __restrict__ znode, int natoms, long nt, const float* __restrict__ emb,
+                                const double* __restrict__ sysemb, const float* __restrict__ agg, float* __restrict__ x) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nt * ROW) return;
+  const long node = i / ROW;
+  const int r = (int)(i % ROW);
+  x[i] = (r < C) ? (float)(((double)emb[znode[node % natoms] * C + r] + sysemb[r]) + (double)agg[i]) : agg[i];
 }
 
 // K6 RMS-norm-SH forward: wave per node, lane owns channels 2l, 2l+1
+// The balance weights 1/3, 1/9, 1/15 are applied as DIVISIONS (correctly rounded, error random per value): multiplying by the float32
+// constants scales the rms of every atom by the same 1e-8-level factor (systematic; see k_node_init).
 __global__ __launch_bounds__(256) void k_norm_fwd(const float* __restrict__ x, const float* __restrict__ aw,
-                                                  const float* __restrict__ ab, const float* __restrict__ sysemb,
+                                                  const float* __restrict__ ab, const double* __restrict__ sysemb,
                                                   float* __restrict__ y, long nt) {
   UMX_WAVE_ITEM(node, nt)
   const int c0 = lane * 2;
@@ -234,13 +253,14 @@ __global__ __launch_bounds__(256) void k_norm_fwd(const float* __restrict__ x, c
   for (int r = 0; r < 9; ++r) v[r] = *reinterpret_cast<const float2*>(x + node * ROW + r * C + c0);
   const float mean0 = wave_sum(v[0].x + v[0].y) * (1.0f / C);
   v[0].x -= mean0; v[0].y -= mean0;
-  float q = (v[0].x * v[0].x + v[0].y * v[0].y) * (1.0f / 3.0f);
+  float q0 = v[0].x * v[0].x + v[0].y * v[0].y, q1 = 0.f, q2 = 0.f;
 #pragma unroll
-  for (int r = 1; r < 4; ++r) q += (v[r].x * v[r].x + v[r].y * v[r].y) * (1.0f / 9.0f);
+  for (int r = 1; r < 4; ++r) q1 += v[r].x * v[r].x + v[r].y * v[r].y;
 #pragma unroll
-  for (int r = 4; r < 9; ++r) q += (v[r].x * v[r].x + v[r].y * v[r].y) * (1.0f / 15.0f);
+  for (int r = 4; r < 9; ++r) q2 += v[r].x * v[r].x + v[r].y * v[r].y;
+  float q = q0 / 3.0f + q1 / 9.0f + q2 / 15.0f;
   q = wave_sum(q) * (1.0f / C);
-  const float s = rsqrt_f(q + NORM_EPS);
+  const float s = rstd_eps(q, 1e-5);
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
     const int l = (r == 0) ? 0 : (r < 4 ? 1 : 2);
@@ -248,8 +268,8 @@ __global__ __launch_bounds__(256) void k_norm_fwd(const float* __restrict__ x, c
     float2 o = make_float2(v[r].x * s * w.x, v[r].y * s * w.y);
     if (r == 0) {
       const float2 b = *reinterpret_cast<const float2*>(ab + c0);
-      o.x += b.x; o.y += b.y;
-      if (sysemb) { o.x += sysemb[c0]; o.y += sysemb[c0 + 1]; }
+      if (sysemb) { o.x = (float)((double)o.x + ((double)b.x + sysemb[c0])); o.y = (float)((double)o.y + ((double)b.y + sysemb[c0 + 1])); }
+      else { o.x += b.x; o.y += b.y; }
     }
     *reinterpret_cast<float2*>(y + node * ROW + r * C + c0) = o;
   }
@@ -269,19 +289,19 @@ __global__ __launch_bounds__(256) void k_norm_bwd(const float* __restrict__ gy, 
   }
   const float mean0 = wave_sum(v[0].x + v[0].y) * (1.0f / C);
   v[0].x -= mean0; v[0].y -= mean0;
-  float q = 0.f, dot = 0.f;
+  float ql[3] = {0.f, 0.f, 0.f}, dot = 0.f;
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
     const int l = (r == 0) ? 0 : (r < 4 ? 1 : 2);
-    const float bal = (l == 0) ? (1.0f / 3.0f) : (l == 1 ? (1.0f / 9.0f) : (1.0f / 15.0f));
     const float2 w = *reinterpret_cast<const float2*>(aw + l * C + c0);
     g[r].x *= w.x; g[r].y *= w.y;
-    q += (v[r].x * v[r].x + v[r].y * v[r].y) * bal;
+    ql[l] += v[r].x * v[r].x + v[r].y * v[r].y;
     dot += g[r].x * v[r].x + g[r].y * v[r].y;
   }
+  float q = ql[0] / 3.0f + ql[1] / 9.0f + ql[2] / 15.0f;           // the forward's expression (k_norm_fwd)
   q = wave_sum(q) * (1.0f / C);
   dot = wave_sum(dot);
-  const float s = rsqrt_f(q + NORM_EPS);
+  const float s = rstd_eps(q, 1e-5);
   const float k = s * s * s * dot * (1.0f / C);
   float2 o[9];
 #pragma unroll
@@ -312,7 +332,7 @@ __global__ __launch_bounds__(256) void k_ln_silu_fwd(const float* __restrict__ x
   const float mu = wave_sum(v.x + v.y) * (1.0f / RH);
   v.x -= mu; v.y -= mu;
   const float var = wave_sum(v.x * v.x + v.y * v.y) * (1.0f / RH);
-  const float rstd = rsqrt_f(var + LN_EPS);
+  const float rstd = rstd_eps(var, 1e-5);
   const float2 ww = *reinterpret_cast<const float2*>(w + c0), bb = *reinterpret_cast<const float2*>(b + c0);
   *reinterpret_cast<float2*>(y + row * RH + c0) =
       make_float2(silu_f(v.x * rstd * ww.x + bb.x), silu_f(v.y * rstd * ww.y + bb.y));
@@ -329,7 +349,7 @@ __global__ __launch_bounds__(256) void k_ln_silu_bwd(const float* __restrict__ g
   const float mu = wave_sum(v.x + v.y) * (1.0f / RH);
   v.x -= mu; v.y -= mu;
   const float var = wave_sum(v.x * v.x + v.y * v.y) * (1.0f / RH);
-  const float rstd = rsqrt_f(var + LN_EPS);
+  const float rstd = rstd_eps(var, 1e-5);
   const float2 ww = *reinterpret_cast<const float2*>(w + c0), bb = *reinterpret_cast<const float2*>(b + c0);
   const float xh0 = v.x * rstd, xh1 = v.y * rstd;
   const float gw0 = go.x * silu_grad_f(xh0 * ww.x + bb.x) * ww.x;
@@ -400,8 +420,10 @@ __global__ __launch_bounds__(256) void k_energy_node(const float* __restrict__ p
 
 // K9/K11 readout, stage 2: per image E = rmsd * sum_i e_node[i] + refsum, float64, fixed summation order (strided partial sums,
 // then a tree over the 256 partials) so the result does not depend on scheduling
+// flag: the engine's sticky range flag -- set when an image's energy is not finite (an activation beyond the fp16 operand range of the
+// default precision mode, or a float32 overflow); read back by the host at the next synchronisation point (UMX_ERR_RANGE)
 __global__ __launch_bounds__(256) void k_energy(const float* __restrict__ e_node, int natoms, double rmsd, double refsum,
-                                                double* __restrict__ e_img) {
+                                                double* __restrict__ e_img, int* __restrict__ flag) {
   __shared__ double part[256];
   const int img = blockIdx.x, t = threadIdx.x;
   double acc = 0.0;
@@ -412,7 +434,11 @@ __global__ __launch_bounds__(256) void k_energy(const float* __restrict__ e_node
     if (t < s) part[t] += part[t + s];
     __syncthreads();
   }
-  if (t == 0) e_img[img] = part[0] * rmsd + refsum;
+  if (t == 0) {
+    const double e = part[0] * rmsd + refsum;
+    e_img[img] = e;
+    if (!isfinite(e)) atomicOr(flag, 1);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -498,7 +524,12 @@ __global__ void k_gate_edge_bwd(const float* __restrict__ ghid, const float* __r
 template <int NROWS>
 __global__ __launch_bounds__(256) void k_rotate_back_reduce(const float* __restrict__ msg, const float* __restrict__ frame,
                                                             const int* __restrict__ row_ptr, const float* xin,
-                                                            float* xout, long nt, float scale) {
+                                                            float* xout, long nt, float div,
+                                                            const int* __restrict__ znode = nullptr, int natoms = 0,
+                                                            const float* __restrict__ emb = nullptr, const double* __restrict__ sysemb = nullptr) {
+  // emb != null (edge-degree embedding, K4 + K5 in one): the base of the l = 0 row is the node initialisation emb[Z] + sys_emb itself,
+  // added in DOUBLE together with the aggregate and rounded once -- a float32 x0 row is the same for every atom of an element, and so
+  // is its rounding error (round 3: no error may be shared by all atoms)
   UMX_WAVE_LOOP(node, nt) {
   const int c0 = lane * 2;
   float ax[9], ay[9];
@@ -514,13 +545,19 @@ __global__ __launch_bounds__(256) void k_rotate_back_reduce(const float* __restr
       if (r < NROWS) { const float2 t = *reinterpret_cast<const float2*>(m + r * C); vx[r] = t.x; vy[r] = t.y; }
       else { vx[r] = 0.f; vy[r] = 0.f; }
     }
-    const float sc = f[34] * scale;
+    const float sc = f[34] / div;            // a DIVISION by 5 (or 1): 0.2f is not 1/5, and its error would be shared by every atom
     rot_bwd_acc(f, vx, sc, ax);
     rot_bwd_acc(f, vy, sc, ay);
   }
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
-    const float2 b = xin ? *reinterpret_cast<const float2*>(xin + node * ROW + r * C + c0) : make_float2(0.f, 0.f);   // null: the bare sum (graph-parallel partial)
+    if (emb && r == 0) {
+      const float* er = emb + (long)znode[node % natoms] * C + c0;
+      *reinterpret_cast<float2*>(xout + node * ROW + c0) = make_float2((float)(((double)er[0] + sysemb[c0]) + (double)ax[0]),
+                                                                        (float)(((double)er[1] + sysemb[c0 + 1]) + (double)ay[0]));
+      continue;
+    }
+    const float2 b = (xin && !emb) ? *reinterpret_cast<const float2*>(xin + node * ROW + r * C + c0) : make_float2(0.f, 0.f);   // null: the bare sum (graph-parallel partial)
     *reinterpret_cast<float2*>(xout + node * ROW + r * C + c0) = make_float2(b.x + ax[r], b.y + ay[r]);
   }
   }
@@ -533,7 +570,7 @@ template <int NROWS, bool PLOUT = false>
 __global__ __launch_bounds__(256) void k_rotate_back_bwd(const float* __restrict__ gnode, const float* __restrict__ msg,
                                                          const float* __restrict__ frame, const int* __restrict__ edst,
                                                          float* __restrict__ gmsg, float* __restrict__ dedd,
-                                                         float* __restrict__ tau, long ne, float scale) {
+                                                         float* __restrict__ tau, long ne, float div) {
   UMX_WAVE_ITEM(e, ne)
   const int c0 = lane * 2;
   const float* f = frame + e * FRAME;
@@ -547,7 +584,7 @@ __global__ __launch_bounds__(256) void k_rotate_back_bwd(const float* __restrict
     else { mx[r] = 0.f; my[r] = 0.f; }
   }
   rot_fwd(f, gx, lx); rot_fwd(f, gy, ly);
-  const float sc = f[34] * scale;
+  const float sc = f[34] / div;
   float s = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
@@ -563,7 +600,7 @@ __global__ __launch_bounds__(256) void k_rotate_back_bwd(const float* __restrict
   }
   s = wave_sum(s); tx = wave_sum(tx); ty = wave_sum(ty); tz = wave_sum(tz);
   if (lane == 0) {
-    dedd[e] += f[35] * scale * s;
+    dedd[e] += f[35] / div * s;
     tau[e * 4 + 0] += tx; tau[e * 4 + 1] += ty; tau[e * 4 + 2] += tz;
   }
 }
@@ -647,11 +684,11 @@ __global__ __launch_bounds__(256) void k_gather_rotate_bwd(const float* __restri
 
 // dE/dd through the gaussian basis: dedd[e] += sum_k ggauss[e][k] * d/dd exp(gcoef (d - mu_k)^2)
 __global__ __launch_bounds__(256) void k_radial_dd(const float* __restrict__ ggauss, const float* __restrict__ evec,
-                                                   float gcoef, const float* __restrict__ gmu, float* __restrict__ dedd, long ne) {
+                                                   double gcoef, const double* __restrict__ gmu, float* __restrict__ dedd, long ne) {
   UMX_WAVE_LOOP(e, ne) {
   const float d = evec[e * 4 + 3];
-  const float t = d - gmu[lane];
-  float v = ggauss[e * NG + lane] * exp_f(gcoef * t * t) * 2.0f * gcoef * t;
+  const double t = (double)d - gmu[lane];
+  float v = ggauss[e * NG + lane] * exp_f((float)(gcoef * t * t)) * (float)(2.0 * gcoef * t);
   v = wave_sum(v);
   if (lane == 0) dedd[e] += v;
   }
@@ -666,7 +703,9 @@ __global__ void k_add_rows(float* dst, const float* a, const float* __restrict__
 }
 
 // dE/dvec per edge from dE/dd and the torque (frame detached at the +y pole, as the reference does)
-__global__ void k_force_edge(const float* __restrict__ dedd, const float* __restrict__ tau, const float* __restrict__ frame,
+// dedd2: the radial-MLP part of dE/dd, accumulated apart (the fused radial tail kernels may run on the side stream, concurrently with
+// edge kernels that add to dedd); the total is written back to dedd (debug capture)
+__global__ void k_force_edge(float* __restrict__ dedd, const float* __restrict__ dedd2, const float* __restrict__ tau, const float* __restrict__ frame,
                              const float* __restrict__ evec, float* __restrict__ gvec, long ne) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= ne) return;
@@ -674,7 +713,8 @@ __global__ void k_force_edge(const float* __restrict__ dedd, const float* __rest
   const float* f = frame + e * FRAME;
   float lx = tau[e * 4 + 2], lz = -tau[e * 4 + 0];
   if (fabsf(v.y - 1.0f) <= 1e-8f + 1e-5f) { lx = 0.f; lz = 0.f; }
-  const float inv = 1.0f / v.w, g = dedd[e];
+  const float inv = 1.0f / v.w, g = dedd[e] + dedd2[e];
+  dedd[e] = g;
   // R^T (lx, 0, lz)
   const float tx = f[0] * lx + f[6] * lz, ty = f[1] * lx + f[7] * lz, tz = f[2] * lx + f[8] * lz;
   *reinterpret_cast<float4*>(gvec + e * 4) = make_float4(g * v.x + tx * inv, g * v.y + ty * inv, g * v.z + tz * inv, 0.f);

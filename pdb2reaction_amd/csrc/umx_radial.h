@@ -81,7 +81,7 @@ __device__ __forceinline__ float2 ln_silu_row(float2 v, float2 ww, float2 bb) {
   const float mu = wave_sum_dpp(v.x + v.y) * (1.0f / RH);
   v.x -= mu; v.y -= mu;
   const float var = wave_sum_dpp(v.x * v.x + v.y * v.y) * (1.0f / RH);
-  const float rstd = r_rsqrt<FAST>(var + LN_EPS);
+  const float rstd = FAST == 0 ? rstd_eps(var, 1e-5) : r_rsqrt<FAST>(var + LN_EPS);
   return make_float2(r_silu<FAST>(v.x * rstd * ww.x + bb.x), r_silu<FAST>(v.y * rstd * ww.y + bb.y));
 }
 // backward of it (the arithmetic of k_ln_silu_bwd): go = dE/d(output), v = the pre-LayerNorm row
@@ -90,7 +90,7 @@ __device__ __forceinline__ float2 ln_silu_row_bwd(float2 go, float2 v, float2 ww
   const float mu = wave_sum_dpp(v.x + v.y) * (1.0f / RH);
   v.x -= mu; v.y -= mu;
   const float var = wave_sum_dpp(v.x * v.x + v.y * v.y) * (1.0f / RH);
-  const float rstd = r_rsqrt<FAST>(var + LN_EPS);
+  const float rstd = FAST == 0 ? rstd_eps(var, 1e-5) : r_rsqrt<FAST>(var + LN_EPS);
   const float xh0 = v.x * rstd, xh1 = v.y * rstd;
   const float gw0 = go.x * r_silu_grad<FAST>(xh0 * ww.x + bb.x) * ww.x;
   const float gw1 = go.y * r_silu_grad<FAST>(xh1 * ww.y + bb.y) * ww.y;
@@ -123,9 +123,9 @@ __device__ __forceinline__ void rad_mma(const float* __restrict__ a_lds, const f
 // TR = 32-row MFMA tiles per workgroup tile (RT = 32 TR edges).  TR = 1 halves the LDS and accumulator footprint so that three
 // workgroups share a CU: the VALU-heavy LayerNorm passes of one overlap the MFMAs of the others (measured against TR = 2 below).
 template <int OUTQ3, int FAST, int TR>
-__global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const float* __restrict__ evec, const int* __restrict__ ez, float gcoef,
-                                                        const float* __restrict__ gmu, const float* __restrict__ w1g,
-                                                        const float* __restrict__ ts, const float* __restrict__ tt,
+__global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const float* __restrict__ evec, const int* __restrict__ ez, double gcoef,
+                                                        const double* __restrict__ gmu, const float* __restrict__ w1g,
+                                                        const double* __restrict__ ts, const double* __restrict__ tt,
                                                         const float* __restrict__ ln1w, const float* __restrict__ ln1b,
                                                         const float* __restrict__ w2, const float* __restrict__ b2,
                                                         const float* __restrict__ ln2w, const float* __restrict__ ln2b,
@@ -162,12 +162,14 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
       const float d = dbuf[row];
 #pragma unroll
       for (int q = 0; q < RT / 16; ++q) {
-        const float4 mu = *reinterpret_cast<const float4*>(gmu + c0 + 4 * q);
-        float4 v; float t;
-        t = d - mu.x; v.x = r_exp<FAST>(gcoef * t * t);
-        t = d - mu.y; v.y = r_exp<FAST>(gcoef * t * t);
-        t = d - mu.z; v.z = r_exp<FAST>(gcoef * t * t);
-        t = d - mu.w; v.w = r_exp<FAST>(gcoef * t * t);
+        // centres and coefficient in DOUBLE, the exponent rounded to float32 once (round 3): a float32 centre is off by up to 2.4e-7 A,
+        // i.e. up to 4e-6 relative on a gaussian, the SAME for every edge -- the largest systematic term of the energy error ~ N
+        const double dd = (double)d;
+        float4 v; double t;
+        t = dd - gmu[c0 + 4 * q + 0]; v.x = r_exp<FAST>((float)(gcoef * t * t));
+        t = dd - gmu[c0 + 4 * q + 1]; v.y = r_exp<FAST>((float)(gcoef * t * t));
+        t = dd - gmu[c0 + 4 * q + 2]; v.z = r_exp<FAST>((float)(gcoef * t * t));
+        t = dd - gmu[c0 + 4 * q + 3]; v.w = r_exp<FAST>((float)(gcoef * t * t));
         *reinterpret_cast<float4*>(bufA + row * R_LDG + c0 + 4 * q) = v;
       }
     }
@@ -190,9 +192,11 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
       const int zz = zbuf[row];
       float* p = bufB + row * R_LD + 2 * lane;
       float2 v = *reinterpret_cast<const float2*>(p);
-      const float2 a = *reinterpret_cast<const float2*>(ts + (zz & 0xffff) * RH + 2 * lane);
-      const float2 b = *reinterpret_cast<const float2*>(tt + (zz >> 16) * RH + 2 * lane);
-      v.x += a.x + b.x; v.y += a.y + b.y;
+      // element tables in DOUBLE, the sum rounded once (round 3): a float32 table entry is off by a fixed 3e-8 relative, the same for every
+      // edge of that element pair -- a pattern the LayerNorm does not remove, measured as a -2e-8 gain on the radial output
+      const double2 a = *reinterpret_cast<const double2*>(ts + (zz & 0xffff) * RH + 2 * lane);
+      const double2 b = *reinterpret_cast<const double2*>(tt + (zz >> 16) * RH + 2 * lane);
+      v.x = (float)((double)v.x + (a.x + b.x)); v.y = (float)((double)v.y + (a.y + b.y));
       if (e0 + row < ne) *reinterpret_cast<float2*>(h1pre + (e0 + row) * RH + 2 * lane) = v;
       *reinterpret_cast<float2*>(p) = ln_silu_row<FAST>(v, l1w, l1b);
     }
@@ -227,8 +231,8 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
 // ga2 = output of the fc3^T GEMM; w2T = W2^T ([k][j]), w1gT = W1g^T ([64 gaussians][128]).
 template <int FAST, int TR>
 __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_tail(const float* __restrict__ ga2, const float* __restrict__ h2pre,
-                                                        const float* __restrict__ h1pre, const float* __restrict__ evec, float gcoef,
-                                                        const float* __restrict__ gmu, const float* __restrict__ ln2w,
+                                                        const float* __restrict__ h1pre, const float* __restrict__ evec, double gcoef,
+                                                        const double* __restrict__ gmu, const float* __restrict__ ln2w,
                                                         const float* __restrict__ ln2b, const float* __restrict__ ln1w,
                                                         const float* __restrict__ ln1b, const float* __restrict__ w2T,
                                                         const float* __restrict__ w1gT, float* __restrict__ dedd, long ne) {
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_tail(const floa
   for (int c = 0; c < RH / 8; ++c) W1T[c] = *reinterpret_cast<const float4*>(w1gT + (gj * 32 + l31) * RH + c * 8 + 4 * h);
   const float2 l1w = *reinterpret_cast<const float2*>(ln1w + 2 * lane), l1b = *reinterpret_cast<const float2*>(ln1b + 2 * lane);
   const float2 l2w = *reinterpret_cast<const float2*>(ln2w + 2 * lane), l2b = *reinterpret_cast<const float2*>(ln2b + 2 * lane);
-  const float mu_col = gmu[gj * 32 + l31];
+  const double mu_col = gmu[gj * 32 + l31];
   const long ntiles = (ne + RT - 1) / RT;
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long e0 = tile * RT;
@@ -298,9 +302,9 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_tail(const floa
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = gi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float t = dbuf[row] - mu_col;
+        const double t = (double)dbuf[row] - mu_col;
         // sum over the 32 columns of this half-wave (two 16-lane rows), for both halves at once
-        const int rs = __builtin_bit_cast(int, row16_sum(a1[r] * r_exp<FAST>(gcoef * t * t) * 2.0f * gcoef * t));
+        const int rs = __builtin_bit_cast(int, row16_sum(a1[r] * r_exp<FAST>((float)(gcoef * t * t)) * (float)(2.0 * gcoef * t)));
         const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rs, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(rs, 16));
         const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rs, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(rs, 48));
         if (lane == 0) { part[gj][row] = s0; part[gj][row + 4] = s1; }      // lane 0 sees h = 0: `row` is the first half's row, +4 the second's

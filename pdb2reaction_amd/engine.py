@@ -21,9 +21,10 @@ _lib = None
 
 
 class ProfileStats(C.Structure):
-    """Mirror of ``umx_profile_stats`` (include/umx.h): [0] split-precision plane GEMM family, [1] fp32-MFMA GEMM family."""
+    """Mirror of ``umx_profile_stats`` (include/umx.h): [0] split-precision plane GEMM family, [1] fp32-MFMA GEMM family, [2] fused
+    radial-MLP kernels."""
 
-    _fields_ = [("ms", C.c_double * 2), ("launches", C.c_int64 * 2), ("alg_flops", C.c_double * 2), ("mfma_flops", C.c_double * 2)]
+    _fields_ = [("ms", C.c_double * 3), ("launches", C.c_int64 * 3), ("alg_flops", C.c_double * 3), ("mfma_flops", C.c_double * 3)]
 
 
 UMX_ERR_RANGE = -6      # include/umx.h
@@ -69,6 +70,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "umx_last_error": ([vp], C.c_char_p),
         "umx_load_weights": ([vp, vp, C.c_size_t], i32),
         "umx_set_precision": ([vp, C.c_char_p], i32),
+        "umx_precision_mode": ([vp], C.c_char_p),
         "umx_set_system": ([vp, i32, C.POINTER(C.c_int32), i32, i32, i32, C.c_float, i32], i32),
         "umx_set_workspace_limit": ([vp, C.c_size_t], i32),
         "umx_energy_forces": ([vp, i32, fp, dp, fp], i32),
@@ -89,18 +91,30 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     if path is None:
         # content check against the sources in this tree: the .so is git-ignored and travels prebuilt, so an edit without a
         # rebuild would silently run old kernels (VERDICT r1 "stale-.so hazard")
-        from .build import source_digest
+        from .build import dependencies, source_digest
 
-        have, want = lib.umx_build_digest().decode(), source_digest()
+        have = lib.umx_build_digest().decode()
+        if all(os.path.exists(d) for d in dependencies()) and any(d.endswith(".hip") for d in dependencies()):
+            want, what = source_digest(), "tree"
+        else:
+            # a deployment that ships the prebuilt library without csrc/ and include/ (ADVICE r2): nothing to hash -- hold the
+            # library to the digest file written next to it at build time, or accept it with a warning when that is absent too
+            try:
+                with open(p + ".digest") as f:
+                    want, what = f.read().strip(), "libumx.so.digest"
+            except OSError:
+                want, what = have, "none"
+                warnings.warn(f"{p}: neither the kernel sources nor libumx.so.digest are present; the library's build digest "
+                              f"({have[:12]}...) cannot be checked", RuntimeWarning)
         if have != want and os.environ.get("UMX_ALLOW_STALE", "0") != "1":
-            raise ImportError(f"{p} was built from other sources (digest {have[:12]}..., tree {want[:12]}...): rebuild with "
+            raise ImportError(f"{p} was built from other sources (digest {have[:12]}..., {what} {want[:12]}...): rebuild with "
                               "`python -m pdb2reaction_amd.build` (UMX_ALLOW_STALE=1 overrides)")
         _lib = lib
     return lib
 
 
 EXPORTED_SYMBOLS = (
-    "umx_abi_version", "umx_build_digest", "umx_create", "umx_destroy", "umx_last_error", "umx_load_weights", "umx_set_precision", "umx_set_system",
+    "umx_abi_version", "umx_build_digest", "umx_create", "umx_destroy", "umx_last_error", "umx_load_weights", "umx_set_precision", "umx_precision_mode", "umx_set_system",
     "umx_set_workspace_limit", "umx_energy_forces", "umx_energy_forces_dev", "umx_gp_begin", "umx_gp_step", "umx_synchronize",
     "umx_last_graph_stats", "umx_profile_enable", "umx_profile_read", "umx_bond_changes", "umx_debug_fetch", "umx_debug_keep",
 )
@@ -110,7 +124,8 @@ class Engine:
     """One UMA-S engine on one GPU (one per process/rank)."""
 
     def __init__(self, device: int = 0, precision: Optional[str] = None):
-        """precision: None = the UMX_PRECISION environment variable (default "split"), else "split" | "split-bf16" | "fp32"."""
+        """precision: None = the UMX_PRECISION environment variable (default "auto": split-f16 up to 4096 atoms per image,
+        split-bf16 above), else "auto" | "split" | "split-bf16" | "fp32"."""
         self.lib = load_library()
         self._h = C.c_void_p()
         st = self.lib.umx_create(C.byref(self._h), int(device))
@@ -187,10 +202,27 @@ class Engine:
                                                  f.ctypes.data_as(fp) if forces else None), "umx_energy_forces")
         return e, f
 
+    def precision_mode(self) -> str:
+        """The arithmetic the engine is in now ("split-f16" | "split-bf16" | "fp32"): what "auto" resolved to for the bound system."""
+        return self.lib.umx_precision_mode(self._h).decode()
+
+    def take_range_error(self) -> bool:
+        """Synchronise and collect the sticky range flag of the device-pointer entries: True when an evaluation since the last
+        check produced a non-finite energy (the flag is cleared), False otherwise; any other failure raises."""
+        st = self.lib.umx_synchronize(self._h)
+        if st == UMX_ERR_RANGE:
+            return True
+        self._chk(st, "umx_synchronize")
+        return False
+
+    def widen(self, why: str = "range violation reported by a peer rank") -> bool:
+        """Public form of the fp16 -> bf16 forward-plane switch, for callers that decide it collectively (parallel.py, hessian.py)."""
+        return self._widen(why)
+
     def _widen(self, why: str) -> bool:
-        """Move an engine in the default mode to UMX_PRECISION=split-bf16 (once); False when that is not the mode in use."""
-        mode = self.precision or os.environ.get("UMX_PRECISION", "split")
-        if self.widened or mode not in ("split", "split-f16") or self._blob is None or self._system is None:
+        """Move an engine whose forward operands are fp16 planes to UMX_PRECISION=split-bf16 (once); False when that is not the
+        arithmetic in use (or UMX_NO_WIDEN=1)."""
+        if self.widened or self._blob is None or self._system is None or self.precision_mode() != "split-f16":
             return False
         if os.environ.get("UMX_NO_WIDEN", "0") == "1":
             return False
@@ -255,8 +287,8 @@ class Engine:
     def profile_read(self, reset: bool = True):
         st = ProfileStats()
         self._chk(self.lib.umx_profile_read(self._h, C.byref(st), int(reset)), "umx_profile_read")
-        fam = [{"ms": st.ms[i], "launches": int(st.launches[i]), "alg_flops": st.alg_flops[i], "mfma_flops": st.mfma_flops[i]} for i in range(2)]
-        return {"split_bf16": fam[0], "fp32": fam[1], "gemm_ms": fam[0]["ms"] + fam[1]["ms"], "gemm_launches": fam[0]["launches"] + fam[1]["launches"],
+        fam = [{"ms": st.ms[i], "launches": int(st.launches[i]), "alg_flops": st.alg_flops[i], "mfma_flops": st.mfma_flops[i]} for i in range(3)]
+        return {"split_bf16": fam[0], "fp32": fam[1], "radial": fam[2], "gemm_ms": fam[0]["ms"] + fam[1]["ms"], "gemm_launches": fam[0]["launches"] + fam[1]["launches"],
                 "gemm_flops": fam[0]["alg_flops"] + fam[1]["alg_flops"]}
 
     def debug_keep(self, on: bool = True):

@@ -38,7 +38,7 @@ def mask_frozen(forces: np.ndarray, frozen: Sequence[int]) -> np.ndarray:
 
 
 def fd_hessian(batch_forces: Callable[[np.ndarray], np.ndarray], coord_ang: np.ndarray, frozen: Sequence[int], *, device,
-               double: bool, partial: bool, batch: int = 64, step: float = FD_STEP_ANG, shard: bool = False, group=None):
+               double: bool, partial: bool, batch: int = 64, step: float = FD_STEP_ANG, shard: bool = False, group=None, engine=None):
     """Central-difference Hessian in eV/A^2 as a torch tensor (n_out, 3, n_out, 3) on `device`.
 
     batch_forces(coords[K,N,3]) -> forces [K,N,3] float32.  Columns of frozen DOF stay zero (full output) or are
@@ -52,6 +52,11 @@ def fd_hessian(batch_forces: Callable[[np.ndarray], np.ndarray], coord_ang: np.n
     structures fail loudly instead of summing inconsistent columns.  With ``shard=False`` (the default, and what
     ``uma_pysis.get_hessian`` does unless sharding was enabled on the calculator) the call is purely local even inside an
     initialised process group -- a rank-0-only frequency step neither hangs nor returns a 1/G-filled matrix.
+
+    `engine` (optional, sharded mode): the ``Engine`` behind `batch_forces`.  An engine that meets an fp16 range violation widens
+    itself to bf16 forward planes locally (``Engine._widen``); the ranks then agree on that before the columns are summed (one
+    MAX all-reduce of the flag) and a rank that computed columns in the narrower arithmetic computes them again, so one Hessian
+    never mixes two arithmetics.
     """
     import torch
     import torch.distributed as dist
@@ -83,15 +88,30 @@ def fd_hessian(batch_forces: Callable[[np.ndarray], np.ndarray], coord_ang: np.n
     hess = torch.zeros((dof, dof), device=device, dtype=dtype)
     per_call = max(batch // 2, 1)
     mine = active[rank::world] if world > 1 else active
-    for start in range(0, len(mine), per_call):
-        cols = mine[start: start + per_call]
-        disp = np.repeat(x0[None], 2 * len(cols), axis=0)
-        for m, k in enumerate(cols):
-            a, c = divmod(k, 3)
-            disp[2 * m, a, c] += step
-            disp[2 * m + 1, a, c] -= step
-        f = torch.from_numpy(np.ascontiguousarray(batch_forces(disp)).reshape(2 * len(cols), dof)).to(device, dtype=dtype)
-        hess[:, torch.as_tensor(cols, device=device, dtype=torch.long)] = (-(f[0::2] - f[1::2]) / (2.0 * step)).T
+
+    def my_columns():
+        for start in range(0, len(mine), per_call):
+            cols = mine[start: start + per_call]
+            disp = np.repeat(x0[None], 2 * len(cols), axis=0)
+            for m, k in enumerate(cols):
+                a, c = divmod(k, 3)
+                disp[2 * m, a, c] += step
+                disp[2 * m + 1, a, c] -= step
+            f = torch.from_numpy(np.ascontiguousarray(batch_forces(disp)).reshape(2 * len(cols), dof)).to(device, dtype=dtype)
+            hess[:, torch.as_tensor(cols, device=device, dtype=torch.long)] = (-(f[0::2] - f[1::2]) / (2.0 * step)).T
+
+    was_wide = bool(getattr(engine, "widened", False))
+    my_columns()
+    if world > 1 and engine is not None:
+        flag = torch.tensor([1.0 if engine.widened else 0.0], dtype=torch.float64,
+                            device="cpu" if dist.get_backend(group) == "gloo" else device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if float(flag[0]) > 0.0 and not was_wide:
+            # some rank left the fp16 operand range during THIS Hessian: all ranks move to bf16 forward planes, and every rank
+            # repeats its columns (those it computed before the switch included) so that all columns share one arithmetic
+            if not engine.widened:
+                engine.widen("fp16 range violation on a peer rank during a sharded FD Hessian")
+            my_columns()
     if world > 1:
         if dist.get_backend(group) == "gloo" and hess.device.type != "cpu":
             host = hess.cpu()

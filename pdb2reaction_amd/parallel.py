@@ -35,8 +35,13 @@ class ShardedImageEvaluator:
     """
 
     def __init__(self, evaluate_local: Callable, n_images: int, n_atoms: int, device: torch.device,
-                 group: Optional["dist.ProcessGroup"] = None):
+                 group: Optional["dist.ProcessGroup"] = None, engine=None):
+        """engine: the ``Engine`` behind ``evaluate_local`` when that goes through the asynchronous device-pointer entry
+        (``umx_energy_forces_dev`` cannot refuse a non-finite energy itself).  With it, the gathered energies are checked after
+        every call: they are the same on every rank, so every rank takes the same decision -- widen the engine to bf16 forward
+        planes (``Engine.widen``) and evaluate again, or raise -- without a further collective."""
         self.evaluate_local = evaluate_local
+        self.engine = engine
         self.n_images, self.n_atoms, self.device, self.group = n_images, n_atoms, device, group
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.world = dist.get_world_size(group) if self.distributed else 1
@@ -70,6 +75,13 @@ class ShardedImageEvaluator:
                 lo, hi = shard_bounds(self.n_images, self.world, r)
                 rows.append(self._recv[r * self.slot: r * self.slot + (hi - lo)])
             out = torch.cat(rows, dim=0)
+        if self.engine is not None and not bool(torch.isfinite(out[:, 0]).all()):
+            self.engine.take_range_error()                      # collect (clear) the sticky flag of this rank's engine, if it was the one
+            if self.engine.widen("non-finite energy in a sharded string evaluation"):
+                return self(coords)                             # every rank is here with the same gathered energies: all widen, all repeat
+            bad = torch.nonzero(~torch.isfinite(out[:, 0])).flatten().tolist()
+            raise RuntimeError(f"non-finite energy for image(s) {bad} (precision mode {self.engine.precision_mode()}): non-finite "
+                               "coordinates, or an overflow that wider forward planes cannot cure")
         return out[:, 0].clone(), out[:, 1:].reshape(self.n_images, self.n_atoms, 3).clone()
 
 
@@ -93,9 +105,13 @@ class GraphParallelEvaluator:
     9 x N x 1152 x 4 B + N x 12 B (92 MB per all-reduce at 20 000 atoms).
     """
 
-    def __init__(self, engine, n_atoms: int, device: torch.device, group: Optional["dist.ProcessGroup"] = None):
+    def __init__(self, engine, n_atoms: int, device: torch.device, group: Optional["dist.ProcessGroup"] = None,
+                 force_collective: bool = False):
+        """force_collective: issue the all-reduces even in a one-rank group (they are the identity there) -- exercises the in-place
+        RCCL call on the engine's own workspace memory where only one GPU is available."""
         self.engine, self.n_atoms, self.device, self.group = engine, int(n_atoms), device, group
-        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        initialised = dist.is_available() and dist.is_initialized()
+        self.distributed = initialised and (dist.get_world_size(group) > 1 or bool(force_collective))
         self.world = dist.get_world_size(group) if self.distributed else 1
         self.rank = dist.get_rank(group) if self.distributed else 0
         self.lo, self.hi = shard_bounds(self.n_atoms, self.world, self.rank)
@@ -104,7 +120,7 @@ class GraphParallelEvaluator:
         self._e = torch.zeros(1, dtype=torch.float64, device=device)
         self._f = torch.zeros(self.n_atoms, 3, dtype=torch.float32, device=device)
 
-    def __call__(self, pos_ang: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def __call__(self, pos_ang: torch.Tensor, _retry: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
         pos = pos_ang.to(device=self.device, dtype=torch.float32).contiguous()
         if pos.shape != (self.n_atoms, 3):
             raise ValueError(f"positions must be ({self.n_atoms}, 3), got {tuple(pos.shape)}")
@@ -125,4 +141,11 @@ class GraphParallelEvaluator:
                 buf.copy_(host)
             else:
                 dist.all_reduce(buf, group=self.group)
+        if not bool(torch.isfinite(self._e).all()):
+            # energies are complete on every rank (node-level work is replicated): every rank sees the same value and takes the same path
+            self.engine.take_range_error()
+            if not _retry and self.engine.widen("non-finite energy in a graph-parallel evaluation"):
+                return self(pos_ang, _retry=True)
+            raise RuntimeError(f"non-finite energy in graph-parallel mode (precision mode {self.engine.precision_mode()}): non-finite "
+                               "coordinates, or an overflow that wider forward planes cannot cure")
         return self._e.clone(), self._f.clone()

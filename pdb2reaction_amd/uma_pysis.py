@@ -154,9 +154,20 @@ class UMAcore:
         weights = resolve_weights(model)                    # raises FileNotFoundError before any GPU work
         self.z = synth.symbols_to_z(self.elem)
         W.check_merged_for(weights, self.z, charge, spin, task_name)   # a MoLE merge is valid for one system only
-        self.engine = Engine(_device_index(device), precision=precision)     # None: UMX_PRECISION (default "split")
+        self.engine = Engine(_device_index(device), precision=precision)     # None: UMX_PRECISION (default "auto")
         self.engine.load_weights(weights)
         self.engine.set_system(self.z, charge=charge, spin=spin, task=task_name, radius=radius, max_neigh=max_neigh)
+        self._gp = None
+        if self.workers > 1 and os.environ.get("UMX_WORKERS_GP", "1") != "0":
+            # the reference's workers > 1 IS graph-parallel inference of one structure over `workers` processes
+            # (ParallelMLIPPredictUnit, :220-242).  Under torch.distributed with one rank per GPU and a world of exactly that
+            # many ranks the same thing happens here: the graph of every geometry is partitioned over the ranks -- which is also
+            # the route for a single structure too large for one GPU's workspace (UMX_ERR_CAPACITY).  Every rank must then call
+            # the calculator with the same coordinates (SPMD), as every rank of such a job runs the same driver.
+            import torch.distributed as dist
+
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() == self.workers:
+                self.enable_graph_parallel(True)
 
     @property
     def device(self):
@@ -245,11 +256,11 @@ class uma_pysis(Calculator):
         hessian_double: bool = CALC_KW["hessian_double"],
         **kwargs,
     ):
-        # not a reference keyword: the arithmetic of the large GEMMs ("split" | "split-bf16" | "fp32"; None = UMX_PRECISION).
+        # not a reference keyword: the arithmetic of the large GEMMs ("auto" | "split" | "split-bf16" | "fp32"; None = UMX_PRECISION).
         # Taken out of **kwargs so that the reference's signature stays as it is.
         precision = kwargs.pop("precision", None)
-        if precision not in (None, "split", "split-f16", "split-bf16", "fp32"):
-            raise ValueError(f"precision must be split, split-bf16 or fp32, got {precision!r}")
+        if precision not in (None, "auto", "split", "split-f16", "split-bf16", "fp32"):
+            raise ValueError(f"precision must be auto, split, split-bf16 or fp32, got {precision!r}")
         super().__init__(charge=charge, mult=spin, **kwargs)
         self._core: Optional[UMAcore] = None
         self._core_kw = dict(
@@ -305,7 +316,7 @@ class uma_pysis(Calculator):
         base = core.compute(coord_ang, forces=True, hessian=False)
         hess = H.fd_hessian(lambda c: core.compute_batch(c, forces=True)["forces"], coord_ang, self.freeze_atoms, device=core.device,
                             double=self.hessian_double, partial=self.return_partial_hessian, batch=FD_BATCH,
-                            shard=self._hess_shard, group=self._hess_group)
+                            shard=self._hess_shard, group=self._hess_group, engine=getattr(core, "engine", None))
         return {"energy": base["energy"], "forces": base["forces"], "hessian": hess}
 
     # ---------- PySisyphus API --------------------------------------

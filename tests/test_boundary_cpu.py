@@ -26,11 +26,11 @@ def header_functions():
 def test_library_exports_every_declared_symbol():
     lib = E.load_library()
     names = header_functions()
-    assert len(names) >= 14
+    assert len(names) >= 21
     for n in names:
         assert hasattr(lib, n), f"libumx.so does not export {n} declared in include/umx.h"
     assert sorted(E.EXPORTED_SYMBOLS) == names
-    assert lib.umx_abi_version() == 6
+    assert lib.umx_abi_version() == 7
 
 
 def test_missing_library_is_loud(tmp_path):
@@ -257,3 +257,31 @@ def test_build_dependency_list_covers_every_kernel_header(monkeypatch):
         assert B.needs_build(), touched
     monkeypatch.setattr(os.path, "getmtime", lambda p: min(real(p), t_lib))
     assert not B.needs_build()
+
+
+def test_prebuilt_library_without_sources_still_loads(monkeypatch, tmp_path):
+    """a deployment that ships libumx.so without csrc/ and include/ must not fail at import -- the library is then
+    held to the libumx.so.digest written next to it at build time (and refused when THAT disagrees)."""
+    import shutil
+
+    from pdb2reaction_amd import build as B
+
+    so = tmp_path / "libumx.so"
+    shutil.copy(E.LIB_PATH, so)
+    good = E.load_library().umx_build_digest().decode()
+    monkeypatch.setattr(B, "dependencies", lambda: [str(tmp_path / "csrc" / "umx_api.hip"), str(tmp_path / "include" / "umx.h")])
+    monkeypatch.setattr(E, "LIB_PATH", str(so))
+    monkeypatch.delenv("UMX_LIBRARY", raising=False)
+    monkeypatch.delenv("UMX_ALLOW_STALE", raising=False)
+    monkeypatch.setattr(E, "_lib", None)
+    (tmp_path / "libumx.so.digest").write_text(good + "\n")
+    assert E.load_library().umx_build_digest().decode() == good          # sources absent, digest file agrees
+    monkeypatch.setattr(E, "_lib", None)
+    (tmp_path / "libumx.so.digest").write_text("0" * 64 + "\n")
+    with pytest.raises(ImportError, match="built from other sources"):
+        E.load_library()
+    (tmp_path / "libumx.so.digest").unlink()
+    monkeypatch.setattr(E, "_lib", None)
+    with pytest.warns(RuntimeWarning, match="cannot be checked"):
+        E.load_library()
+    monkeypatch.setattr(E, "_lib", None)

@@ -1,9 +1,11 @@
 """Graph-parallel single-image mode (rows a12 / f4): the reference's ``workers > 1`` semantics -- the graph of ONE image partitioned
 over ranks (``uma_pysis.py:220-242``) -- on the engine's exchange-point API (umx_gp_begin / umx_gp_step).
 
-World size 1: the partial-sum path with all edges local must reproduce the ordinary evaluation bit for bit.
+World size 1: the partial-sum path with all edges local must reproduce the ordinary evaluation bit for bit -- also with the all-reduces
+actually issued through RCCL (backend nccl, one rank) IN PLACE on the engine's workspace memory.
 World size 2 and 3: ranks share the one GPU of the test box (gloo group, host-staged all-reduce: the collective the RCCL path does on
-device); every rank must end with the same energies / forces as a single engine, up to float32 summation order."""
+device); every rank must end with the ORACLE's energy and forces (float64 restatement, BASELINE tolerances) and with the same numbers
+as every other rank; a rank that owns no atoms / no edges (more ranks than atoms) takes part with zero partial sums."""
 import os
 import socket
 
@@ -45,7 +47,7 @@ def test_world_size_one_is_bitwise_the_ordinary_path():
     eng.close()
 
 
-def _worker(rank, world, port, n_atoms, out):
+def _worker(rank, world, port, n_atoms, out, precision=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -55,47 +57,95 @@ def _worker(rank, world, port, n_atoms, out):
         torch.cuda.set_device(0)
         dev = torch.device("cuda", 0)
         z, imgs, _ = synth.make_images(n_atoms, 1, seed=8)
-        eng = Engine(0)
+        eng = Engine(0, precision=precision)
         eng.load_weights(W.make_synthetic_weights(0))
         eng.set_system(z)
         gp = GraphParallelEvaluator(eng, n_atoms, dev)
         e, f = gp(torch.as_tensor(imgs[0], dtype=torch.float32, device=dev))
         ne_local = eng.graph_stats()[0]
         eng.close()
-        # the calculator boundary: uma_pysis with the graph-parallel mode switched on (the reference's workers > 1)
+        # the calculator boundary: the reference's keyword -- workers = number of ranks switches the graph-parallel mode on by itself
         import importlib
         U = importlib.import_module("pdb2reaction_amd.uma_pysis")
         elem = [synth.SYMBOLS[int(q)] for q in z]
-        calc = U.uma_pysis(model="synthetic", freeze_atoms=[1])
-        calc.enable_graph_parallel(elem)
+        calc = U.uma_pysis(model="synthetic", freeze_atoms=[1], workers=world, **({"precision": precision} if precision else {}))
         r = calc.get_forces(elem, (imgs[0] * U.ANG2BOHR).reshape(-1))
+        assert calc._core._gp is not None and calc._core.parallel_predict
         calc.close()
         out[rank] = (float(e[0]), f.cpu().numpy(), ne_local, (gp.lo, gp.hi), r["energy"] / U.EV2AU, r["forces"].reshape(-1, 3) / U.F_EVAA_2_AU)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_atoms", [(2, 300), (3, 157)])
-def test_ranks_partition_one_image(world, n_atoms):
-    z, imgs, _ = synth.make_images(n_atoms, 1, seed=8)
-    eng, e_ref, f_ref, ne_all = _single(z, imgs)
-    eng.close()
+def _port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    return port
+
+
+@pytest.mark.parametrize("world,n_atoms,precision", [(2, 300, None), (3, 157, None), (2, 120, "split-bf16"), (3, 2, None)])
+def test_ranks_partition_one_image(oracle, world, n_atoms, precision):
+    z, imgs, _ = synth.make_images(n_atoms, 1, seed=8)
+    eng, e_ref, f_ref, ne_all = _single(z, imgs)
+    eng.close()
+    # the ORACLE is the yardstick (the mode was only ever compared with the single-engine HIP result)
+    e_orc, f_orc = oracle.energy_forces(z, np.asarray(imgs[0], dtype=np.float32).astype(np.float64))
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, port, n_atoms, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _port(), n_atoms, out, precision), nprocs=world, join=True)
     assert sorted(out.keys()) == list(range(world))
     assert sum(out[r][2] for r in range(world)) == ne_all               # every directed edge is built by exactly one rank
     assert [out[r][3] for r in range(world)][0][0] == 0 and out[world - 1][3][1] == n_atoms
+    if n_atoms < world:
+        assert any(out[r][3][0] == out[r][3][1] and out[r][2] == 0 for r in range(world))      # a rank without atoms and edges
     for r in range(world):
         e, f, ne_r, _, e_calc, f_calc = out[r]
-        assert abs(e_calc - e_ref[0]) <= 2e-5 and np.all(f_calc[1] == 0.0)              # frozen atom zeroed as usual
+        assert abs(e - e_orc) <= 1e-4 and np.abs(f - f_orc).max() <= 1e-3               # BASELINE.json tolerances, per rank
+        assert abs(e_calc - e_orc) <= 1e-4 and np.all(f_calc[1] == 0.0)                 # frozen atom zeroed as usual
         act = np.arange(n_atoms) != 1
-        assert np.abs(f_calc[act] - f_ref[0][act]).max() <= 2e-5
-        assert 0 < ne_r < ne_all
-        assert abs(e - e_ref[0]) <= 2e-5                                # summation order of float32 partial sums differs
+        if act.any():
+            assert np.abs(f_calc[act] - f_orc[act]).max() <= 1e-3
+        if n_atoms >= world:
+            assert 0 < ne_r < ne_all
+        assert abs(e - e_ref[0]) <= 2e-5                                # vs the single engine: summation order of float32 partial sums
         assert np.abs(f - f_ref[0]).max() <= 2e-5
         assert np.array_equal(f, out[0][1]) and e == out[0][0]          # all ranks hold the same reduced result
+
+
+def _nccl_one_rank(rank, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from pdb2reaction_amd.engine import Engine
+        from pdb2reaction_amd.parallel import GraphParallelEvaluator
+
+        z, imgs, _ = synth.make_images(120, 1, seed=5)
+        eng = Engine(0)
+        eng.load_weights(W.make_synthetic_weights(0))
+        eng.set_system(z)
+        e0, f0 = eng.energy_forces(imgs)
+        gp = GraphParallelEvaluator(eng, len(z), dev, force_collective=True)
+        assert gp.distributed and not gp._stage_cpu
+        e, f = gp(torch.as_tensor(imgs[0], dtype=torch.float32, device=dev))
+        torch.cuda.synchronize()
+        out["n_exchanges"] = gp.n_exchanges
+        out["bitwise"] = bool(float(e[0]) == e0[0] and np.array_equal(f.cpu().numpy(), f0[0]))
+        out["backend"] = dist.get_backend()
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_all_reduce_in_place_on_engine_memory():
+    """The RCCL leg of the graph-parallel mode: with a one-rank nccl group and ``force_collective`` all ten all-reduces are issued by
+    RCCL on the caller's stream directly on the engine's workspace buffers (the ``__cuda_array_interface__`` view, no copy).  A
+    one-rank all-reduce is the identity, so the result must stay bitwise the ordinary evaluation -- what this proves is that RCCL
+    accepts and orders work on memory it did not allocate, between two engine segments, on real hardware."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_nccl_one_rank, args=(_port(), out), nprocs=1, join=True)
+    assert out["backend"] == "nccl" and out["n_exchanges"] == 10 and out["bitwise"] is True

@@ -170,6 +170,102 @@ def test_fp16_operand_range_is_guarded(weights, monkeypatch):
         ref.close()
 
 
+def test_device_pointer_entry_reports_range_violations(weights, monkeypatch):
+    """the asynchronous device-pointer entry cannot look at its own result, so an activation beyond the fp16
+    operand range used to hand NaN energies / forces to torch-resident callers with status 0 and no way to find out.  Now the kernel
+    that writes the energies sets a sticky device flag: umx_synchronize returns UMX_ERR_RANGE (and clears it), and so does the next
+    evaluation on the engine; ShardedImageEvaluator (the multi-GPU string path) checks the gathered energies, widens the engine to
+    bf16 forward planes -- every rank sees the same energies, so all ranks do -- and evaluates again."""
+    import torch
+
+    from pdb2reaction_amd.engine import Engine, UmxError, UMX_ERR_RANGE
+    from pdb2reaction_amd.parallel import ShardedImageEvaluator
+
+    big = dict(weights)
+    key = "blocks.0.edge_wise.so2_conv_1.rad_func.fc3"
+    big[key + ".weight"] = (np.asarray(weights[key + ".weight"]) * 3e4).astype(np.float32)
+    z, imgs, _ = synth.make_images(40, 2, seed=2)
+    dev = torch.device("cuda", 0)
+    pos = torch.as_tensor(imgs, dtype=torch.float32, device=dev)
+    e_t = torch.zeros(2, dtype=torch.float64, device=dev)
+    f_t = torch.zeros(2, 40, 3, dtype=torch.float32, device=dev)
+    ref = Engine(0, precision="split-bf16")
+    eng = Engine(0)                                             # default mode: "auto" -> fp16 planes at this size
+    try:
+        ref.load_weights(big); ref.set_system(z)
+        e0, f0 = ref.energy_forces(imgs)
+        eng.load_weights(big); eng.set_system(z)
+        assert eng.precision_mode() == "split-f16"
+        st = torch.cuda.current_stream().cuda_stream
+        eng.energy_forces_dev(2, pos.data_ptr(), e_t.data_ptr(), f_t.data_ptr(), stream=st)       # status 0: nothing has been looked at
+        assert eng.take_range_error() is True and not torch.isfinite(e_t).all()
+        assert eng.take_range_error() is False                  # cleared by the report
+        eng.energy_forces_dev(2, pos.data_ptr(), e_t.data_ptr(), f_t.data_ptr(), stream=st)
+        with pytest.raises(UmxError, match="previous device-pointer evaluation produced a non-finite energy") as ei:
+            eng.energy_forces_dev(2, pos.data_ptr(), e_t.data_ptr(), f_t.data_ptr(), stream=st)  # the NEXT call refuses to run
+        assert ei.value.status == UMX_ERR_RANGE
+        eng.energy_forces_dev(2, pos.data_ptr(), e_t.data_ptr(), f_t.data_ptr(), stream=st)       # ... once: the flag is cleared
+        with pytest.raises(UmxError, match="device-pointer evaluation produced a non-finite energy"):
+            eng.synchronize()
+        eng.synchronize()
+
+        def local(c):
+            eng.energy_forces_dev(c.shape[0], c.contiguous().data_ptr(), e_t.data_ptr(), f_t.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+            return e_t[: c.shape[0]], f_t[: c.shape[0]]
+
+        ev = ShardedImageEvaluator(local, 2, 40, dev, engine=eng)
+        with pytest.warns(RuntimeWarning, match="split-bf16"):
+            e, f = ev(pos)
+        assert eng.widened and eng.precision_mode() == "split-bf16"
+        assert np.array_equal(e.cpu().numpy(), e0) and np.array_equal(f.cpu().numpy(), f0.astype(np.float64))
+        monkeypatch.setenv("UMX_NO_WIDEN", "1")
+        eng2 = Engine(0)
+        try:
+            eng2.load_weights(big); eng2.set_system(z)
+
+            def local2(c):
+                eng2.energy_forces_dev(c.shape[0], c.contiguous().data_ptr(), e_t.data_ptr(), f_t.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+                return e_t[: c.shape[0]], f_t[: c.shape[0]]
+
+            with pytest.raises(RuntimeError, match=r"non-finite energy for image\(s\) \[0, 1\]"):
+                ShardedImageEvaluator(local2, 2, 40, dev, engine=eng2)(pos)
+            assert eng2.take_range_error() is False             # the evaluator collected the flag before raising
+        finally:
+            eng2.close()
+    finally:
+        eng.close()
+        ref.close()
+
+
+def test_auto_precision_follows_the_system_size(weights, monkeypatch):
+    """UMX_PRECISION=auto (the default): fp16 forward planes up to UMX_AUTO_BF16_ATOMS atoms per image, three bf16 planes above --
+    decided at umx_set_system, which re-packs the weight planes; either way bitwise what the explicitly chosen mode computes."""
+    from pdb2reaction_amd.engine import Engine
+
+    monkeypatch.delenv("UMX_PRECISION", raising=False)
+    monkeypatch.setenv("UMX_AUTO_BF16_ATOMS", "60")
+    z_s, img_s, _ = synth.make_images(40, 2, seed=3)
+    z_l, img_l, _ = synth.make_images(90, 2, seed=4)
+    auto, f16, b16 = Engine(0), Engine(0, precision="split"), Engine(0, precision="split-bf16")
+    try:
+        for e in (auto, f16, b16):
+            e.load_weights(weights)
+        assert (auto.precision_mode(), f16.precision_mode(), b16.precision_mode()) == ("split-f16", "split-f16", "split-bf16")
+        for z, img, want, same in ((z_s, img_s, "split-f16", f16), (z_l, img_l, "split-bf16", b16), (z_s, img_s, "split-f16", f16),
+                                   (z_l, img_l, "split-bf16", b16)):
+            auto.set_system(z)
+            assert auto.precision_mode() == want
+            same.set_system(z)
+            ea, fa = auto.energy_forces(img)
+            er, fr = same.energy_forces(img)
+            assert np.array_equal(ea, er) and np.array_equal(fa, fr)
+        f16.set_system(z_l)                                      # an explicit mode is never changed behind the caller's back
+        assert f16.precision_mode() == "split-f16" and not auto.widened
+    finally:
+        for e in (auto, f16, b16):
+            e.close()
+
+
 def test_no_edges_and_isolated_atoms(engine, oracle):
     """Empty / ragged graphs: a lone atom, two atoms beyond the cutoff, one isolated atom next to a cluster."""
     z = np.array([8], dtype=np.int32)

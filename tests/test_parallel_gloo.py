@@ -130,3 +130,128 @@ def test_fd_hessian_columns_are_sharded_over_ranks():
     a = m @ m.T / 15 + np.eye(15)
     act = [i for i in range(15) if i // 3 != 1]
     assert np.allclose(h0[:, act], a[:, act], atol=2e-3) and np.all(h0[:, 3:6] == 0.0)
+
+
+# ---- range violations must be agreed on by all ranks ---------------------------------------------------------------
+class FakeEngine:
+    """The slice of ``engine.Engine`` the collective callers use: ``widened``, ``widen``, ``take_range_error``, ``precision_mode``."""
+
+    def __init__(self, can_widen=True):
+        self.widened, self.can_widen, self.widen_calls, self.flag_reads = False, can_widen, 0, 0
+
+    def widen(self, why=""):
+        self.widen_calls += 1
+        if self.widened or not self.can_widen:
+            return False
+        self.widened = True
+        return True
+
+    def take_range_error(self):
+        self.flag_reads += 1
+        return False
+
+    def precision_mode(self):
+        return "split-bf16" if self.widened else "split-f16"
+
+
+def _range_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        k, n = 5, 4
+        g = torch.Generator().manual_seed(1)
+        coords = torch.randn(k, n, 3, dtype=torch.float64, generator=g)
+        eng = FakeEngine()
+        calls = []
+
+        def local(c):                                         # rank 1's narrow arithmetic overflows on its first image
+            calls.append(eng.widened)
+            e, f = toy(c)
+            if rank == 1 and not eng.widened:
+                e = e.clone()
+                e[0] = float("nan")
+            return e, f
+
+        e, f = ShardedImageEvaluator(local, k, n, torch.device("cpu"), engine=eng)(coords)
+        stuck = FakeEngine(can_widen=False)
+
+        def local_bad(c):
+            e2, f2 = toy(c)
+            if rank == 0:
+                e2 = e2.clone()
+                e2[1] = float("inf")
+            return e2, f2
+
+        try:
+            ShardedImageEvaluator(local_bad, k, n, torch.device("cpu"), engine=stuck)(coords)
+            msg = "no error"
+        except RuntimeError as exc:
+            msg = str(exc)
+        out[rank] = (e.numpy(), f.numpy(), calls, eng.widened, eng.widen_calls, msg)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_evaluator_widens_on_every_rank_together():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_range_worker, args=(2, port, out), nprocs=2, join=True)
+    g = torch.Generator().manual_seed(1)
+    coords = torch.randn(5, 4, 3, dtype=torch.float64, generator=g)
+    e_ref, f_ref = toy(coords)
+    for r in range(2):
+        e, f, calls, widened, widen_calls, msg = out[r]
+        assert np.array_equal(e, e_ref.numpy()) and np.array_equal(f, f_ref.numpy())
+        assert calls == [False, True] and widened and widen_calls == 1          # BOTH ranks repeated their shard in the wide arithmetic
+        assert "non-finite energy for image(s) [1]" in msg                      # cannot widen: the same error on every rank
+
+
+def _hess_range_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pdb2reaction_amd.hessian import fd_hessian
+
+        n = 4
+        rng = np.random.default_rng(0)
+        m = rng.standard_normal((3 * n, 3 * n))
+        a = m @ m.T / (3 * n) + np.eye(3 * n)
+        eng = FakeEngine()
+        calls = []
+
+        def forces(c):                                        # the narrow arithmetic is measurably different; rank 1 leaves it on its 2nd batch
+            calls.append(eng.widened)
+            if rank == 1 and len(calls) == 2 and not eng.widened:
+                eng.widened = True                            # what Engine._widen does locally on UMX_ERR_RANGE
+            scale = 1.0 if eng.widened else 1.01
+            return (-(c.reshape(len(c), -1) @ a) * scale).reshape(c.shape).astype(np.float32)
+
+        x0 = rng.standard_normal((n, 3))
+        h = fd_hessian(forces, x0, [], device=torch.device("cpu"), double=True, partial=False, batch=4, shard=True, engine=eng)
+        wide = FakeEngine()
+        wide.widened = True
+        h_wide = fd_hessian(lambda c: (-(c.reshape(len(c), -1) @ a)).reshape(c.shape).astype(np.float32), x0, [], device=torch.device("cpu"),
+                            double=True, partial=False, batch=4, shard=True, engine=wide)
+        out[rank] = (h.numpy(), h_wide.numpy(), calls, eng.widened, wide.widen_calls)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_fd_hessian_never_mixes_two_arithmetics():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_hess_range_worker, args=(2, port, out), nprocs=2, join=True)
+    for r in range(2):
+        h, h_wide, calls, widened, wide_calls = out[r]
+        assert widened and np.array_equal(h, h_wide)                 # every column in the wide arithmetic, on every rank
+        assert calls[-3:] == [True, True, True] and len(calls) == 6  # 3 batches (6 DOF / 2 per batch) done twice
+        assert wide_calls == 0                                       # already wide everywhere: no repetition, no widen call
+    assert np.array_equal(out[0][0], out[1][0])

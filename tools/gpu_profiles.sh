@@ -20,7 +20,7 @@ echo "== 5. GEMM PMC counters at the real c3 shapes" &&
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS -d $O/g1 -o g -f csv -- $R/build/overlap_bench pmc 1 > $O/g1.log 2>&1 &&
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS GRBM_GUI_ACTIVE -d $O/g2 -o g -f csv -- $R/build/overlap_bench pmc 1 > $O/g2.log 2>&1 &&
 python3 tools/gemm_pmc_summary.py $O/g1 $O/g2 $P/r02_gemm_pmc_counters.json | tee $O/gemm_pmc_summary.log &&
-echo "== 1. bench line (default build; AFTER the PMC summary so that `traffic` is the one of this very build)" &&
+echo "== 1. bench line (default build; AFTER the PMC summary so that the traffic figure is the one of this very build)" &&
 cp $P/r02_pmc_hbm_traffic.json profiles/r02_pmc_hbm_traffic.json &&
 timeout -k 10 600 python3 bench.py --steps 3 --warmup 1 > $O/bench.log 2>&1 && grep '^{' $O/bench.log | tail -1 > $P/r02_bench_c3_n1_split.json &&
 echo "== 6. c5 (20 000 atoms x 8 images) kernel stats" &&

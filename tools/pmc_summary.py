@@ -31,7 +31,7 @@ def load(d, counter):
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 iters = int(sys.argv[3])
-kernels, total, fam_b, fam_n, f32_b = [], 0.0, 0.0, 0, 0.0
+kernels, total, fam_b, fam_n, f32_b, rad_b = [], 0.0, 0.0, 0, 0.0, 0.0
 for name, (n, fkb) in fetch.items():
     wn, wkb = write.get(name, (n, 0.0))
     b = (2.0 * fkb + wkb) * 1024.0
@@ -39,20 +39,23 @@ for name, (n, fkb) in fetch.items():
     if "umx_gemm_pl" in name or "umx_gemm_q_kernel" in name:
         fam_b += b
         fam_n += n
-    elif "umx_gemm_kernel" in name:
+    elif "umx_gemm_kernel" in name or "k_gemm_f64acc" in name:
         f32_b += b
+    elif "k_radial_head" in name or "k_radial_tail" in name:
+        rad_b += b
     kernels.append({"kernel": name, "launches_per_iteration": n / iters, "fetch_size_kb_raw_per_launch": fkb / n,
                     "write_size_kb_per_launch": wkb / max(wn, 1), "hbm_bytes_per_launch": b / n})
 kernels.sort(key=lambda k: -k["hbm_bytes_per_launch"] * k["launches_per_iteration"])
 out = {
     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline (two separate passes)",
     "correction": "gfx950: FETCH_SIZE reports half of wide coalesced reads -> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
-    "workload": "c3: 2000 atoms x 16 images, 1 GPU, split-bf16 build",
+    "workload": "c3: 2000 atoms x 16 images, 1 GPU, default precision mode (auto -> fp16 forward planes at this size)",
     "csrc_sha256": source_digest(),
     "hbm_bytes_per_iteration": total / iters,
     "dominant_family": {"kernel": "umx_gemm_q_kernel<*> + umx_gemm_pl16_kernel<*> + umx_gemm_pl_kernel<*>", "launches_per_iteration": fam_n / iters,
                         "hbm_bytes_per_launch_avg": fam_b / max(fam_n, 1), "hbm_bytes_per_iteration": fam_b / iters},
     "fp32_gemm_family_hbm_bytes_per_iteration": f32_b / iters,
+    "radial_hbm_bytes_per_iteration": rad_b / iters,
     "kernels": kernels[:24],
 }
 json.dump(out, open(sys.argv[4], "w"), indent=1)

@@ -49,7 +49,7 @@ __global__ void k_lnparts(const float* x, float* out, int rows) {
   v.x -= mu; v.y -= mu;
   const float var = umx::wave_sum_dpp(v.x * v.x + v.y * v.y) * (1.0f / 128);
   const float rstd = umx::r_rsqrt<0>(var + umx::LN_EPS);
-  const float var2 = umx::wave_sum(v.x * v.x + v.y * v.y) * (1.0f / 128);      // butterfly order instead of DPP order
+  const float var2 = umx::wave_sum_shfl(v.x * v.x + v.y * v.y) * (1.0f / 128);      // butterfly order instead of DPP order
   if (lane == 0) { out[row * 4 + 0] = mu; out[row * 4 + 1] = var; out[row * 4 + 2] = rstd; out[row * 4 + 3] = var2; }
 }
 

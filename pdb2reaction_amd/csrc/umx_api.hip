@@ -266,9 +266,14 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
   q.Cp = Cp; q.ldc = ldc; q.offC = offC; q.offCi = offCi; q.bias = bias; q.conj = conj; q.M = (int)M; q.N = N; q.K = K;
   // reverse pass (P=2: two ring stages of a 256x256 tile fit the LDS): the wide tile needs a third less L2->LDS fill per FLOP and
   // measured 9-11 % faster wherever N fills whole tiles (UMX_WIDE=0 disables)
-  const bool wide = eng->wide_tiles && P == 2 && N % (cplx ? 128 : 256) == 0;
-  const int bmr = cplx ? 128 : 256, bnc = wide ? (cplx ? 128 : 256) : (cplx ? 64 : 128);
-  const long nM = (M + bmr - 1) / bmr, nN = (N + bnc - 1) / bnc;
+  // Small systems (c1: 50 atoms x 8 images = 13 k edges = 51 row tiles): a launch whose wide grid does not even put one workgroup on
+  // every CU is bound by ONE tile's k-loop, so the narrow tiles (twice the workgroups, half the work each) finish sooner.
+  const int bmr = cplx ? 128 : 256;
+  const long nM = (M + bmr - 1) / bmr;
+  const bool fills = nM * (N / (cplx ? 128 : 256)) >= 256;          // wide grid >= one workgroup per CU
+  const bool wide = eng->wide_tiles && P == 2 && N % (cplx ? 128 : 256) == 0 && fills;
+  const int bnc = wide ? (cplx ? 128 : 256) : (cplx ? 64 : 128);
+  const long nN = (N + bnc - 1) / bnc;
   dim3 grid((unsigned)(((nM + 7) / 8) * 8 * nN)), block(512);
   ProfRec* pr = nullptr;
   if (eng->prof_on) {
@@ -286,7 +291,7 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
   const bool use16 = eng->mfma16 >= 2 || (eng->mfma16 == 1 && (cplx || K >= 512));
   if (P == 3 && eng->q3) {
     // forward operands in the quad-row layout: 256x256 tiles where N fills them, else 256x128 (umx_gemm_q.h)
-    const bool wq = eng->q3_wide && N % (cplx ? 128 : 256) == 0;
+    const bool wq = eng->q3_wide && N % (cplx ? 128 : 256) == 0 && fills;
     const int bnq = wq ? (cplx ? 128 : 256) : (cplx ? 64 : 128);
     const long nNq = (N + bnq - 1) / bnq;
     dim3 gq((unsigned)(((nM + 7) / 8) * 8 * nNq));

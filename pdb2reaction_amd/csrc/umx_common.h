@@ -51,11 +51,37 @@ __device__ __forceinline__ float silu_grad_f(float x) {
   for (long _it = (long)blockIdx.x * 4 + (threadIdx.x >> 6); _it < (count); _it += (long)gridDim.x * 4) \
     if (const long idx = __builtin_amdgcn_readfirstlane((int)_it); true)
 
-__device__ __forceinline__ float wave_sum(float v) {
+// Wave-wide sum on the VALU (DPP) instead of six dependent ds_bpermute round trips: the wave-per-item kernels run at few waves per
+// SIMD, so the ~600-cycle latency of a __shfl_xor butterfly is NOT hidden by other waves (measured in the fused radial kernels: the
+// LayerNorm passes took as long as the MFMAs).  quad_perm / row_ror adds leave every lane with the sum of its 16-lane row; the four
+// row sums are combined through v_readlane.  Round 3: every wave_sum of the engine is this form (the per-edge torque sums of the
+// reverse edge kernels were 18-24 ds_bpermute per edge).
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
+  return v + __builtin_bit_cast(float, moved);
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);       // quad_perm:[1,0,3,2]
+  v = dpp_add<0x4E>(v);       // quad_perm:[2,3,0,1]
+  v = dpp_add<0x124>(v);      // row_ror:4
+  v = dpp_add<0x128>(v);      // row_ror:8
+  return v;
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  const int r = __builtin_bit_cast(int, row16_sum(v));
+  return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 16))) +
+         (__builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 48)));
+}
+__device__ __forceinline__ float wave_sum_shfl(float v) {       // the butterfly form (UMX_WAVE_SUM_SHFL builds: A/B only)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+#ifdef UMX_WAVE_SUM_SHFL
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_shfl(v); }
+#else
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
+#endif
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

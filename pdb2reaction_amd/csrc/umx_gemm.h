@@ -249,20 +249,29 @@ __global__ __launch_bounds__(256, 2) void umx_gemm_kernel(const GemmP p) {
 // measurable, while it removes their share of the one-signed energy drift that grows with the number of atoms (a float32 dot
 // product of 128 terms errs by ~3e-8 relative; rounded once the error is 3e-8 of the RESULT only and unbiased).  Used when the
 // engine runs large systems ("energy error vs N").  64 x 64 tile, 16 x 16 threads, 4 x 4 outputs per thread.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
 template <int AMODE>
 __global__ __launch_bounds__(256) void k_gemm_f64acc(const GemmP p) {
-  __shared__ float As[32][65];
-  __shared__ float Bs[32][65];
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  // v_mfma_f64_16x16x4_f64 (same peak as the f64 VALU on this part, but a quarter of the LDS operand traffic per FLOP: a VALU version
+  // with 4 x 4 register tiles ran LDS-bound at 26 % of the f64 peak).  64 x 64 tile, 4 waves as 2 x 2, each wave 2 x 2 MFMA tiles;
+  // operands converted to double once, while staging.  LDS rows of 80 doubles: the four k-groups of a fragment read land 32 banks
+  // apart, so each 32-lane half of a ds_read_b64 touches 32 distinct bank pairs.
+  // Lane maps (cdna_hip_programming.md): A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]; D: col = l & 15, row = (l >> 4) + 4 reg.
+  constexpr int LD = 80;
+  __shared__ double As[32][LD];
+  __shared__ double Bs[32][LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lk = lane >> 4;
   const int nN = (p.N + 63) / 64;
   const int mt = blockIdx.x / nN, nt = blockIdx.x % nN;
   const long zoffA = (long)blockIdx.z * p.zA;
   const float* Bz = p.B + (p.zBl ? (blockIdx.z == 0 ? 0 : blockIdx.z < 4 ? 1 : 2) * p.zBl : 0);
-  double acc[4][4];
+  f64x4 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
   for (int k0 = 0; k0 < p.K; k0 += 32) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -270,38 +279,43 @@ __global__ __launch_bounds__(256) void k_gemm_f64acc(const GemmP p) {
       const long grow = (long)mt * 64 + r;
       float v = grow < p.M ? p.A[grow * p.lda + p.offA0 + zoffA + k0 + kk] : 0.f;
       if (AMODE == A_SILU) v = silu_f(v);
-      As[kk][r] = v;
+      As[kk][r] = (double)v;
       const int brow = nt * 64 + r;
-      Bs[kk][r] = brow < p.N ? Bz[(long)brow * p.ldb + k0 + kk] : 0.f;
+      Bs[kk][r] = brow < p.N ? (double)Bz[(long)brow * p.ldb + k0 + kk] : 0.0;
     }
     __syncthreads();
-#pragma unroll 8
-    for (int kk = 0; kk < 32; ++kk) {
-      double a[4], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { a[i] = (double)As[kk][ty * 4 + i]; b[i] = (double)Bs[kk][tx * 4 + i]; }
+    for (int ks = 0; ks < 8; ++ks) {
+      double a[2], b[2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int t = 0; t < 2; ++t) {
+        a[t] = As[ks * 4 + lk][wm * 32 + t * 16 + l15];
+        b[t] = Bs[ks * 4 + lk][wn * 32 + t * 16 + l15];
+      }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
   const long zoffC = (long)blockIdx.z * p.zC, zoffR = (long)blockIdx.z * p.zRes;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const long row = (long)mt * 64 + ty * 4 + i;
-    if (row >= p.M) continue;
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = nt * 64 + tx * 4 + j;
+    for (int j = 0; j < 2; ++j) {
+      const int col = nt * 64 + wn * 32 + j * 16 + l15;
       if (col >= p.N) continue;
-      double v = acc[i][j];
-      if (p.bias && (p.zBl == 0 || blockIdx.z == 0)) v += (double)p.bias[col];
-      if (p.resid) v += (double)p.resid[row * p.ldres + p.offRes + zoffR + col];
-      p.Cp[row * p.ldc + p.offC + zoffC + col] = (float)v;
+      const double bv = (p.bias && (p.zBl == 0 || blockIdx.z == 0)) ? (double)p.bias[col] : 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long row = (long)mt * 64 + wm * 32 + i * 16 + lk + 4 * r;
+        if (row >= p.M) continue;
+        double v = acc[i][j][r] + bv;
+        if (p.resid) v += (double)p.resid[row * p.ldres + p.offRes + zoffR + col];
+        p.Cp[row * p.ldc + p.offC + zoffC + col] = (float)v;
+      }
     }
-  }
 }
 
 }  // namespace umx

@@ -19,28 +19,13 @@
 
 namespace umx {
 
+#ifndef UMX_ABL
+#define UMX_ABL 0        // dev ablation mask of k_radial_head (tools/gpu_ab_lib.sh): 1 no MFMA, 2 no LayerNorm/SiLU, 4 no element tables, 8 no gaussian exp, 16 no global stores
+#endif
 constexpr int R_LD = 132;      // padded LDS row of a 128-wide activation tile (floats)
 constexpr int R_LDG = 68;      // padded LDS row of the 64-wide gaussian tile
 
-// Wave-wide sum on the VALU (DPP) instead of six dependent ds_bpermute round trips: these kernels run at two waves per SIMD, so the
-// ~600-cycle latency of a __shfl_xor butterfly is NOT hidden by other waves (measured: the LayerNorm passes took as long as the MFMAs).
-// quad_perm / row_ror adds leave every lane with the sum of its 16-lane row; the four row sums are combined through v_readlane.
-template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
-  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
-  return v + __builtin_bit_cast(float, moved);
-}
-__device__ __forceinline__ float row16_sum(float v) {
-  v = dpp_add<0xB1>(v);       // quad_perm:[1,0,3,2]
-  v = dpp_add<0x4E>(v);       // quad_perm:[2,3,0,1]
-  v = dpp_add<0x124>(v);      // row_ror:4
-  v = dpp_add<0x128>(v);      // row_ror:8
-  return v;
-}
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-  const int r = __builtin_bit_cast(int, row16_sum(v));
-  return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 16))) +
-         (__builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 48)));
-}
+// (dpp_add / row16_sum / wave_sum_dpp: umx_common.h)
 
 // Transcendentals (template parameter FAST = UMX_RADIAL_FAST): these kernels are VALU-bound on exactly these functions (two
 // SiLU + one rsqrt per element pair and LayerNorm row, 64 gaussians per edge).
@@ -74,6 +59,11 @@ template <int FAST> __device__ __forceinline__ float r_silu_grad(float x) {
   const float sg = r_sigmoid<FAST>(x);
   return sg * (1.0f + x * (1.0f - sg));
 }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier: it also waits for every
+// GLOBAL store in flight (h1pre / h2pre / the fc3 operand rows), i.e. it exposes a full HBM write round trip at each of the seven
+// barriers of a tile.  Every barrier of these kernels protects LDS buffers only (round 3; ablation: the stores cost 4.4 of 12.8 ms).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // LayerNorm(128) + SiLU of one row held as 2 values per lane (the arithmetic of k_ln_silu_fwd)
 template <int FAST>
@@ -149,13 +139,13 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
   const long ntiles = (ne + RT - 1) / RT;
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long e0 = tile * RT;
-    __syncthreads();                                 // the previous tile's buffers are free
+    lds_barrier();                                 // the previous tile's buffers are free
     if (tid < RT) {
       const long e = e0 + tid < ne ? e0 + tid : ne - 1;
       dbuf[tid] = evec[e * 4 + 3];
       zbuf[tid] = ez[e];
     }
-    __syncthreads();
+    lds_barrier();
     {   // gaussian basis of the tile -> bufA as [RT][R_LDG]: 256 / RT threads per row, RT / 4 columns each
       constexpr int TPR = 256 / RT;
       const int row = tid / TPR, c0 = (tid % TPR) * (RT / 4);
@@ -166,59 +156,72 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
         // i.e. up to 4e-6 relative on a gaussian, the SAME for every edge -- the largest systematic term of the energy error ~ N
         const double dd = (double)d;
         float4 v; double t;
+        if (UMX_ABL & 8) { v.x = v.y = v.z = v.w = d; }
+        else {
         t = dd - gmu[c0 + 4 * q + 0]; v.x = r_exp<FAST>((float)(gcoef * t * t));
         t = dd - gmu[c0 + 4 * q + 1]; v.y = r_exp<FAST>((float)(gcoef * t * t));
         t = dd - gmu[c0 + 4 * q + 2]; v.z = r_exp<FAST>((float)(gcoef * t * t));
         t = dd - gmu[c0 + 4 * q + 3]; v.w = r_exp<FAST>((float)(gcoef * t * t));
+        }
         *reinterpret_cast<float4*>(bufA + row * R_LDG + c0 + 4 * q) = v;
       }
     }
-    __syncthreads();
+    lds_barrier();
     f32x16 acc[TR];
 #pragma unroll
     for (int i = 0; i < TR; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    rad_mma<NG / 8, R_LDG, TR>(bufA, W1, acc, l31, h);
+    if (!(UMX_ABL & 1)) rad_mma<NG / 8, R_LDG, TR>(bufA, W1, acc, l31, h);
     // epilogue 1: the raw fc1 tile to bufB; the row pass below adds the element tables, writes h1pre (whole 512-B rows) and normalises
 #pragma unroll
     for (int i = 0; i < TR; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) bufB[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * R_LD + col] = acc[i][r];
-    __syncthreads();
-#pragma unroll 2
-    for (int rr = 0; rr < RT / 4; ++rr) {            // wave w owns rows 16w .. 16w+15: + tables, h1pre out, LN + SiLU in place
+    lds_barrier();
+    // Pass 1a: + element tables, back into LDS -- global LOADS only.  gfx9 counts loads and stores on one in-order counter (vmcnt), so a
+    // table load issued behind an h1pre store cannot be waited for without waiting for that store as well: with the stores in this
+    // loop every pair of rows exposed a full HBM write round trip.  Pass 1b below has the stores and no loads.
+#pragma unroll 4
+    for (int rr = 0; rr < RT / 4; ++rr) {            // wave w owns rows 16w .. 16w+15
       const int row = wave * (RT / 4) + rr;
       const int zz = zbuf[row];
       float* p = bufB + row * R_LD + 2 * lane;
       float2 v = *reinterpret_cast<const float2*>(p);
       // element tables in DOUBLE, the sum rounded once (round 3): a float32 table entry is off by a fixed 3e-8 relative, the same for every
       // edge of that element pair -- a pattern the LayerNorm does not remove, measured as a -2e-8 gain on the radial output
-      const double2 a = *reinterpret_cast<const double2*>(ts + (zz & 0xffff) * RH + 2 * lane);
-      const double2 b = *reinterpret_cast<const double2*>(tt + (zz >> 16) * RH + 2 * lane);
+      const double2 a = (UMX_ABL & 4) ? double2{0.0, 0.0} : *reinterpret_cast<const double2*>(ts + (zz & 0xffff) * RH + 2 * lane);
+      const double2 b = (UMX_ABL & 4) ? double2{0.0, 0.0} : *reinterpret_cast<const double2*>(tt + (zz >> 16) * RH + 2 * lane);
       v.x = (float)((double)v.x + (a.x + b.x)); v.y = (float)((double)v.y + (a.y + b.y));
-      if (e0 + row < ne) *reinterpret_cast<float2*>(h1pre + (e0 + row) * RH + 2 * lane) = v;
-      *reinterpret_cast<float2*>(p) = ln_silu_row<FAST>(v, l1w, l1b);
+      *reinterpret_cast<float2*>(p) = v;
     }
-    __syncthreads();
+#pragma unroll 2
+    for (int rr = 0; rr < RT / 4; ++rr) {            // pass 1b (same rows, same wave: no barrier): h1pre out (whole 512-B rows), LN + SiLU in place
+      const int row = wave * (RT / 4) + rr;
+      float* p = bufB + row * R_LD + 2 * lane;
+      const float2 v = *reinterpret_cast<const float2*>(p);
+      if (!(UMX_ABL & 16) && e0 + row < ne) *reinterpret_cast<float2*>(h1pre + (e0 + row) * RH + 2 * lane) = v;
+      *reinterpret_cast<float2*>(p) = (UMX_ABL & 2) ? v : ln_silu_row<FAST>(v, l1w, l1b);
+    }
+    lds_barrier();
 #pragma unroll
     for (int i = 0; i < TR; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    rad_mma<RH / 8, R_LD, TR>(bufB, W2, acc, l31, h);
+    if (!(UMX_ABL & 1)) rad_mma<RH / 8, R_LD, TR>(bufB, W2, acc, l31, h);
     // epilogue 2: fc2 tile + bias to bufA (the gaussian tile is dead: every wave passed the barriers behind fc1)
 #pragma unroll
     for (int i = 0; i < TR; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) bufA[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * R_LD + col] = acc[i][r] + bias2;
-    __syncthreads();
+    lds_barrier();
 #pragma unroll 2
     for (int rr = 0; rr < RT / 4; ++rr) {            // h2pre out, LN + SiLU -> the fc3 operand
       const int row = wave * (RT / 4) + rr;
       const long e = e0 + row;
       const float2 v = *reinterpret_cast<const float2*>(bufA + row * R_LD + 2 * lane);
-      const float2 o = ln_silu_row<FAST>(v, l2w, l2b);
-      if (e < ne) {
+      const float2 o = (UMX_ABL & 2) ? v : ln_silu_row<FAST>(v, l2w, l2b);
+      if (!(UMX_ABL & 16) && e < ne) {
         *reinterpret_cast<float2*>(h2pre + e * RH + 2 * lane) = v;
         if (OUTQ3) q_store2<(OUTQ3 == 2)>(reinterpret_cast<unsigned short*>(out), e, RH, 2 * lane, o.x, o.y);
         else *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + e * RH + 2 * lane) = o;
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_tail(const floa
   const long ntiles = (ne + RT - 1) / RT;
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long e0 = tile * RT;
-    __syncthreads();
+    lds_barrier();
     if (tid < RT) dbuf[tid] = evec[(e0 + tid < ne ? e0 + tid : ne - 1) * 4 + 3];
 #pragma unroll 4
     for (int rr = 0; rr < RT / 4; ++rr) {            // LN2 + SiLU backward: g_h2 -> bufA
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_tail(const floa
       const float2 x = *reinterpret_cast<const float2*>(h2pre + e * RH + 2 * lane);
       *reinterpret_cast<float2*>(bufA + row * R_LD + 2 * lane) = ln_silu_row_bwd<FAST>(go, x, l2w, l2b);
     }
-    __syncthreads();
+    lds_barrier();
     f32x16 acc[TR];
 #pragma unroll
     for (int i = 0; i < TR; ++i)
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_tail(const floa
     for (int i = 0; i < TR; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) bufB[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * R_LD + col] = acc[i][r];
-    __syncthreads();
+    lds_barrier();
 #pragma unroll 4
     for (int rr = 0; rr < RT / 4; ++rr) {            // LN1 + SiLU backward: g_h1 -> bufA (its fc2^T reads finished at the barrier above)
       const int row = wave * (RT / 4) + rr;
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_tail(const floa
       const float2 x = *reinterpret_cast<const float2*>(h1pre + e * RH + 2 * lane);
       *reinterpret_cast<float2*>(bufA + row * R_LD + 2 * lane) = ln_silu_row_bwd<FAST>(go, x, l1w, l1b);
     }
-    __syncthreads();
+    lds_barrier();
     if (gi < TR) {   // g_gauss = g_h1 . W1g (128 -> 64): one 32 x 32 tile per wave (wave-uniform), then dE/dd = sum_k g_gauss[k] d/dd exp(gcoef (d - mu_k)^2)
       f32x16 a1;
 #pragma unroll
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_tail(const floa
         if (lane == 0) { part[gj][row] = s0; part[gj][row + 4] = s1; }      // lane 0 sees h = 0: `row` is the first half's row, +4 the second's
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < RT && e0 + tid < ne) dedd[e0 + tid] += part[0][tid] + part[1][tid];
   }
 }

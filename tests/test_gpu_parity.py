@@ -266,6 +266,29 @@ def test_auto_precision_follows_the_system_size(weights, monkeypatch):
             e.close()
 
 
+def test_single_image_beyond_the_workspace_names_the_way_out(weights):
+    """One image whose edge pipeline does not fit the workspace budget cannot be evaluated by one engine (every per-edge activation
+    of the four layers is kept for the reverse pass: ~120 KB per directed edge, i.e. ~25 000 atoms on a 288 GB part).  The status is
+    UMX_ERR_CAPACITY and the text says what to do: the graph-parallel mode (uma_pysis(workers=<ranks>) under torch.distributed),
+    which partitions the edges of the ONE image over several GPUs -- the reference's workers > 1 (uma_pysis.py:220-242)."""
+    from pdb2reaction_amd.engine import Engine, UmxError
+
+    z, imgs, _ = synth.make_images(300, 2, seed=4)
+    eng = Engine(0)
+    try:
+        eng.load_weights(weights)
+        eng.set_system(z)
+        eng.set_workspace_limit(200 << 20)                      # 200 MiB: one 300-atom image needs ~2 GiB
+        with pytest.raises(UmxError, match=r"one image \(300 atoms, \d+ directed edges\) needs \d+ MiB.*graph-parallel.*workers=") as ei:
+            eng.energy_forces(imgs)
+        assert ei.value.status == -4
+        eng.set_workspace_limit(0)                              # back to the automatic budget: the engine is usable again
+        e, f = eng.energy_forces(imgs)
+        assert np.isfinite(e).all() and np.isfinite(f).all()
+    finally:
+        eng.close()
+
+
 def test_no_edges_and_isolated_atoms(engine, oracle):
     """Empty / ragged graphs: a lone atom, two atoms beyond the cutoff, one isolated atom next to a cluster."""
     z = np.array([8], dtype=np.int32)

@@ -47,6 +47,7 @@ from pdb2reaction_amd.uma_pysis import EV2AU, F_EVAA_2_AU  # noqa: E402
 FLOP_PER_EDGE = 30.98e6          # algorithmic E+F work per directed edge
 PEAK_FP32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense f32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (not the 2:1-sparse headline)
+PEAK_FP64_MFMA_TFLOPS = 78.6     # AMD MI355X datasheet: f64 matrix = f64 vector peak (the micro-arch guide has no f64 row)
 
 
 PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_hbm_traffic.json")
@@ -243,7 +244,7 @@ def main():
             "dtype": ("f16-split" if mode in ("split", "split-f16") else "bf16-split") if split else "f32",
             "dtype_detail": ((("forward GEMMs: 2 fp16 activation planes x 3 exact fp16 weight planes, 4 MFMA products (fp32-level); " if mode in ("split", "split-f16")
                                else "forward GEMMs: 3 x 3 bf16 planes, 6 MFMA products (24-bit); ")
-                              + "reverse GEMMs: 2 x 2 bf16 planes, 3 products (16-bit); fp32 accumulate; everything else fp32") if split
+                              + "reverse GEMMs: 2 x 2 bf16 planes, 3 products (16-bit); fp32 accumulate; node-level linears float64-accumulated; everything else fp32") if split
                              else "every GEMM on v_mfma_f32_32x32x2_f32"),
             "precision_mode": mode, "precision_requested": mode_req,
             "data": "synthetic",
@@ -266,10 +267,10 @@ def main():
                          "executed_flops_per_launch": dom["mfma_flops"] / max(dom["launches"], 1),
                          "ms_per_step": dom["ms"] / args.steps, "share_of_step": dom["ms"] / (ms * args.steps),
                          "vs_fp32_mfma_peak": alg / PEAK_FP32_MFMA_TFLOPS,
-                         "other_gemm_family": {"kernel": "umx_gemm_kernel<*> (fp32 MFMA)" if split else None,
+                         "other_gemm_family": {"kernel": "k_gemm_f64acc<*> (node-level linears, float64-accumulated on v_mfma_f64_16x16x4_f64; UMX_NODE_F64=0: umx_gemm_kernel<*>, fp32 MFMA)" if split else None,
                                                "ms_per_step": f32["ms"] / args.steps if split else 0.0,
                                                "achieved": f32["alg_flops"] / max(f32["ms"], 1e-9) / 1e9 if split else 0.0,
-                                               "peak": PEAK_FP32_MFMA_TFLOPS}},
+                                               "peak": PEAK_FP64_MFMA_TFLOPS if os.environ.get("UMX_NODE_F64", "1") != "0" else PEAK_FP32_MFMA_TFLOPS}},
         }
         # second regime: the HBM-bound gather / rotate / gate / segmented-reduce kernels.  Everything outside the two GEMM
         # families is timed as the remainder of the step; the fused radial-MLP kernels (VALU / fp32-MFMA bound, not HBM bound) are timed

@@ -62,10 +62,11 @@ const char* umx_last_error(const umx_engine* eng);
  * The environment variable UMX_PRECISION is read here and fixes the arithmetic of the large SO(2)/radial GEMMs:
  *   auto (default, ABI v7): the engine's choice for the bound system, decided (and the weight planes re-packed if need be) at
  *                umx_set_system.  Today that is split-f16 at every size: measured against the float64 oracle both split forms carry
- *                the same systematic energy error of <= 1e-8 eV per atom (20 000 atoms: -1.3e-4 eV split-f16, -2.0e-4 eV
+ *                the same systematic energy error of <= 1e-8 eV per atom (20 000 atoms: -1.5e-4 eV split-f16, -1.9e-4 eV
  *                split-bf16), so the wider form buys range, not accuracy.  UMX_AUTO_BF16_ATOMS=<n> makes "auto" take split-bf16
- *                above n atoms per image.  ENERGY ERROR BOUND of every mode: max(1e-4 eV, 1e-8 eV x atoms) against float64
- *                arithmetic on the same weights (a plain float32 evaluation in the reference's style: 1.2e-7 eV per atom).
+ *                above n atoms per image.  ENERGY ERROR BOUND of the split modes: max(1e-4 eV, 1e-8 eV x atoms) against float64
+ *                arithmetic on the same weights (fp32 mode: 3e-8 eV per atom; a plain float32 evaluation in the reference's
+ *                style: 1.2e-7 eV per atom).
  *   split (= split-f16): forward operands as two fp16 planes (activations) x three fp16 planes (weights, exact),
  *                4 MFMA products; reverse pass two bf16 planes, 3 products.  fp32-level accuracy; operand range +-4094.
  *   split-bf16 : forward operands as three bf16 planes, 6 products (beyond fp32 accuracy, no range limit, ~12 % slower).

@@ -27,6 +27,17 @@ __global__ void k_eval(const float* x, double* out, int n, int which) {
     case 11: { const float a = 0.77f + 0.06f * (fabsf(v) - floorf(fabsf(v))); f = 1.0f / a; r = 1.0 / (double)a; break; }
     case 12: { const float a = 0.6f + 0.1f * (fabsf(v) - floorf(fabsf(v))); f = (float)(1.0 / sqrt((double)a)); r = 1.0 / sqrt((double)a); break; }
     case 13: { const float a = 0.6f + 0.1f * (fabsf(v) - floorf(fabsf(v))); f = umx::r_rsqrt<0>(a + umx::LN_EPS); r = 1.0 / sqrt((double)a + (double)umx::LN_EPS); break; }
+    case 14: f = umx::r_exp<2>(-v); r = exp(-d); break;
+    case 15: f = umx::r_sigmoid<2>(v); r = 1.0 / (1.0 + exp(-d)); break;
+    case 16: f = umx::r_silu<2>(v); r = d / (1.0 + exp(-d)); break;
+    case 17: f = umx::r_silu<0>(v); r = d / (1.0 + exp(-d)); break;
+    case 18: { const float a = fabsf(v) + 1e-3f; f = umx::r_rcp<2>(a); r = 1.0 / (double)a; break; }
+    case 19: f = umx::r_silu_grad<2>(v); r = 0; { const double sd = 1.0 / (1.0 + exp(-d)); r = sd * (1.0 + d * (1.0 - sd)); } break;
+    case 20: f = umx::r_silu_grad<0>(v); r = 0; { const double sd = 1.0 / (1.0 + exp(-d)); r = sd * (1.0 + d * (1.0 - sd)); } break;
+    case 21: { const float dd = 1.0f + umx::r_exp<2>(-v); float y = __frcp_rn(dd); y = fmaf(fmaf(-dd, y, 1.0f), y, y); y = fmaf(fmaf(-dd, y, 1.0f), y, y); f = v * y; r = d / (1.0 + exp(-d)); break; }
+    case 22: { const float dd = 1.0f + umx::r_exp<2>(-v); f = v / dd; r = d / (1.0 + exp(-d)); break; }
+    case 23: { const float dd = 1.0f + umx::r_exp<2>(-v); float y = __frcp_rn(dd); const float q = v * y; f = fmaf(fmaf(-dd, q, v), y, q); r = d / (1.0 + exp(-d)); break; }
+    case 24: { const float a = 0.6f + 0.1f * (fabsf(v) - floorf(fabsf(v))); f = umx::scale_rstd(1.2345678f, umx::rstd_eps(a, umx::LN_EPS)); r = 1.2345678f / sqrt((double)a + (double)umx::LN_EPS); break; }
     case 8: { const float s = 1.0f / (1.0f + expf(-v)); f = s * (1.0f + v * (1.0f - s)); const double sd = 1.0 / (1.0 + exp(-d)); r = sd * (1.0 + d * (1.0 - sd)); break; }
   }
   out[i] = ((double)f - r) / fabs(r);
@@ -114,8 +125,8 @@ int main() {
   hipMalloc(&dx, n * sizeof(float)); hipMalloc(&dout, n * sizeof(double));
   hipMemcpy(dx, h.data(), n * sizeof(float), hipMemcpyHostToDevice);
   std::vector<double> o(n);
-  const char* names[] = {"expf(-x)", "sigmoid = 1/(1+expf(-x))", "silu = x/(1+expf(-x))", "silu = x*(1/(1+expf(-x)))", "1/sqrtf(a)", "1/a", "sqrtf(a)", "__expf(-x)", "silu_grad", "1/sqrtf(a), a in [0.6,0.7]", "sqrtf(a), a in [0.6,0.7]", "1/a, a in [0.77,0.83]", "(float)(1/sqrt((double)a))", "r_rsqrt<0>(a + LN_EPS)"};
-  for (int w = 0; w < 14; ++w) {
+  const char* names[] = {"expf(-x)", "sigmoid = 1/(1+expf(-x))", "silu = x/(1+expf(-x))", "silu = x*(1/(1+expf(-x)))", "1/sqrtf(a)", "1/a", "sqrtf(a)", "__expf(-x)", "silu_grad", "1/sqrtf(a), a in [0.6,0.7]", "sqrtf(a), a in [0.6,0.7]", "1/a, a in [0.77,0.83]", "(float)(1/sqrt((double)a))", "r_rsqrt<0>(a + LN_EPS)", "r_exp<2>(-x)", "r_sigmoid<2>", "r_silu<2>", "r_silu<0>", "r_rcp<2>", "r_silu_grad<2>", "r_silu_grad<0>", "silu: exp<2>, rcp 2 Newton", "silu: exp<2>, true division", "silu: exp<2>, q = x*rcp + 1 residual step", "scale_rstd(c, rstd_eps(a, LN_EPS)), a in [0.6,0.7]"};
+  for (int w = 0; w < 25; ++w) {
     k_eval<<<(n + 255) / 256, 256>>>(dx, dout, n, w);
     hipMemcpy(o.data(), dout, n * sizeof(double), hipMemcpyDeviceToHost);
     double m = 0, a = 0, mx = 0;

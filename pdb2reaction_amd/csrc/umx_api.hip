@@ -68,7 +68,7 @@ struct umx_engine {
                                    // the next GEMM, which slows down by as much as was hidden; stream priorities change nothing on this pool.  Off by default.
   hipEvent_t ev_sf = nullptr, ev_shead = nullptr, ev_stail = nullptr;
   int radial_tr = 2;               // UMX_RADIAL_TR: 32-row MFMA tiles per workgroup tile of the fused radial kernels (1: 3 workgroups per CU, 2: 2)
-  int radial_fast = 0;             // UMX_RADIAL_FAST: transcendentals inside the fused radial kernels: 0 libm, 1 raw hardware, 2 refined hardware (umx_radial.h)
+  int radial_fast = 0;             // UMX_RADIAL_FAST: transcendentals inside the fused radial kernels: 0 libm (default), 1 raw hardware, 2 refined hardware (umx_radial.h)
   bool fused_radial = true;        // UMX_FUSED_RADIAL=0: the radial MLP's small layers as separate GEMM / LayerNorm launches (umx_radial.h fuses them)
   int q3_stages = 2;               // UMX_Q3S: LDS ring depth of the forward Q3 GEMMs (2 or 3)
   bool q3_wide = true;             // UMX_Q3WIDE=0 (dev): 256x128 tiles for every forward GEMM

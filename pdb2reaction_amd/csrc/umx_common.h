@@ -29,12 +29,23 @@ constexpr float SQRT3 = 1.7320508075688772f;
 // kernels (and in GEMM prologues with ample VALU slack), so the extra instructions are free.
 __device__ __forceinline__ float exp_f(float x) { return expf(x); }
 __device__ __forceinline__ float rsqrt_f(float x) { return 1.0f / sqrtf(x); }
-// 1 / sqrt(x + eps) for the normalisations, in DOUBLE and rounded once (round 3).  In float32 `x + 1e-5f` is a grid value plus a
-// constant: within a binade the sum always lands on the same fraction of an ulp, so its rounding error is the SAME for every row --
-// measured +2.1e-8 relative on var + eps at var ~ 0.65, i.e. a -1.1e-8 gain on every LayerNorm output of the radial MLP (a -2e-8
-// gain on its output for every edge) and likewise on every RMS norm: an energy error that grows with the number of atoms.  One
-// double sqrt + divide per ROW (128 / 1152 elements): free.
-__device__ __forceinline__ float rstd_eps(float x, double eps) { return (float)(1.0 / sqrt((double)x + eps)); }
+// 1 / sqrt(x + eps) for the normalisations (round 3).  In float32 `x + 1e-5f` is a grid value plus a constant: within a binade the
+// sum always lands on the same fraction of an ulp, so its rounding error is the SAME for every row -- measured +2.1e-8 relative on
+// var + eps at var ~ 0.65, i.e. a -1.1e-8 gain on every LayerNorm output of the radial MLP (a -2e-8 gain on its output for every
+// edge) and likewise on every RMS norm: an energy error that grows with the number of atoms.  Cure: carry the rounding error of the
+// sum along (Fast2Sum: dl = eps - ((x + eps) - x) is exact for x >= eps): 1/sqrt(s + dl) = y (1 + c) with c = -dl y^2 / 2 ~ 1e-8.
+// The factor cannot be folded into y -- y sits on the float grid and y (1 + c) rounds straight back to it (the same trap) -- so it
+// travels with y and is applied where the row is scaled, inside ONE fma: v y (1 + c) = fma(v, y, (v y) c), rounded once.  Two
+// extra instructions per element.  (A double sqrt + divide per row did the same but cost the fused radial kernels 2.7 ms per c3
+// iteration: every lane of the wave computes it.)  func_bias.hip: LayerNorm + SiLU gain -1.22e-8 -> see DESIGN.md section 5.
+struct Rstd { float y, c; };
+__device__ __forceinline__ Rstd rstd_eps(float x, float eps) {
+  const float s = __fadd_rn(x, eps);                       // (explicitly rounded ops: must not be re-associated into dl = 0)
+  const float dl = __fsub_rn(eps, __fsub_rn(s, x));
+  const float y = 1.0f / sqrtf(s);
+  return Rstd{y, -0.5f * dl * y * y};
+}
+__device__ __forceinline__ float scale_rstd(float v, Rstd r) { return fmaf(v, r.y, (v * r.y) * r.c); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float silu_grad_f(float x) {

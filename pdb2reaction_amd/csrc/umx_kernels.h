@@ -260,12 +260,12 @@ __global__ __launch_bounds__(256) void k_norm_fwd(const float* __restrict__ x, c
   for (int r = 4; r < 9; ++r) q2 += v[r].x * v[r].x + v[r].y * v[r].y;
   float q = q0 / 3.0f + q1 / 9.0f + q2 / 15.0f;
   q = wave_sum(q) * (1.0f / C);
-  const float s = rstd_eps(q, 1e-5);
+  const Rstd s = rstd_eps(q, NORM_EPS);
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
     const int l = (r == 0) ? 0 : (r < 4 ? 1 : 2);
     const float2 w = *reinterpret_cast<const float2*>(aw + l * C + c0);
-    float2 o = make_float2(v[r].x * s * w.x, v[r].y * s * w.y);
+    float2 o = make_float2(scale_rstd(v[r].x, s) * w.x, scale_rstd(v[r].y, s) * w.y);
     if (r == 0) {
       const float2 b = *reinterpret_cast<const float2*>(ab + c0);
       if (sysemb) { o.x = (float)((double)o.x + ((double)b.x + sysemb[c0])); o.y = (float)((double)o.y + ((double)b.y + sysemb[c0 + 1])); }
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd(const float* __restrict__ gy, 
   float q = ql[0] / 3.0f + ql[1] / 9.0f + ql[2] / 15.0f;           // the forward's expression (k_norm_fwd)
   q = wave_sum(q) * (1.0f / C);
   dot = wave_sum(dot);
-  const float s = rstd_eps(q, 1e-5);
+  const float s = rstd_eps(q, NORM_EPS).y;                 // (reverse pass: feeds forces only)
   const float k = s * s * s * dot * (1.0f / C);
   float2 o[9];
 #pragma unroll
@@ -332,10 +332,10 @@ __global__ __launch_bounds__(256) void k_ln_silu_fwd(const float* __restrict__ x
   const float mu = wave_sum(v.x + v.y) * (1.0f / RH);
   v.x -= mu; v.y -= mu;
   const float var = wave_sum(v.x * v.x + v.y * v.y) * (1.0f / RH);
-  const float rstd = rstd_eps(var, 1e-5);
+  const Rstd rstd = rstd_eps(var, LN_EPS);
   const float2 ww = *reinterpret_cast<const float2*>(w + c0), bb = *reinterpret_cast<const float2*>(b + c0);
   *reinterpret_cast<float2*>(y + row * RH + c0) =
-      make_float2(silu_f(v.x * rstd * ww.x + bb.x), silu_f(v.y * rstd * ww.y + bb.y));
+      make_float2(silu_f(scale_rstd(v.x, rstd) * ww.x + bb.x), silu_f(scale_rstd(v.y, rstd) * ww.y + bb.y));
   }
 }
 
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void k_ln_silu_bwd(const float* __restrict__ g
   const float mu = wave_sum(v.x + v.y) * (1.0f / RH);
   v.x -= mu; v.y -= mu;
   const float var = wave_sum(v.x * v.x + v.y * v.y) * (1.0f / RH);
-  const float rstd = rstd_eps(var, 1e-5);
+  const float rstd = rstd_eps(var, LN_EPS).y;              // (reverse pass: feeds forces only)
   const float2 ww = *reinterpret_cast<const float2*>(w + c0), bb = *reinterpret_cast<const float2*>(b + c0);
   const float xh0 = v.x * rstd, xh1 = v.y * rstd;
   const float gw0 = go.x * silu_grad_f(xh0 * ww.x + bb.x) * ww.x;

@@ -117,9 +117,9 @@ __global__ __launch_bounds__(256) void k_ln_silu_fwd_pl(const float* __restrict_
   const float mu = wave_sum(v.x + v.y) * (1.0f / RH);
   v.x -= mu; v.y -= mu;
   const float var = wave_sum(v.x * v.x + v.y * v.y) * (1.0f / RH);
-  const float rstd = rstd_eps(var, 1e-5);
+  const Rstd rstd = rstd_eps(var, LN_EPS);
   const float2 ww = *reinterpret_cast<const float2*>(w + c0), bb = *reinterpret_cast<const float2*>(b + c0);
-  const float o0 = silu_f(v.x * rstd * ww.x + bb.x), o1 = silu_f(v.y * rstd * ww.y + bb.y);
+  const float o0 = silu_f(scale_rstd(v.x, rstd) * ww.x + bb.x), o1 = silu_f(scale_rstd(v.y, rstd) * ww.y + bb.y);
   if (Q) q_store2<(P == 2)>(y, row, RH, c0, o0, o1);            // Q with P = 2: the fp16 two-plane format
   else pl_store2<P>(y + row * (RH * P), c0, o0, o1);
   }

@@ -28,11 +28,15 @@ constexpr int R_LDG = 68;      // padded LDS row of the 64-wide gaussian tile
 // (dpp_add / row16_sum / wave_sum_dpp: umx_common.h)
 
 // Transcendentals (template parameter FAST = UMX_RADIAL_FAST): these kernels are VALU-bound on exactly these functions (two
-// SiLU + one rsqrt per element pair and LayerNorm row, 64 gaussians per edge).
-// MODE 0: libm-accurate (umx_common.h policy).  MODE 1: hardware approximations as they are.  MODE 2: hardware instructions with
-// the argument reduced / the result refined so that each function is accurate to about 1 ulp without the libm call sequences:
-// exp by Cody-Waite reduction to |r| <= ln2/2 before v_exp_f32 (the plain v_exp_f32(x * log2e) form loses absolute accuracy in the
-// product for large |x|), reciprocal and reciprocal square root by one Newton step on v_rcp_f32 / v_rsq_f32.
+// SiLU per element pair, 64 gaussians per edge).
+// MODE 0: the libm calls (umx_common.h policy).  MODE 1: hardware approximations as they are (biased: a one-signed energy shift).
+// MODE 2: hardware instructions with the argument reduced / the result refined so that each function is accurate to about 1 ulp
+// without the libm call sequences: exp by Cody-Waite reduction to |r| <= ln2/2 before v_exp_f32 (the plain v_exp_f32(x * log2e)
+// form loses absolute accuracy in the product for large |x|), reciprocal by one Newton step on v_rcp_f32.
+// Measured with csrc/func_bias.hip on 4 M arguments (mean SIGNED relative error / mean |error|): exp -2.349e-9 / 2.22e-8 against
+// libm's -2.354e-9 / 2.21e-8; sigmoid +1.6e-9 / 3.21e-8 against +1.2e-9 / 3.20e-8; SiLU -1.3e-9 / 3.82e-8 against -5.6e-10 / 3.81e-8;
+// reciprocal +4e-12 in both: as accurate per call, but the SiLU bias is 2.3x libm's and shows at c5 (-1.74e-4 against -1.28e-4 eV),
+// for 0.8 ms per c3 iteration -- mode 0 stays the default.
 template <int FAST> __device__ __forceinline__ float r_exp(float x) {
   if (FAST == 0) return expf(x);
   if (FAST == 1) return __expf(x);
@@ -71,8 +75,8 @@ __device__ __forceinline__ float2 ln_silu_row(float2 v, float2 ww, float2 bb) {
   const float mu = wave_sum_dpp(v.x + v.y) * (1.0f / RH);
   v.x -= mu; v.y -= mu;
   const float var = wave_sum_dpp(v.x * v.x + v.y * v.y) * (1.0f / RH);
-  const float rstd = FAST == 0 ? rstd_eps(var, 1e-5) : r_rsqrt<FAST>(var + LN_EPS);
-  return make_float2(r_silu<FAST>(v.x * rstd * ww.x + bb.x), r_silu<FAST>(v.y * rstd * ww.y + bb.y));
+  const Rstd rstd = rstd_eps(var, LN_EPS);            // compensated sum, in every mode (umx_common.h: `var + 1e-5f` rounds one way)
+  return make_float2(r_silu<FAST>(scale_rstd(v.x, rstd) * ww.x + bb.x), r_silu<FAST>(scale_rstd(v.y, rstd) * ww.y + bb.y));
 }
 // backward of it (the arithmetic of k_ln_silu_bwd): go = dE/d(output), v = the pre-LayerNorm row
 template <int FAST>
@@ -80,7 +84,7 @@ __device__ __forceinline__ float2 ln_silu_row_bwd(float2 go, float2 v, float2 ww
   const float mu = wave_sum_dpp(v.x + v.y) * (1.0f / RH);
   v.x -= mu; v.y -= mu;
   const float var = wave_sum_dpp(v.x * v.x + v.y * v.y) * (1.0f / RH);
-  const float rstd = FAST == 0 ? rstd_eps(var, 1e-5) : r_rsqrt<FAST>(var + LN_EPS);
+  const float rstd = rstd_eps(var, LN_EPS).y;         // (reverse pass: feeds dE/dd only)
   const float xh0 = v.x * rstd, xh1 = v.y * rstd;
   const float gw0 = go.x * r_silu_grad<FAST>(xh0 * ww.x + bb.x) * ww.x;
   const float gw1 = go.y * r_silu_grad<FAST>(xh1 * ww.y + bb.y) * ww.y;

@@ -110,7 +110,9 @@ int umx_energy_forces(umx_engine* eng, int n_images, const float* pos_ang, doubl
  * after enqueueing the final kernels (one small device-to-host read of per-image edge counts
  * happens inside for workspace planning, so the host does wait for the caller's earlier work).
  * The stream only has to live until this call returns: umx_synchronize waits on an event the engine
- * owns, not on the handle.  A non-finite energy is reported late, see UMX_ERR_RANGE.             */
+ * owns, not on the handle.  A non-finite energy is reported late, see UMX_ERR_RANGE; a non-finite
+ * coordinate in d_pos_ang is found by the radius-graph kernel and refused by this very call
+ * (UMX_ERR_ARG) -- it would otherwise silently drop that atom's edges.                            */
 int umx_energy_forces_dev(umx_engine* eng, int n_images, const float* d_pos_ang,
                           double* d_energy_ev, float* d_forces_ev_ang, void* hip_stream);
 

@@ -1463,7 +1463,7 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
   }
   HIPCHK(eng, hipMemsetAsync(eng->d_img_edges + K, 0, sizeof(int), s));
   hipLaunchKernelGGL(k_graph_count, dim3(nblk(nt, 4)), dim3(256), 0, s, d_pos, N, nt, eng->cutoff * eng->cutoff, eng->max_neigh, eng->d_deg_all, eng->d_cand_all,
-                     eng->gp ? eng->gp_lo : 0L, eng->gp ? eng->gp_hi : nt);
+                     eng->gp ? eng->gp_lo : 0L, eng->gp ? eng->gp_hi : nt, eng->d_flags);
   hipLaunchKernelGGL(k_image_edges, dim3((unsigned)K), dim3(256), 0, s, eng->d_deg_all, N, eng->d_img_edges, eng->d_img_edges + K);
   HIPCHK(eng, hipGetLastError());
   std::vector<int> img_edges(K + 1);
@@ -1472,9 +1472,12 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
   HIPCHK(eng, hipMemcpyAsync(&range_flag, eng->d_flags, sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(eng, hipStreamSynchronize(s));
   if (range_flag) {
-    // set by an EARLIER evaluation through a device-pointer entry (this one has not computed an energy yet; on this stream that
-    // evaluation is complete): its caller got NaN energies / forces and, most likely, derived these positions from them
     HIPCHK(eng, hipMemsetAsync(eng->d_flags, 0, sizeof(int), s));
+    if (range_flag & 2)      // set by THIS call's k_graph_count
+      return fail(eng, UMX_ERR_ARG, "umx_energy_forces: non-finite position (device buffer)" +
+                  std::string((range_flag & 1) ? "; the previous device-pointer evaluation had already produced a non-finite energy" : ""));
+    // bit 0: set by an EARLIER evaluation through a device-pointer entry (this one has not computed an energy yet; on this stream that
+    // evaluation is complete): its caller got NaN energies / forces and, most likely, derived these positions from them
     return fail(eng, UMX_ERR_RANGE, std::string("the previous device-pointer evaluation produced a non-finite energy") +
                 (eng->pl && eng->fwd_fmt == 1 ? " (an activation beyond the fp16 operand range of the split-f16 forward planes: re-load with UMX_PRECISION=split-bf16 or fp32)"
                                               : " (non-finite input or an overflow in float32)"));

@@ -25,15 +25,18 @@ __device__ __forceinline__ float dist2_f(float dx, float dy, float dz) { return 
 // ------------------------------------------------------------------------------------------------
 // [lo, hi): the target nodes whose incoming edges this engine builds (all of them normally; one rank's share in the graph-parallel
 // single-image mode, where every other node gets an empty row).
+// flag: bit 1 of the engine's sticky status word -- a non-finite coordinate (every comparison with it is false, so the atom would just
+// lose its edges); the device-pointer entries read the word right behind this kernel and refuse the evaluation (ABI v7)
 __global__ __launch_bounds__(256) void k_graph_count(const float* __restrict__ pos, int natoms, long nt, float rc2, int max_neigh,
-                                                     int* __restrict__ deg, int* __restrict__ cand, long lo, long hi) {
+                                                     int* __restrict__ deg, int* __restrict__ cand, long lo, long hi, int* __restrict__ flag) {
   UMX_WAVE_ITEM(node, nt)
+  const float xi = pos[node * 3 + 0], yi = pos[node * 3 + 1], zi = pos[node * 3 + 2];
+  if (lane == 0 && !(isfinite(xi) && isfinite(yi) && isfinite(zi))) atomicOr(flag, 2);
   if (node < lo || node >= hi) {                 // wave-uniform
     if (lane == 0) { cand[node] = 0; deg[node] = 0; }
     return;
   }
   const long base = (node / natoms) * natoms;
-  const float xi = pos[node * 3 + 0], yi = pos[node * 3 + 1], zi = pos[node * 3 + 2];
   int cnt = 0;
   for (int j0 = 0; j0 < natoms; j0 += 64) {
     const int j = j0 + lane;

@@ -208,6 +208,11 @@ def test_device_pointer_entry_reports_range_violations(weights, monkeypatch):
         with pytest.raises(UmxError, match="device-pointer evaluation produced a non-finite energy"):
             eng.synchronize()
         eng.synchronize()
+        bad = pos.clone()
+        bad[1, 7, 2] = float("nan")                             # a NaN coordinate in a DEVICE buffer: refused by the call itself
+        with pytest.raises(UmxError, match=r"non-finite position \(device buffer\)") as ei:
+            eng.energy_forces_dev(2, bad.data_ptr(), e_t.data_ptr(), f_t.data_ptr(), stream=st)
+        assert ei.value.status == -1 and eng.take_range_error() is False
 
         def local(c):
             eng.energy_forces_dev(c.shape[0], c.contiguous().data_ptr(), e_t.data_ptr(), f_t.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)

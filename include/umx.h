@@ -125,7 +125,7 @@ int umx_energy_forces_dev(umx_engine* eng, int n_images, const float* d_pos_ang,
  * (RCCL all-reduce on the same stream, or any other collective) and calls umx_gp_step again, until *done = 1.  Exchange points:
  * the edge-degree aggregate, one node aggregate per layer (forward), one node gradient per layer (reverse) and the forces --
  * 9 all-reduces of n_atoms*1152 floats and one of n_atoms*3.  Energies are complete on every rank (node-level work is replicated);
- * forces are complete after the last all-reduce.  Split-precision modes only (auto / split / split-bf16); `hip_stream` must stay
+ * forces are complete after the last all-reduce.  Every precision mode (fp32 since round 3); `hip_stream` must stay
  * alive until umx_gp_step has reported *done.  A rank without edges (node_lo == node_hi, or isolated targets) takes part with
  * all-zero partial sums.                                                                                                      */
 int umx_gp_begin(umx_engine* eng, const float* d_pos_ang, int node_lo, int node_hi, double* d_energy_ev,

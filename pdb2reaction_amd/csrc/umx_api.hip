@@ -844,12 +844,18 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       // g_xn: every rank holds the contributions of its own edges only.  A rank WITHOUT edges (fewer atoms than ranks, or only isolated
       // targets) has run no edge kernel: G1 still holds g_xn2 of the atom-wise backward and must not enter the sum
       if (ne == 0) P.stream([=, &w]() -> int { HIPCHK(eng, hipMemsetAsync(w.G1, 0, (size_t)nn * ROW * sizeof(float), eng->stream)); return UMX_OK; });
+      else if (!(pl && eng->fuse_modrot))      // fp32 mode / unfused reverse: the partial g_xn of this rank's edges has to exist BEFORE the exchange
+        P.stream([=, &w]() -> int {
+          hipLaunchKernelGGL(k_gather_rotate_bwd, dim3(nblk(nn, 4)), B256, 0, eng->stream, w.gy1, w.frame, w.row_ptr, w.out_ptr, w.out_edge, w.G1, nn);
+          HIPCHK(eng, hipGetLastError());
+          return UMX_OK;
+        });
       P.sync(w.G1, (size_t)nn * ROW);
     }
     P.stream([=, &w]() -> int {
       hipStream_t s = eng->stream;
       const std::string t = "." + std::to_string(i);
-      if (!(ne > 0 && eng->pl && eng->fuse_modrot) && !(gp && ne == 0))
+      if (!(ne > 0 && eng->pl && eng->fuse_modrot) && !gp)
         hipLaunchKernelGGL(k_gather_rotate_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.gy1, w.frame, w.row_ptr, w.out_ptr, w.out_edge, w.G1, nn);   // G1 = g_xn
       hipLaunchKernelGGL(k_norm_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.G1, xin, Lp->n1w, w.G2, w.G0, nn);                      // G0 = g_xin
       HIPCHK(eng, hipGetLastError());
@@ -1626,7 +1632,6 @@ int umx_gp_begin(umx_engine* eng, const float* d_pos, int node_lo, int node_hi, 
   if (!eng->have_system) return fail(eng, UMX_ERR_ARG, "umx_gp_begin: bind a system first (umx_set_system)");
   if (!d_pos || !d_energy || !d_forces) return fail(eng, UMX_ERR_ARG, "umx_gp_begin: bad arguments (forces are part of the exchange)");
   if (node_lo < 0 || node_hi > eng->natoms || node_lo > node_hi) return fail(eng, UMX_ERR_ARG, "umx_gp_begin: node range outside [0, n_atoms]");
-  if (!eng->pl || !eng->fuse_modrot) return fail(eng, UMX_ERR_ARG, "umx_gp_begin: graph-parallel mode needs the default split-precision path");
   if (eng->gp_plan) gp_clear(eng);                       // an abandoned evaluation
   HIPCHK(eng, hipSetDevice(eng->dev));
   eng->gp = true; eng->gp_lo = node_lo; eng->gp_hi = node_hi;

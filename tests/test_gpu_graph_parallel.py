@@ -20,10 +20,10 @@ from pdb2reaction_amd import synth, weights as W
 pytestmark = pytest.mark.gpu
 
 
-def _single(z, pos):
+def _single(z, pos, precision=None):
     from pdb2reaction_amd.engine import Engine
 
-    eng = Engine(0)
+    eng = Engine(0, precision=precision)
     eng.load_weights(W.make_synthetic_weights(0))
     eng.set_system(z)
     e, f = eng.energy_forces(pos)
@@ -85,10 +85,10 @@ def _port():
     return port
 
 
-@pytest.mark.parametrize("world,n_atoms,precision", [(2, 300, None), (3, 157, None), (2, 120, "split-bf16"), (3, 2, None)])
+@pytest.mark.parametrize("world,n_atoms,precision", [(2, 300, None), (3, 157, None), (2, 120, "split-bf16"), (2, 90, "fp32"), (3, 2, None)])
 def test_ranks_partition_one_image(oracle, world, n_atoms, precision):
     z, imgs, _ = synth.make_images(n_atoms, 1, seed=8)
-    eng, e_ref, f_ref, ne_all = _single(z, imgs)
+    eng, e_ref, f_ref, ne_all = _single(z, imgs, precision)
     eng.close()
     # the ORACLE is the yardstick (the mode was only ever compared with the single-engine HIP result)
     e_orc, f_orc = oracle.energy_forces(z, np.asarray(imgs[0], dtype=np.float32).astype(np.float64))

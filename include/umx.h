@@ -141,6 +141,12 @@ int umx_synchronize(umx_engine* eng);
  * the maximum in-degree.  (Diagnostics for roofline accounting)         */
 int umx_last_graph_stats(const umx_engine* eng, int64_t* n_edges_total, int32_t* max_degree);
 
+/* Target-node partitions the most recent evaluation used per image: 0 = the ordinary path.  An image whose per-edge activations do not
+ * fit the workspace budget in one piece (~120 KB per directed edge) is evaluated in 2..16 partitions that keep their own activations
+ * (~72 KB per edge) and share one region for the GEMM operands, with the graph-parallel plan's exchange points summed locally (ABI v7);
+ * beyond that -- ~1.5x the atoms -- UMX_ERR_CAPACITY names the multi-GPU graph-parallel mode.                                    */
+int umx_last_partitions(const umx_engine* eng);
+
 /* Per-launch device time (HIP events on the launch stream) of three kernel families since the last reset.
  * Family 0 = split-precision LDS-DMA GEMMs (umx_gemm_q_kernel / umx_gemm_pl*_kernel: SO(2) / radial-fc3 linears and their transposes),
  * family 1 = fp32-MFMA GEMM (umx_gemm_kernel: small radial / atom-wise / readout linears; everything in fp32 mode),

@@ -134,6 +134,10 @@ struct umx_engine {
   long cap_nodes = 0, cap_edges = 0;
   int* d_deg_all = nullptr; int* d_cand_all = nullptr; long deg_all_cap = 0;
   int* d_img_edges = nullptr; long img_edges_cap = 0;
+  // partitioned evaluation of ONE oversized image on one GPU (eval_partitioned): per-partition degree arrays and partial forces
+  int force_parts = 0;             // UMX_FORCE_PARTS (dev / tests): evaluate every image in this many target-node partitions
+  int* d_part_deg = nullptr; float* d_part_f = nullptr; long part_cap = 0;
+  int last_parts = 0;              // partitions used by the most recent evaluation (0: the ordinary path)
   // host io staging for the host-pointer entry point
   float* d_io_pos = nullptr; double* d_io_e = nullptr; float* d_io_f = nullptr; long io_cap = 0, io_img_cap = 0;
   // stats / profiling / debug
@@ -379,10 +383,11 @@ struct Bump {
 
 inline int ws_mode(const umx_engine* eng) { return !eng->pl ? 0 : (eng->q3 && eng->fwd_fmt == 1) ? 2 : 3; }
 
-// pl: 0 = fp32 path, else the number of planes of the forward operands (3 bf16 / 2 fp16); see ws_mode()
-size_t carve(char* base, long nn, long ne, WS* w, int pl) {
-  Bump b{base};
-  WS t;
+// Workspace layout.  PERSISTENT buffers live from the forward to the reverse pass of an evaluation (node-level state, the graph, and the
+// per-edge activations of all four layers: ~72 KB per directed edge); TRANSIENT buffers are the operands between a producer and a GEMM
+// (~48 KB per edge) and are dead at every exchange point of the plan -- which is what lets the partitions of ONE oversized image share a
+// single transient region (eval_partitioned).  pl: 0 = fp32 path, else the number of planes of the forward operands (3 bf16 / 2 fp16).
+void carve_persist(Bump& b, long nn, long ne, WS& t) {
   t.deg = nullptr;  // deg comes from the per-call array
   t.row_ptr = b.take<int>(nn + 1); t.stats = b.take<int>(4);
   for (auto& x : t.xs) x = b.take<float>(nn * ROW);
@@ -399,10 +404,13 @@ size_t carve(char* base, long nn, long ne, WS* w, int pl) {
   t.tau = b.take<float>(ne * 4); t.tau2 = b.take<float>(ne * 4); t.gvec = b.take<float>(ne * 4);
   for (auto& x : t.h1pre) x = b.take<float>(ne * RH);
   for (auto& x : t.h2pre) x = b.take<float>(ne * RH);
-  t.ra = b.take<float>(ne * RH); t.rad_deg = b.take<float>(ne * 3 * C);
+  t.rad_deg = b.take<float>(ne * 3 * C);
   for (auto& x : t.rad) x = b.take<float>(ne * RAD);
   for (auto& x : t.hg) x = b.take<float>(ne * HG);
   for (auto& x : t.msg) x = b.take<float>(ne * ROW);
+}
+void carve_trans(Bump& b, long ne, WS& t, int pl) {
+  t.ra = b.take<float>(ne * RH);
   t.hid = b.take<float>(ne * ROW); t.gy1 = b.take<float>(ne * XROT);
   t.e128a = b.take<float>(ne * RH); t.e128b = b.take<float>(ne * RH); t.ggauss = b.take<float>(ne * NG);
   t.xrot = t.ghg = t.grad = nullptr;
@@ -418,6 +426,12 @@ size_t carve(char* base, long nn, long ne, WS* w, int pl) {
     t.xrot = b.take<float>(ne * XROT); t.gmsg = b.take<float>(ne * ROW);
     t.ghg = b.take<float>(ne * HG); t.grad = b.take<float>(ne * RAD);
   }
+}
+size_t carve(char* base, long nn, long ne, WS* w, int pl) {
+  Bump b{base};
+  WS t;
+  carve_persist(b, nn, ne, t);
+  carve_trans(b, ne, t, pl);
   if (w) *w = t;
   return (b.off + 255) & ~size_t(255);
 }
@@ -990,6 +1004,7 @@ int umx_create(umx_engine** out, int device_ordinal) {
   if (const char* ev = std::getenv("UMX_FUSE_MODROT")) e->fuse_modrot = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_STREAMS")) e->n_lanes = std::atoi(ev) >= 2 ? 2 : 1;
   if (const char* ev = std::getenv("UMX_SIDE")) e->side = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("UMX_FORCE_PARTS")) e->force_parts = std::max(0, std::min(16, std::atoi(ev)));
   if (const char* ev = std::getenv("UMX_WS_GB")) e->ws_cap_default = (size_t)std::max(0L, std::atol(ev)) << 30;
   if (const char* ev = std::getenv("UMX_AUTO_BF16_ATOMS")) e->auto_atoms = std::max(0, std::atoi(ev));
   if (const char* ev = std::getenv("UMX_NODE_F64")) e->node_f64_on = std::atoi(ev) != 0;
@@ -1024,7 +1039,7 @@ int umx_destroy(umx_engine* eng) {
   (void)hipSetDevice(eng->dev);
   (void)hipStreamSynchronize(eng->stream);
   for (auto& r : eng->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-  void* ptrs[] = {eng->d_w, eng->d_dw, eng->d_bw, eng->d_gmu, eng->d_z, eng->d_sysemb, eng->arena, eng->d_deg_all, eng->d_cand_all, eng->d_img_edges, eng->d_io_pos, eng->d_io_e, eng->d_io_f, eng->d_flags, eng->d_dtab};
+  void* ptrs[] = {eng->d_w, eng->d_dw, eng->d_bw, eng->d_gmu, eng->d_z, eng->d_sysemb, eng->arena, eng->d_deg_all, eng->d_cand_all, eng->d_img_edges, eng->d_io_pos, eng->d_io_e, eng->d_io_f, eng->d_flags, eng->d_dtab, eng->d_part_deg, eng->d_part_f};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   (void)hipStreamSynchronize(eng->stream2);
   (void)hipEventDestroy(eng->ev_fork); (void)hipEventDestroy(eng->ev_join);
@@ -1440,6 +1455,113 @@ int umx_synchronize(umx_engine* eng) {
   return UMX_OK;
 }
 
+// ---- one image in P target-node partitions on ONE GPU ----------------------------------------------------------------------------
+// The graph-parallel plan (exchange points, partial sums over a rank's own edges) run for P "virtual ranks" one after another: each
+// partition keeps its own PERSISTENT workspace (node-level state + the per-edge activations of its edges), all of them share ONE
+// TRANSIENT region (the producer -> GEMM operands are dead at every exchange point), and the all-reduce of an exchange point is a local
+// sum.  Memory per directed edge drops from ~120 KB to ~72 KB + 48 KB / P, i.e. a single image of up to ~1.5x the atoms fits the same
+// HBM; node-level work (< 3 %) is done P times.  Used automatically when one image exceeds the workspace budget.
+struct PartPtrs { float* p[16]; int n; };
+__global__ void k_sum_parts(PartPtrs pp, size_t count, float* __restrict__ also) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float sum = 0.f;
+  for (int k = 0; k < pp.n; ++k) sum += pp.p[k][i];          // fixed order: deterministic
+  for (int k = 0; k < pp.n; ++k) pp.p[k][i] = sum;
+  if (also) also[i] = sum;
+}
+
+static int eval_partitioned(umx_engine* eng, hipStream_t s, const float* d_pos, double* d_energy, float* d_forces, int P, size_t budget,
+                            int64_t* edges_out, int* maxdeg_out) {
+  const int N = eng->natoms;
+  if (P < 2 || P > 16) return fail(eng, UMX_ERR_ARG, "eval_partitioned: 2..16 partitions");
+  if (eng->part_cap < (long)P * N) {
+    HIPCHK(eng, hipStreamSynchronize(s));
+    if (eng->d_part_deg) HIPCHK(eng, hipFree(eng->d_part_deg));
+    if (eng->d_part_f) HIPCHK(eng, hipFree(eng->d_part_f));
+    eng->d_part_deg = nullptr; eng->d_part_f = nullptr; eng->part_cap = 0;
+    HIPCHK(eng, hipMalloc(&eng->d_part_deg, ((size_t)2 * P * N + 32) * sizeof(int)));
+    HIPCHK(eng, hipMalloc(&eng->d_part_f, (size_t)P * N * 3 * sizeof(float)));
+    eng->part_cap = (long)P * N;
+  }
+  int* d_cnt = eng->d_part_deg + (size_t)2 * P * N;           // [P] edge totals, [P] = max degree
+  HIPCHK(eng, hipMemsetAsync(d_cnt, 0, (P + 1) * sizeof(int), s));
+  std::vector<long> lo(P), hi(P);
+  for (int p = 0; p < P; ++p) {
+    lo[p] = (long)N * p / P; hi[p] = (long)N * (p + 1) / P;
+    int* deg = eng->d_part_deg + (size_t)(2 * p) * N;
+    hipLaunchKernelGGL(k_graph_count, dim3(nblk(N, 4)), dim3(256), 0, s, d_pos, N, (long)N, eng->cutoff * eng->cutoff, eng->max_neigh, deg, deg + N,
+                       lo[p], hi[p], eng->d_flags);
+    hipLaunchKernelGGL(k_image_edges, dim3(1), dim3(256), 0, s, deg, N, d_cnt + p, d_cnt + P);
+  }
+  HIPCHK(eng, hipGetLastError());
+  std::vector<int> cnt(P + 1);
+  int flag = 0;
+  HIPCHK(eng, hipMemcpyAsync(cnt.data(), d_cnt, (P + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(eng, hipMemcpyAsync(&flag, eng->d_flags, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(eng, hipStreamSynchronize(s));
+  if (flag & 2) { HIPCHK(eng, hipMemsetAsync(eng->d_flags, 0, sizeof(int), s)); return fail(eng, UMX_ERR_ARG, "umx_energy_forces: non-finite position (device buffer)"); }
+  // layout: P persistent regions, then one transient region sized for the largest partition
+  const int mode = ws_mode(eng);
+  std::vector<size_t> off(P + 1, 0);
+  size_t tmax = 0;
+  for (int p = 0; p < P; ++p) {
+    Bump bp{nullptr}; WS t; carve_persist(bp, N, cnt[p], t);
+    off[p + 1] = off[p] + ((bp.off + 255) & ~size_t(255));
+    Bump bt{nullptr}; carve_trans(bt, cnt[p], t, mode);
+    tmax = std::max(tmax, (bt.off + 255) & ~size_t(255));
+  }
+  const size_t total = off[P] + tmax;
+  if (total > budget) return UMX_ERR_CAPACITY;              // (the caller tries more partitions)
+  if (eng->arena_bytes < total) {
+    HIPCHK(eng, hipStreamSynchronize(s));
+    HIPCHK(eng, hipStreamSynchronize(eng->stream2));
+    if (eng->arena) { HIPCHK(eng, hipFree(eng->arena)); eng->arena = nullptr; eng->arena_bytes = 0; }
+    HIPCHK(eng, hipMalloc(&eng->arena, total));
+    eng->arena_bytes = total;
+  }
+  eng->cap_nodes = 0; eng->cap_edges = 0;                    // the ordinary path re-carves (and re-sizes) the arena on its next call
+  std::vector<WS> ws(P);
+  for (int p = 0; p < P; ++p) {
+    Bump bp{eng->arena + off[p]}; carve_persist(bp, N, cnt[p], ws[p]);
+    Bump bt{eng->arena + off[P]}; carve_trans(bt, cnt[p], ws[p], mode);
+  }
+  std::vector<Plan> plans(P);
+  const bool gp_keep = eng->gp; const long lo_keep = eng->gp_lo, hi_keep = eng->gp_hi;
+  for (int p = 0; p < P; ++p) {
+    eng->gp = true; eng->gp_lo = lo[p]; eng->gp_hi = hi[p];
+    int* deg = eng->d_part_deg + (size_t)(2 * p) * N;
+    plan_chunk(eng, ws[p], d_pos, deg, deg + N, 1, cnt[p], d_energy, d_forces ? eng->d_part_f + (size_t)p * N * 3 : nullptr, plans[p]);
+  }
+  eng->gp = gp_keep; eng->gp_lo = lo_keep; eng->gp_hi = hi_keep;
+  std::vector<size_t> at(P, 0);
+  int st = UMX_OK;
+  for (;;) {
+    PartPtrs pp; pp.n = P;
+    size_t count = 0; int waiting = 0;
+    for (int p = 0; p < P && st == UMX_OK; ++p) {
+      pp.p[p] = nullptr;
+      while (at[p] < plans[p].segs.size()) {
+        Seg& sg = plans[p].segs[at[p]++];
+        if (sg.sync_buf) { pp.p[p] = sg.sync_buf; count = sg.sync_count; ++waiting; break; }
+        st = sg.fn();
+        if (st != UMX_OK) break;
+      }
+    }
+    if (st != UMX_OK || waiting == 0) break;
+    if (waiting != P) { st = fail(eng, UMX_ERR_ARG, "eval_partitioned: the partitions' plans disagree on their exchange points"); break; }
+    const bool is_forces = d_forces && pp.p[0] == eng->d_part_f;
+    hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, pp, count, is_forces ? d_forces : (float*)nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { st = fail(eng, UMX_ERR_HIP, std::string("k_sum_parts: ") + hipGetErrorName(e)); break; }
+  }
+  if (st != UMX_OK) return st;
+  *edges_out = 0;
+  for (int p = 0; p < P; ++p) *edges_out += cnt[p];
+  *maxdeg_out = cnt[P];
+  return UMX_OK;
+}
+
 // Evaluate on `run_stream` (may be the legacy default stream 0).  eng->stream is swapped for the duration so that every
 // helper launches there; it is restored on every exit path.
 static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_images, const float* d_pos, double* d_energy, float* d_forces) {
@@ -1532,7 +1654,29 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
     }
     return UMX_OK;
   };
-  CHK(plan(max_chunk));
+  {
+    const int pst = eng->force_parts >= 2 ? UMX_ERR_CAPACITY : plan(max_chunk);
+    if (pst == UMX_ERR_CAPACITY && !eng->gp && !eng->dbg_on) {
+      // One image does not fit the budget in one piece (or UMX_FORCE_PARTS): image by image, in as few target-node partitions as fit
+      const std::string why = eng->err;
+      int64_t etot = 0; int mdeg = 0;
+      for (long k = 0; k < K; ++k) {
+        int stp = UMX_ERR_CAPACITY;
+        for (int parts = eng->force_parts >= 2 ? eng->force_parts : 2; parts <= 16 && stp == UMX_ERR_CAPACITY; parts = eng->force_parts >= 2 ? 17 : parts + 1) {
+          int64_t e1 = 0; int m1 = 0;
+          stp = eval_partitioned(eng, s, d_pos + k * N * 3, d_energy + k, d_forces ? d_forces + k * N * 3 : nullptr, parts, budget * lanes, &e1, &m1);
+          if (stp == UMX_OK) { etot += e1; mdeg = std::max(mdeg, m1); eng->last_parts = parts; }
+        }
+        if (stp == UMX_ERR_CAPACITY) return fail(eng, UMX_ERR_CAPACITY, why + " -- and not in 16 partitions on this GPU either");
+        if (stp != UMX_OK) return stp;
+      }
+      eng->last_edges = etot; eng->last_maxdeg = mdeg;
+      HIPCHK(eng, hipEventRecord(eng->ev_done, s));
+      return UMX_OK;
+    }
+    if (pst != UMX_OK) return pst;
+    eng->last_parts = 0;
+  }
   if (lanes == 2 && chunks.size() > 1) {
     // the lanes work in pairs of chunks: an even number of chunks of (nearly) equal size, so that no chunk runs without a partner
     const long n_even = (long)((chunks.size() + 1) / 2 * 2);
@@ -1721,6 +1865,8 @@ int umx_last_graph_stats(const umx_engine* eng, int64_t* n_edges_total, int32_t*
   if (max_degree) *max_degree = eng->last_maxdeg;
   return UMX_OK;
 }
+
+int umx_last_partitions(const umx_engine* eng) { return eng ? eng->last_parts : 0; }
 
 int umx_profile_enable(umx_engine* eng, int on) {
   if (!eng) return UMX_ERR_ARG;

@@ -284,12 +284,79 @@ def test_single_image_beyond_the_workspace_names_the_way_out(weights):
         eng.load_weights(weights)
         eng.set_system(z)
         eng.set_workspace_limit(200 << 20)                      # 200 MiB: one 300-atom image needs ~2 GiB
-        with pytest.raises(UmxError, match=r"one image \(300 atoms, \d+ directed edges\) needs \d+ MiB.*graph-parallel.*workers=") as ei:
+        with pytest.raises(UmxError, match=r"one image \(300 atoms, \d+ directed edges\) needs \d+ MiB.*graph-parallel.*workers=.*16 partitions") as ei:
             eng.energy_forces(imgs)
         assert ei.value.status == -4
         eng.set_workspace_limit(0)                              # back to the automatic budget: the engine is usable again
         e, f = eng.energy_forces(imgs)
         assert np.isfinite(e).all() and np.isfinite(f).all()
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("parts", [2, 3, 5])
+def test_one_image_in_target_node_partitions(weights, oracle, parts, monkeypatch):
+    """an image whose edge pipeline does not fit the workspace in one piece is evaluated in target-node partitions on the
+    SAME GPU -- the graph-parallel plan for `parts` virtual ranks run one after another, own per-edge activations, ONE shared region for
+    the GEMM operands, exchange points summed locally (`eval_partitioned`).  Forced here on small systems (UMX_FORCE_PARTS): results
+    against the oracle at the BASELINE tolerances and against the ordinary path (float32 summation order), several images per call,
+    energy-only calls, a partition without edges (dilute system, more partitions than bonded atoms)."""
+    from pdb2reaction_amd.engine import Engine
+
+    z, imgs, _ = synth.make_images(97, 3, seed=11)
+    ref = Engine(0)
+    monkeypatch.setenv("UMX_FORCE_PARTS", str(parts))
+    eng = Engine(0)
+    try:
+        for e_ in (ref, eng):
+            e_.load_weights(weights)
+            e_.set_system(z)
+        e0, f0 = ref.energy_forces(imgs)
+        e, f = eng.energy_forces(imgs)
+        assert ref.last_partitions() == 0 and eng.last_partitions() == parts and eng.graph_stats() == ref.graph_stats()
+        assert np.abs(e - e0).max() <= 2e-5 and np.abs(f - f0).max() <= 2e-5
+        for k in range(3):
+            e_ref, f_ref = oracle.energy_forces(z, imgs[k].astype(np.float32).astype(np.float64))
+            assert abs(e[k] - e_ref) <= TOL_E and np.abs(f[k] - f_ref).max() <= TOL_F
+        e2, _ = eng.energy_forces(imgs, forces=False)
+        assert np.array_equal(e2, e)
+        e3, f3 = eng.energy_forces(imgs)                                    # deterministic (fixed summation order over the partitions)
+        assert np.array_equal(e3, e) and np.array_equal(f3, f)
+        zd = np.array([8, 1, 1, 6, 7], dtype=np.int32)                       # two bonded groups 30 A apart + one isolated atom
+        pd = np.array([[[0, 0, 0], [0.96, 0, 0], [-0.3, 0.9, 0], [30, 0, 0], [60, 0, 0]]], np.float32)
+        pd[0, 4] = [31.2, 0.4, 0.1]
+        pd = np.concatenate([pd, [[[90.0, 0, 0]]]], axis=1)
+        zd = np.concatenate([zd, [1]]).astype(np.int32)
+        for e_ in (ref, eng):
+            e_.set_system(zd)
+        ed0, fd0 = ref.energy_forces(pd)
+        ed, fd = eng.energy_forces(pd)
+        assert abs(ed[0] - ed0[0]) <= 2e-5 and np.abs(fd - fd0).max() <= 2e-5 and np.all(fd[0, 5] == 0.0)
+    finally:
+        ref.close()
+        eng.close()
+
+
+def test_oversized_image_falls_back_to_partitions(weights, oracle):
+    """The automatic route: with a workspace budget that holds the image only in pieces the engine partitions it by itself."""
+    from pdb2reaction_amd.engine import Engine
+
+    z, imgs, _ = synth.make_images(300, 1, seed=4)
+    eng = Engine(0)
+    try:
+        eng.load_weights(weights)
+        eng.set_system(z)
+        e0, f0 = eng.energy_forces(imgs)
+        assert eng.last_partitions() == 0
+        eng.set_workspace_limit(1800 << 20)                     # the whole image needs ~2.2 GiB; its persistent part ~1.4 GiB
+        e, f = eng.energy_forces(imgs)
+        assert 2 <= eng.last_partitions() <= 16
+        assert np.abs(e - e0).max() <= 2e-5 and np.abs(f - f0).max() <= 2e-5
+        e_ref, f_ref = oracle.energy_forces(z, imgs[0].astype(np.float32).astype(np.float64))
+        assert abs(e[0] - e_ref) <= TOL_E and np.abs(f[0] - f_ref).max() <= TOL_F
+        eng.set_workspace_limit(0)
+        e2, f2 = eng.energy_forces(imgs)                        # back on the ordinary path, bitwise as before
+        assert eng.last_partitions() == 0 and np.array_equal(e2, e0) and np.array_equal(f2, f0)
     finally:
         eng.close()
 

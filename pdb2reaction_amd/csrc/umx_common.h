@@ -27,7 +27,11 @@ constexpr float SQRT3 = 1.7320508075688772f;
 // deterministic error of the fast v_exp/v_rsq approximations does not average out over atoms -- it showed up
 // as a same-sign per-atom energy bias of ~1e-7 eV that grows linearly with N.  These ops live in HBM-bound
 // kernels (and in GEMM prologues with ample VALU slack), so the extra instructions are free.
+#ifdef UMX_EXP_DOUBLE      // dev experiment: correctly rounded transcendentals, to measure what the float ones contribute to the energy error
+__device__ __forceinline__ float exp_f(float x) { return (float)exp((double)x); }
+#else
 __device__ __forceinline__ float exp_f(float x) { return expf(x); }
+#endif
 __device__ __forceinline__ float rsqrt_f(float x) { return 1.0f / sqrtf(x); }
 // 1 / sqrt(x + eps) for the normalisations (round 3).  In float32 `x + 1e-5f` is a grid value plus a constant: within a binade the
 // sum always lands on the same fraction of an ulp, so its rounding error is the SAME for every row -- measured +2.1e-8 relative on
@@ -46,10 +50,15 @@ __device__ __forceinline__ Rstd rstd_eps(float x, float eps) {
   return Rstd{y, -0.5f * dl * y * y};
 }
 __device__ __forceinline__ float scale_rstd(float v, Rstd r) { return fmaf(v, r.y, (v * r.y) * r.c); }
+#ifdef UMX_EXP_DOUBLE
+__device__ __forceinline__ float silu_f(float x) { return (float)((double)x / (1.0 + exp(-(double)x))); }
+__device__ __forceinline__ float sigmoid_f(float x) { return (float)(1.0 / (1.0 + exp(-(double)x))); }
+#else
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+#endif
 __device__ __forceinline__ float silu_grad_f(float x) {
-  const float s = 1.0f / (1.0f + expf(-x));
+  const float s = sigmoid_f(x);
   return s * (1.0f + x * (1.0f - s));
 }
 

@@ -38,6 +38,9 @@ constexpr int R_LDG = 68;      // padded LDS row of the 64-wide gaussian tile
 // reciprocal +4e-12 in both: as accurate per call, but the SiLU bias is 2.3x libm's and shows at c5 (-1.74e-4 against -1.28e-4 eV),
 // for 0.8 ms per c3 iteration -- mode 0 stays the default.
 template <int FAST> __device__ __forceinline__ float r_exp(float x) {
+#ifdef UMX_EXP_DOUBLE
+  if (FAST == 0) return (float)exp((double)x);
+#endif
   if (FAST == 0) return expf(x);
   if (FAST == 1) return __expf(x);
   const float n = rintf(x * 1.44269504088896341f);
@@ -57,8 +60,13 @@ template <int FAST> __device__ __forceinline__ float r_rsqrt(float x) {
   if (FAST == 2) y = fmaf(fmaf(-0.5f * x * y, y, 0.5f), y, y);
   return y;
 }
+#ifdef UMX_EXP_DOUBLE
+template <int FAST> __device__ __forceinline__ float r_sigmoid(float x) { return (float)(1.0 / (1.0 + exp(-(double)x))); }
+template <int FAST> __device__ __forceinline__ float r_silu(float x) { return (float)((double)x / (1.0 + exp(-(double)x))); }
+#else
 template <int FAST> __device__ __forceinline__ float r_sigmoid(float x) { return r_rcp<FAST>(1.0f + r_exp<FAST>(-x)); }
 template <int FAST> __device__ __forceinline__ float r_silu(float x) { return x * r_sigmoid<FAST>(x); }
+#endif
 template <int FAST> __device__ __forceinline__ float r_silu_grad(float x) {
   const float sg = r_sigmoid<FAST>(x);
   return sg * (1.0f + x * (1.0f - sg));

@@ -272,18 +272,29 @@ __global__ __launch_bounds__(256) void k_gemm_f64acc(const GemmP p) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
-  for (int k0 = 0; k0 < p.K; k0 += 32) {
+  // k-steps of 32 with the NEXT step's operands fetched into registers before this step's MFMAs: small node counts (c1: 400 rows,
+  // 7 row tiles) leave one workgroup per CU, so nothing else hides the global-load latency of the 4 ... 16 steps.
+  float ra[8], rb[8];
+  auto fetch = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int idx = tid + 256 * i, r = idx >> 5, kk = idx & 31;
       const long grow = (long)mt * 64 + r;
-      float v = grow < p.M ? p.A[grow * p.lda + p.offA0 + zoffA + k0 + kk] : 0.f;
-      if (AMODE == A_SILU) v = silu_f(v);
-      As[kk][r] = (double)v;
+      ra[i] = grow < p.M ? p.A[grow * p.lda + p.offA0 + zoffA + k0 + kk] : 0.f;
       const int brow = nt * 64 + r;
-      Bs[kk][r] = brow < p.N ? (double)Bz[(long)brow * p.ldb + k0 + kk] : 0.0;
+      rb[i] = brow < p.N ? Bz[(long)brow * p.ldb + k0 + kk] : 0.f;
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < p.K; k0 += 32) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i, r = idx >> 5, kk = idx & 31;
+      As[kk][r] = (double)(AMODE == A_SILU ? silu_f(ra[i]) : ra[i]);
+      Bs[kk][r] = (double)rb[i];
     }
     __syncthreads();
+    if (k0 + 32 < p.K) fetch(k0 + 32);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       double a[2], b[2];

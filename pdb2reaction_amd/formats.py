@@ -11,6 +11,8 @@ tests/test_formats.py pin it); pure Python/numpy, no third-party IO:
 * ``summary.yaml`` of a path search: ``out_dir / n_images / n_segments / segments[index, tag, kind, barrier_kcal, delta_kcal,
   bond_changes]`` (+ optional ``energy_diagrams``), dumped with ``yaml.safe_dump(sort_keys=False, allow_unicode=True)``; the
   bond-change report text becomes a list of one-key mappings (``path_search.py:245-293,2762-2786``).
+* energy series of a trajectory: ``recompute_energies`` (all frames in ONE batched engine call), ``transform_series``,
+  ``write_energy_csv`` -- ``trj2fig.py:112-205,287-303`` (plotting itself is out of scope).
 * HEI rule lives in :func:`pdb2reaction_amd.string.select_hei_index` (``path_opt.py:259-273``).
 """
 from __future__ import annotations
@@ -167,6 +169,88 @@ try:  # Hartree -> kcal/mol exactly as pysisyphus.constants builds it: E_h * N_A
     AU2KCALPERMOL = _sc.value("Hartree energy") * _sc.N_A / 1000.0 / 4.184
 except Exception:  # CODATA 2022
     AU2KCALPERMOL = 627.5094740630558
+
+
+# ---- energy series of a trajectory (the consumer of the .trj files: ``trj2fig.py:112-205,287-303``) ------------------------------
+def recompute_energies(traj_path: PathLike, charge: Optional[int], multiplicity: Optional[int], *, calc=None,
+                       max_batch: Optional[int] = None) -> List[float]:
+    """Hartree energy of every frame of an XYZ trajectory, re-scored by the calculator (``trj2fig.py:112-134``: one
+    ``uma_pysis(charge=charge or 0, spin=multiplicity or 1)``, ``get_energy(symbols, positions * ANG2BOHR)`` per frame).
+
+    The reference walks the frames one by one; here ALL frames go to the engine in one batched call
+    (``uma_pysis.get_energy_batch``; ``max_batch`` frames at a time if given) -- per frame the same number ``get_energy`` returns.
+    ``calc``: an existing calculator to use (it is not closed); by default one is created as in the reference and closed again.
+    Frames must hold the same atoms in the same order (the reference binds the calculator to the first frame's elements)."""
+    symbols, coords_ang, _ = read_trj(traj_path)
+    if len(coords_ang) == 0:
+        raise RuntimeError(f"No frames found in {traj_path}")
+    from ._calculator_base import ANG2BOHR
+
+    own = calc is None
+    if own:
+        from .uma_pysis import uma_pysis
+
+        calc = uma_pysis(charge=charge or 0, spin=multiplicity or 1)
+    try:
+        coords_bohr = np.asarray(coords_ang, dtype=np.float64) * ANG2BOHR
+        step = len(coords_bohr) if not max_batch else max(1, int(max_batch))
+        energies: List[float] = []
+        for k0 in range(0, len(coords_bohr), step):
+            energies += [float(e) for e in calc.get_energy_batch(symbols, coords_bohr[k0:k0 + step])["energy"]]
+        return energies
+    finally:
+        if own and hasattr(calc, "close"):
+            calc.close()
+
+
+def _parse_reference_spec(spec: Optional[str]):
+    """``-r/--reference``: None -> "init"; "none"/"null" -> None (absolute energies); "init"; else an integer frame index
+    (``trj2fig.py:137-157``)."""
+    if spec is None:
+        return "init"
+    s = str(spec).strip()
+    if s.lower() in ("none", "null"):
+        return None
+    if s.lower() == "init":
+        return "init"
+    try:
+        return int(s)
+    except ValueError:
+        raise ValueError(f"Invalid -r/--reference: {spec!r}. Use 'init', 'None', or an integer index.")
+
+
+def transform_series(energies_hartree: Sequence[float], ref_spec_raw: Optional[str], unit: str,
+                     reverse_x: bool) -> Tuple[List[float], str, bool]:
+    """(values, y-axis label, is_delta) of an energy profile (``trj2fig.py:160-205``): relative to the reference frame ("init" = first
+    frame, or the last one when the x axis is reversed; an explicit index must lie in 0..n-1 -> IndexError) or absolute when the
+    reference is none; ``unit`` "kcal" scales by AU2KCALPERMOL, anything else stays in Hartree."""
+    ref = _parse_reference_spec(ref_spec_raw)
+    n = len(energies_hartree)
+    if ref is None:
+        idx = None
+    elif ref == "init":
+        idx = n - 1 if reverse_x else 0
+    else:
+        idx = int(ref)
+        if idx < 0 or idx >= n:
+            raise IndexError(f"Reference index {idx} out of range (0..{n-1}).")
+    scale = AU2KCALPERMOL if unit == "kcal" else 1.0
+    name = "kcal/mol" if unit == "kcal" else "hartree"
+    if idx is None:
+        return [float(e * scale) for e in energies_hartree], f"E ({name})", False
+    base = energies_hartree[idx]
+    return [float((e - base) * scale) for e in energies_hartree], f"\u0394E ({name})", True
+
+
+def write_energy_csv(out: PathLike, energies_hartree: Sequence[float], series: Sequence[float], unit: str, is_delta: bool) -> None:
+    """``frame,energy_hartree,<delta|energy>_<unit>`` with ``%.8f`` / ``%.6f`` values, csv-module line ends (``trj2fig.py:287-303``)."""
+    import csv
+
+    with Path(out).open("w", newline="", encoding="utf-8") as fh:
+        w = csv.writer(fh)
+        w.writerow(["frame", "energy_hartree", f"delta_{unit}" if is_delta else f"energy_{unit}"])
+        for i, (eh, y) in enumerate(zip(energies_hartree, series)):
+            w.writerow([i, f"{eh:.8f}", f"{y:.6f}"])
 
 
 def barrier_and_delta_kcal(energies_hartree: Sequence[float]) -> Tuple[float, float]:

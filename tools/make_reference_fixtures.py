@@ -30,6 +30,13 @@ and, into tests/golden/ref_uma_pysis_methods.json (round 3: the file that IS the
                                                                                    (HIP kernel k_bond_changes), oracle/bond_changes_oracle
   pdb2reaction/path_opt.py            _write_ase_trj_with_energy (:276-290)     -> pdb2reaction_amd.formats.write_trj_with_energy
 
+and, into tests/golden/ref_energy_series.json (the consumer of the .trj files):
+
+  pdb2reaction/trj2fig.py             recompute_energies, transform_series (+ _parse_reference_spec,
+                                      _resolve_reference_index), write_csv (:112-205,287-303)
+                                                                                -> pdb2reaction_amd.formats.recompute_energies (ONE batched
+                                                                                   engine call for all frames), transform_series, write_energy_csv
+
 Unit constants the reference takes from pysisyphus.constants are passed in from scipy and recorded
 in the fixture.
 """
@@ -222,8 +229,10 @@ def main():
     OUT.write_text(json.dumps(fx, indent=1) + "\n")          # insertion order matters (YAML key order of dict-valued inputs)
     print(f"wrote {OUT} ({OUT.stat().st_size} bytes): " + ", ".join(f"{k}={len(v)}" for k, v in fx.items() if isinstance(v, list)))
     boundary_fixtures()
+    energy_series_fixtures()
 
 OUT_BOUNDARY = ROOT / "tests" / "golden" / "ref_uma_pysis_methods.json"
+OUT_SERIES = ROOT / "tests" / "golden" / "ref_energy_series.json"
 UMA_METHODS = ["_ensure_core", "_au_energy", "_au_forces", "_au_hessian", "_active_and_frozen_dof_idx", "_zero_frozen_forces_ev",
                "_apply_analytical_active_trim", "_build_fd_hessian_gpu", "get_energy", "get_forces", "get_hessian"]
 
@@ -392,6 +401,96 @@ def boundary_fixtures():
 
     OUT_BOUNDARY.write_text(json.dumps(fx, separators=(",", ":")) + "\n")
     print(f"wrote {OUT_BOUNDARY} ({OUT_BOUNDARY.stat().st_size} bytes): " + ", ".join(f"{k}={len(v)}" for k, v in fx.items() if isinstance(v, list)))
+
+
+def energy_series_fixtures():
+    """trj2fig.py:112-205,287-303: the consumer of the `.trj` files -- energies re-scored frame by frame through the calculator, the
+    dE series and its CSV.  The reference's `recompute_energies` is compiled as written; the ASE reader it calls (`read(path, index=":",
+    format="xyz")`) is replaced by a plain XYZ-frame parser handing out objects with the two `Atoms` methods it uses, and
+    `uma_pysis(charge=, spin=)` by the reference's own get_energy (compiled from uma_pysis.py as above) on the toy core."""
+    import csv
+    import io
+    import contextlib
+
+    sys.path.insert(0, str(ROOT / "tests"))
+    from toy_core import ToyPairCore, toy_geometry
+    from pdb2reaction_amd.formats import AU2KCALPERMOL
+
+    EV2AU = 1.0 / AU2EV
+    ns_calc = grab(REF / "uma_pysis.py", ["get_energy", "_au_energy", "_ensure_core"], cls="uma_pysis", extra={"EV2AU": EV2AU})
+    RefCalc = type("RefCalc", (), {m: ns_calc[m] for m in ("get_energy", "_au_energy", "_ensure_core")})
+    made = []
+
+    class _Atoms:
+        def __init__(self, sym, pos):
+            self._s, self._p = list(sym), np.asarray(pos, dtype=float)
+
+        def get_chemical_symbols(self):
+            return list(self._s)
+
+        def get_positions(self):
+            return self._p.copy()
+
+    def _read(path, index=":", format="xyz"):
+        assert index == ":" and format == "xyz"
+        lines = Path(path).read_text().split("\n")
+        out, i = [], 0
+        while i < len(lines) and lines[i].strip():
+            n = int(lines[i])
+            rows = [ln.split() for ln in lines[i + 2:i + 2 + n]]
+            out.append(_Atoms([r[0] for r in rows], [[float(v) for v in r[1:4]] for r in rows]))
+            i += 2 + n
+        return out
+
+    def _factory(charge=0, spin=1):
+        me = RefCalc()
+        me._core = ToyPairCore(made[-1]["n_atoms"], seed=made[-1]["seed"])
+        made[-1]["ctor"] = {"charge": charge, "spin": spin}
+        return me
+
+    ns = grab(REF / "trj2fig.py", ["recompute_energies", "_parse_reference_spec", "_resolve_reference_index", "transform_series", "write_csv"],
+              extra={"read": _read, "Atoms": _Atoms, "uma_pysis": _factory, "AU2KCALPERMOL": AU2KCALPERMOL, "csv": csv})
+    rng = np.random.default_rng(20261006)
+    fx: Dict[str, Any] = {"generated_by": "tools/make_reference_fixtures.py:energy_series_fixtures",
+                          "reference": "t-0hmura/pdb2reaction (local checkout): pdb2reaction/trj2fig.py:112-205,287-303",
+                          "constants": {"AU2KCALPERMOL": AU2KCALPERMOL, "ANG2BOHR": ANG2BOHR, "EV2AU": EV2AU}}
+    fx["recompute_energies"] = []
+    with tempfile.TemporaryDirectory() as td:
+        for n_at, k, seed, charge, mult in ((4, 5, 3, 0, 1), (6, 3, 4, -1, 2), (3, 1, 5, None, 3), (5, 7, 6, 2, None)):
+            sym = [str(a) for a in rng.choice(["H", "C", "N", "O"], size=n_at)]
+            base = toy_geometry(n_at, seed)
+            frames = [base + rng.normal(size=(n_at, 3)) * 0.05 for _ in range(k)]
+            text = "".join(f"{n_at}\nframe {i}\n" + "".join(f"{s} {x:.15f} {y:.15f} {z:.15f}\n" for s, (x, y, z) in zip(sym, fr))
+                           for i, fr in enumerate(frames))
+            path = Path(td) / "a.trj"
+            path.write_text(text)
+            made.append({"n_atoms": n_at, "seed": seed})
+            en = ns["recompute_energies"](path, charge, mult)
+            fx["recompute_energies"].append({"text": text, "charge": charge, "multiplicity": mult, "n_atoms": n_at, "core_seed": seed,
+                                             "ctor": made[-1]["ctor"], "energies": en})
+    fx["transform_series"] = []
+    series = [[-1.5, -1.49, -1.52, -1.4801], [0.25], list((rng.normal(size=9) * 0.01 - 228.0).tolist())]
+    for en in series:
+        for spec in (None, "init", "INIT", "none", "Null", "0", " 2 ", "-1", "7", "abc", "1.5", str(len(en) - 1), str(len(en))):
+            for unit in ("kcal", "hartree"):
+                for rev in (False, True):
+                    rec = {"energies": en, "reference": spec, "unit": unit, "reverse_x": rev}
+                    try:
+                        v, lab, isd = ns["transform_series"](en, spec, unit, rev)
+                        rec.update(values=v, ylabel=lab, is_delta=isd)
+                    except Exception as exc:
+                        rec.update(raises=type(exc).__name__, message=str(exc))
+                    fx["transform_series"].append(rec)
+    fx["write_csv"] = []
+    with tempfile.TemporaryDirectory() as td:
+        for en, unit, isd in ((series[0], "kcal", True), (series[2], "hartree", False), (series[1], "kcal", False)):
+            vals = [float(x) for x in rng.normal(size=len(en)) * 12.0]
+            p2 = Path(td) / "o.csv"
+            with contextlib.redirect_stdout(io.StringIO()):
+                ns["write_csv"](p2, en, vals, unit, isd)
+            fx["write_csv"].append({"energies": en, "series": vals, "unit": unit, "is_delta": isd, "bytes": p2.read_bytes().decode("utf-8")})
+    OUT_SERIES.write_text(json.dumps(fx, indent=1) + "\n")
+    print(f"wrote {OUT_SERIES} ({OUT_SERIES.stat().st_size} bytes): " + ", ".join(f"{k}={len(v)}" for k, v in fx.items() if isinstance(v, list)))
 
 
 if __name__ == "__main__":

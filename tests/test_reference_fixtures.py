@@ -127,3 +127,32 @@ def test_summary_yaml_matches_reference(fx, tmp_path):
         assert (tmp_path / "summary.yaml").read_text(encoding="utf-8") == case["text"]
     b, dlt = F.barrier_and_delta_kcal([-1.0, -0.98, -1.01])
     assert b == pytest.approx(0.02 * 627.509474, rel=1e-7) and dlt == pytest.approx(-0.01 * 627.509474, rel=1e-7)
+
+
+def test_default_settings_match_reference(fx):
+    """uma_pysis.py:132-165 (CALC_KW / GEOM_KW_DEFAULT), the constructor's keyword-only signature (:432-452), path_opt.py:168-200
+    (GS_KW / STOPT_KW) and the L-BFGS memory / damping defaults (opt.py:222-246): recorded VALUES of the reference's dicts."""
+    import importlib
+    import inspect
+
+    from pdb2reaction_amd import gsm, lbfgs
+    import pdb2reaction_amd as pkg
+
+    U = importlib.import_module("pdb2reaction_amd.uma_pysis")
+    d = fx["defaults"]
+    assert U.CALC_KW == d["CALC_KW"] and list(U.CALC_KW) == list(d["CALC_KW"])          # same keys in the same order, same values
+    assert U.GEOM_KW_DEFAULT == d["GEOM_KW_DEFAULT"] and pkg.CALC_KW is U.CALC_KW
+    sig = inspect.signature(U.uma_pysis.__init__)
+    kw_only = {n: p.default for n, p in sig.parameters.items() if p.kind is inspect.Parameter.KEYWORD_ONLY}
+    ref_kw = d["uma_pysis.__init__"]["keyword_only"]
+    assert {k: kw_only[k] for k in ref_kw} == ref_kw                                     # every reference keyword, same default
+    assert [n for n, p in sig.parameters.items() if p.kind is inspect.Parameter.POSITIONAL_OR_KEYWORD] == d["uma_pysis.__init__"]["positional"]
+    assert [n for n, p in sig.parameters.items() if p.kind is inspect.Parameter.VAR_KEYWORD] == [d["uma_pysis.__init__"]["var_keyword"]]
+    extra = set(kw_only) - set(ref_kw)
+    assert extra <= {"precision"}, extra                                                 # the one keyword this build adds
+    assert gsm.GS_KW == d["GS_KW"]
+    assert {k: gsm.STOPT_KW[k] for k in d["STOPT_KW"]} == d["STOPT_KW"]                  # + max_step / thresh, which the reference merges in from opt:
+    assert set(gsm.STOPT_KW) - set(d["STOPT_KW"]) == {"max_step", "thresh"}
+    lb = inspect.signature(lbfgs.BatchedLBFGS.__init__).parameters
+    assert lb["keep_last"].default == d["LBFGS_KW"]["keep_last"] and lb["beta"].default == d["LBFGS_KW"]["beta"]
+    assert lb["thresh"].default == d["OPT_BASE_KW"]["thresh"]

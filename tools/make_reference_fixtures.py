@@ -225,6 +225,27 @@ def main():
         fx["summary_yaml"].append({"out_dir": "result_path_search", "n_images": 37, "segments": segs_in, "energy_diagram": dg,
                                    "text": _yaml.safe_dump(sm, sort_keys=False, allow_unicode=True)})
 
+    # ---- default settings (uma_pysis.py:132-165,432-452; path_opt.py:168-200; opt.py:171-246): the VALUES of the module-level
+    # dict assignments (only those Assign nodes are evaluated, `**OPT_BASE_KW` resolving to the one just evaluated) and the
+    # keyword defaults of the calculator's constructor
+    def literal_dicts(path, names, given=None):
+        env: Dict[str, Any] = dict(given or {})
+        for node in ast.parse(path.read_text()).body:
+            tgt = node.targets[0] if isinstance(node, ast.Assign) else node.target if isinstance(node, ast.AnnAssign) else None
+            if isinstance(tgt, ast.Name) and tgt.id in names and getattr(node, "value", None) is not None:
+                env[tgt.id] = eval(compile(ast.Expression(node.value), f"<{path.name}:{tgt.id}>", "eval"), {"__builtins__": {}, "dict": dict}, env)
+        return {k: env[k] for k in names}
+
+    dflt = literal_dicts(REF / "uma_pysis.py", ["GEOM_KW_DEFAULT", "CALC_KW"])
+    dflt.update(literal_dicts(REF / "path_opt.py", ["GS_KW", "STOPT_KW"]))
+    dflt.update(literal_dicts(REF / "opt.py", ["OPT_BASE_KW", "LBFGS_KW"]))
+    cls = next(n for n in ast.parse((REF / "uma_pysis.py").read_text()).body if isinstance(n, ast.ClassDef) and n.name == "uma_pysis")
+    init = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "__init__")
+    dflt["uma_pysis.__init__"] = {"positional": [a.arg for a in init.args.args], "var_keyword": init.args.kwarg.arg if init.args.kwarg else None,
+                                  "keyword_only": {a.arg: eval(compile(ast.Expression(d), "<uma_pysis.__init__>", "eval"), {"__builtins__": {}}, {"CALC_KW": dflt["CALC_KW"]})
+                                                   for a, d in zip(init.args.kwonlyargs, init.args.kw_defaults)}}
+    fx["defaults"] = dflt
+
     OUT.parent.mkdir(parents=True, exist_ok=True)
     OUT.write_text(json.dumps(fx, indent=1) + "\n")          # insertion order matters (YAML key order of dict-valued inputs)
     print(f"wrote {OUT} ({OUT.stat().st_size} bytes): " + ", ".join(f"{k}={len(v)}" for k, v in fx.items() if isinstance(v, list)))

@@ -152,7 +152,7 @@ def rmsd_ang(a_bohr: np.ndarray, b_bohr: np.ndarray) -> float:
 
 
 def freeze_union(freeze_ref, freeze_mob, n_atoms: Optional[int] = None) -> List[int]:
-    """Sorted union of two freeze lists, out-of-range indices dropped (reference ``_freeze_union``, :228-238)."""
+    """Sorted union of two freeze lists, out-of-range indices dropped (reference ``_freeze_union``, ``align_freeze_atoms.py:253-268``)."""
     cand = sorted({int(i) for i in list(freeze_ref if freeze_ref is not None else []) + list(freeze_mob if freeze_mob is not None else [])})
     return cand if n_atoms is None else [i for i in cand if 0 <= i < int(n_atoms)]
 
@@ -163,7 +163,7 @@ def align_second_to_first(ref_bohr: np.ndarray, mob_bohr: np.ndarray, anchors: S
     1 anchor: translate it onto its partner, then the best rotation ABOUT that point (all-atom RMSD);
     2 anchors: match midpoints, align the anchor axis, then the best rotation about that axis (all-atom RMSD), falling
     back to Kabsch when the axis is degenerate; otherwise Kabsch on the anchors (all atoms when there are none), RMSD
-    reported on the fitted selection (reference ``align_second_to_first_kabsch_inplace``, :245-386).
+    reported on the fitted selection (reference ``align_second_to_first_kabsch_inplace``, ``align_freeze_atoms.py:271-387``).
     """
     p = np.asarray(ref_bohr, dtype=float).reshape(-1, 3)
     q = np.asarray(mob_bohr, dtype=float).reshape(-1, 3)

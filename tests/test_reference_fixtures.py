@@ -156,3 +156,27 @@ def test_default_settings_match_reference(fx):
     lb = inspect.signature(lbfgs.BatchedLBFGS.__init__).parameters
     assert lb["keep_last"].default == d["LBFGS_KW"]["keep_last"] and lb["beta"].default == d["LBFGS_KW"]["beta"]
     assert lb["thresh"].default == d["OPT_BASE_KW"]["thresh"]
+
+
+def test_pair_alignment_matches_reference(fx):
+    """align_second_to_first_kabsch_inplace + _freeze_union (align_freeze_atoms.py:253-387): no anchors, one, two, two on ONE point
+    (degenerate axis -> Kabsch reported on all atoms), many, out-of-range indices; the union comes from both structures."""
+    from pdb2reaction_amd import prestep as P
+
+    assert len(fx["align_pair"]) >= 10
+    modes = set()
+    for c in fx["align_pair"]:
+        n = len(c["ref_bohr"])
+        assert P.freeze_union(c["freeze_ref"], c["freeze_mob"], n) == c["union"]
+        assert P.freeze_union(c["freeze_ref"], c["freeze_mob"]) == c["union_unbounded"]
+        out, rep = P.align_second_to_first(np.asarray(c["ref_bohr"]), np.asarray(c["mob_bohr"]), c["union"])
+        want = c["report"]
+        assert rep["mode"] == want["mode"] and rep["n_used"] == want["n_used"] and type(rep["n_used"]) is int
+        np.testing.assert_allclose(out, np.asarray(c["aligned_bohr"]), rtol=0, atol=1e-12)
+        np.testing.assert_allclose([rep["before_A"], rep["after_A"]], [want["before_A"], want["after_A"]], rtol=1e-12, atol=1e-13)
+        assert c["freeze_during_write"] == [] and c["freeze_after"] == sorted(c["freeze_mob"], key=c["freeze_mob"].index)   # (the fixture's own sanity)
+        modes.add((want["mode"], want["n_used"] <= 2))
+    assert {("kabsch", False), ("one_anchor", True), ("two_anchor", True), ("kabsch", True)} <= modes
+    with pytest.raises(ValueError) as ei:
+        P.align_second_to_first(np.zeros((3, 3)), np.zeros((4, 3)), [])
+    assert type(ei.value).__name__ == fx["align_pair_mismatch"]["raises"] and str(ei.value) == fx["align_pair_mismatch"]["message"]

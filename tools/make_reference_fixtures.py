@@ -225,6 +225,47 @@ def main():
         fx["summary_yaml"].append({"out_dir": "result_path_search", "n_images": 37, "segments": segs_in, "energy_diagram": dg,
                                    "text": _yaml.safe_dump(sm, sort_keys=False, allow_unicode=True)})
 
+    # ---- rigid pre-alignment of a pair (align_freeze_atoms.py:253-387): 0 / 1 / 2 / degenerate-2 / many anchors.  The geometry objects
+    # are data holders with the three members the function touches (coords3d, freeze_atoms, set_coords)
+    class _Geom:
+        def __init__(self, c, fz):
+            self.coords3d = np.array(c, float)
+            self.freeze_atoms = np.array(fz, int)
+            self.seen_freeze = None
+
+        def set_coords(self, flat, cartesian=True):
+            assert cartesian is True
+            self.seen_freeze = list(self.freeze_atoms)                 # must be empty while the coordinates are written
+            self.coords3d = np.array(flat, float).reshape(-1, 3)
+
+    import io
+    import contextlib
+    al2 = grab(REF / "align_freeze_atoms.py", ["kabsch_R_t", "_rodrigues", "_rotation_align_vectors", "_orth_proj_perp", "_rmsd", "_coords3d",
+                                                "_set_all_coords_disabling_freeze", "_freeze_union", "align_second_to_first_kabsch_inplace"])
+    rng2 = np.random.default_rng(20261007)
+    fx["align_pair"] = []
+    for n, fz_ref, fz_mob in ((9, [], []), (9, [4], []), (9, [], [4, 4]), (9, [2], [7]), (9, [7, 2], [2]), (9, [1, 3], [5, 8, 1]),
+                              (6, [0, 1, 2, 3, 4, 5], []), (7, [3, 40, -2], []), (7, [50], [1, 6]), (5, [0, 4], [])):
+        P = rng2.normal(size=(n, 3)) * 4.0
+        ang = rng2.normal(size=3)
+        rot = al2["_rodrigues"](ang / np.linalg.norm(ang), float(rng2.uniform(0.3, 2.5)))
+        Q = P @ rot.T + rng2.normal(size=3) * 2.0 + rng2.normal(size=(n, 3)) * 0.15
+        degenerate = (n == 5)
+        if degenerate:                                                # both anchors on one point in the reference: falls through to Kabsch
+            P[4] = P[0]
+        g_ref, g_mob = _Geom(P, fz_ref), _Geom(Q, fz_mob)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            rep = al2["align_second_to_first_kabsch_inplace"](g_ref, g_mob, verbose=True)
+        fx["align_pair"].append({"ref_bohr": P.tolist(), "mob_bohr": Q.tolist(), "freeze_ref": fz_ref, "freeze_mob": fz_mob,
+                                 "union": al2["_freeze_union"](g_ref, g_mob, n_atoms=n), "union_unbounded": al2["_freeze_union"](g_ref, g_mob),
+                                 "aligned_bohr": g_mob.coords3d.tolist(), "report": rep, "freeze_during_write": g_mob.seen_freeze,
+                                 "freeze_after": [int(i) for i in g_mob.freeze_atoms], "printed": buf.getvalue()})
+    try:
+        al2["align_second_to_first_kabsch_inplace"](_Geom(np.zeros((3, 3)), []), _Geom(np.zeros((4, 3)), []), verbose=False)
+    except Exception as exc:
+        fx["align_pair_mismatch"] = {"raises": type(exc).__name__, "message": str(exc)}
+
     # ---- default settings (uma_pysis.py:132-165,432-452; path_opt.py:168-200; opt.py:171-246): the VALUES of the module-level
     # dict assignments (only those Assign nodes are evaluated, `**OPT_BASE_KW` resolving to the one just evaluated) and the
     # keyword defaults of the calculator's constructor

@@ -222,3 +222,33 @@ def test_hip_bond_changes_match_reference_compare_structures(fx):
     with pytest.raises(AssertionError, match="Atom types and ordering must be identical."):
         BC.compare_structures(SimpleNamespace(atoms=["H", "C"], coords3d=np.zeros((2, 3))),
                               SimpleNamespace(atoms=["C", "H"], coords3d=np.zeros((2, 3))))
+
+
+def test_harmonic_bias_wrapper_matches_reference_class(fx):
+    """opt.py:286-343, the whole ``HarmonicBiasCalculator`` as written, over the reference's own get_forces / get_energy on the toy
+    core: restraint energy and forces added to the base calculator's, the two tuple-returning conveniences, ``set_pairs`` element
+    types, attribute forwarding, and the number of base evaluations -- plus the batched entry this build adds."""
+    from pdb2reaction_amd import prestep as PS
+
+    assert len(fx["harmonic_bias_wrapper"]) >= 2
+    for c in fx["harmonic_bias_wrapper"]:
+        core = ToyPairCore(c["n_atoms"], seed=c["core_seed"])
+        base = U.uma_pysis(freeze_atoms=c["freeze_atoms"])
+        base._core = core
+        wb = PS.HarmonicBias(base, k=c["k_ev_ang2"])
+        wb.set_pairs([(np.int64(i), j, np.float32(t)) for i, j, t in c["pairs_in"]])
+        assert [list(p) for p in wb._pairs] == c["pairs_stored"] and [type(v).__name__ for v in wb._pairs[0]] == c["pair_types"]
+        assert wb.k_au_bohr2 == c["k_au_bohr2"]
+        x = np.asarray(c["coords_bohr"])
+        el = ["C"] * c["n_atoms"]
+        rf = wb.get_forces(el, x.reshape(-1))
+        close(rf["energy"], c["get_forces"]["energy"]); close(rf["forces"], c["get_forces"]["forces"])
+        assert isinstance(rf["energy"], float) and rf["forces"].shape == (3 * c["n_atoms"],)
+        close(wb.get_energy(el, x)["energy"], c["get_energy"])
+        e2, f2 = wb.get_energy_and_forces(el, x)
+        close(e2, c["energy_and_forces"][0]); close(f2, c["energy_and_forces"][1])
+        e3, g3 = wb.get_energy_and_gradient(el, x.reshape(-1))
+        close(e3, c["energy_and_gradient"][0]); close(g3, c["energy_and_gradient"][1])
+        assert list(wb.freeze_atoms) == c["forwarded_freeze_atoms"] and core.calls == c["base_calls"]
+        rb = wb.get_forces_batch(el, np.stack([x, x + 0.01]))                       # this build's batched entry: image 0 is the same number
+        close(rb["energy"][0], c["get_forces"]["energy"]); close(rb["forces"][0], c["get_forces"]["forces"])

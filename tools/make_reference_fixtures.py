@@ -461,6 +461,30 @@ def boundary_fixtures():
             wr([_Img(sym, x) for x in imgs], en, p)
             fx["write_ase_trj"].append({"symbols": sym, "images_ang": [x.tolist() for x in imgs], "energies_hartree": en, "text": p.read_text()})
 
+    # ---- the restraint wrapper around the calculator (opt.py:286-343): the whole class as written, on the reference's own get_forces /
+    # get_energy over the toy core
+    Bias = grab(REF / "opt.py", ["HarmonicBiasCalculator"])["HarmonicBiasCalculator"]
+    fx["harmonic_bias_wrapper"] = []
+    for n_at, seed, k_ev, fz in ((5, 31, 10.0, []), (7, 32, 2.5, [0, 3])):
+        x = toy_geometry(n_at, seed) * ANG2BOHR
+        prs = [(int(i), int(j), float(t)) for i, j, t in zip(rng.integers(0, n_at, 5), rng.integers(0, n_at, 5), rng.uniform(0.9, 2.8, 5))]
+        prs += [(0, n_at + 2, 1.0), (2, 2, 1.1)]
+        base = ref_calc(ToyPairCore(n_at, seed=seed), freeze_atoms=fz)
+        wb = Bias(base, k=k_ev)
+        wb.set_pairs([(np.int64(i), j, np.float32(t)) for i, j, t in prs])          # set_pairs normalises the element types
+        el = ["C"] * n_at
+        rf = wb.get_forces(el, x.reshape(-1))
+        re_ = wb.get_energy(el, x)
+        e2, f2 = wb.get_energy_and_forces(el, x)
+        e3, g3 = wb.get_energy_and_gradient(el, x.reshape(-1))
+        fx["harmonic_bias_wrapper"].append({
+            "n_atoms": n_at, "core_seed": seed, "k_ev_ang2": k_ev, "freeze_atoms": fz, "coords_bohr": x.tolist(),
+            "pairs_in": [[int(i), int(j), float(np.float32(t))] for i, j, t in prs],
+            "pairs_stored": [list(p) for p in wb._pairs], "pair_types": [[type(v).__name__ for v in p] for p in wb._pairs][0],
+            "k_au_bohr2": wb.k_au_bohr2, "get_forces": {"energy": rf["energy"], "forces": np.asarray(rf["forces"]).tolist()},
+            "get_energy": re_["energy"], "energy_and_forces": [e2, np.asarray(f2).tolist()], "energy_and_gradient": [e3, np.asarray(g3).tolist()],
+            "forwarded_freeze_atoms": list(wb.freeze_atoms), "base_calls": base._core.calls})
+
     OUT_BOUNDARY.write_text(json.dumps(fx, separators=(",", ":")) + "\n")
     print(f"wrote {OUT_BOUNDARY} ({OUT_BOUNDARY.stat().st_size} bytes): " + ", ".join(f"{k}={len(v)}" for k, v in fx.items() if isinstance(v, list)))
 

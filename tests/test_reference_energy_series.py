@@ -97,17 +97,15 @@ def test_recompute_energies_rejects_what_the_reference_cannot_score(tmp_path):
 
 
 @pytest.mark.gpu
-def test_recompute_energies_one_batched_call_on_the_engine(tmp_path, monkeypatch):
+def test_recompute_energies_one_batched_call_on_the_engine(tmp_path):
     """On the HIP engine: all frames in ONE `umx_energy_forces` call, per frame bitwise what `get_energy` gives frame by frame (the
     reference's loop), and the profile derived from it."""
-    monkeypatch.setenv("UMX_ALLOW_SYNTHETIC", "1")
     z, imgs, _ = synth.make_images(60, 5, seed=21)
     sym = [synth.SYMBOLS[int(q)] for q in z]
     p = tmp_path / "path.trj"
     F.write_trj_with_energy(sym, [np.asarray(x, dtype=np.float64) for x in imgs], [0.0] * len(imgs), p)
     with U.uma_pysis(model="synthetic") as calc:
-        with pytest.warns(RuntimeWarning):
-            en = F.recompute_energies(p, 0, 1, calc=calc)
+        en = F.recompute_energies(p, 0, 1, calc=calc)
         _, coords, _ = F.read_trj(p)
         one_by_one = [float(calc.get_energy(sym, (c * U.ANG2BOHR).reshape(-1))["energy"]) for c in coords]
         assert en == one_by_one

@@ -147,6 +147,16 @@ int umx_last_graph_stats(const umx_engine* eng, int64_t* n_edges_total, int32_t*
  * beyond that -- ~1.5x the atoms -- UMX_ERR_CAPACITY names the multi-GPU graph-parallel mode.                                    */
 int umx_last_partitions(const umx_engine* eng);
 
+/* Workspace hint (ABI v8): the caller expects batches of up to `n_images` images of the bound system.  The workspace grows with the largest
+ * batch seen, and every growth is a release + allocation of the whole region, which the driver clears at ~50 ms per GiB (2 s for the 43 GiB of
+ * twelve 500-atom images): a string that grows from 2 to 12 images paid that five times (7 s).  With the hint the next evaluation sizes the
+ * workspace ONCE for `n_images` images of the densest image it sees (+5 %), provided that fits the budget (UMX_WS_GB); larger batches still
+ * grow it, a hint that does not fit is ignored (the batch is chunked as usual).  0 clears the hint.  Re-binding a system keeps it.   */
+int umx_reserve_images(umx_engine* eng, int n_images);
+
+/* Size of the workspace in bytes and how often it has been (re-)allocated since umx_create (diagnostics, ABI v8).              */
+int umx_workspace_stats(const umx_engine* eng, int64_t* bytes, int32_t* allocations);
+
 /* Per-launch device time (HIP events on the launch stream) of three kernel families since the last reset.
  * Family 0 = split-precision LDS-DMA GEMMs (umx_gemm_q_kernel / umx_gemm_pl*_kernel: SO(2) / radial-fc3 linears and their transposes),
  * family 1 = fp32-MFMA GEMM (umx_gemm_kernel: small radial / atom-wise / readout linears; everything in fp32 mode),

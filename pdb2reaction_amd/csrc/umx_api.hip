@@ -138,6 +138,9 @@ struct umx_engine {
   int force_parts = 0;             // UMX_FORCE_PARTS (dev / tests): evaluate every image in this many target-node partitions
   int* d_part_deg = nullptr; float* d_part_f = nullptr; long part_cap = 0;
   int last_parts = 0;              // partitions used by the most recent evaluation (0: the ordinary path)
+  int arena_allocs = 0;            // how often the workspace has been (re-)allocated (umx_workspace_stats)
+  int hint_applied = 0;            // the hint value the workspace has been sized for already
+  int hint_images = 0;             // umx_reserve_images: size the workspace for this many images at the next growth
   // host io staging for the host-pointer entry point
   float* d_io_pos = nullptr; double* d_io_e = nullptr; float* d_io_f = nullptr; long io_cap = 0, io_img_cap = 0;
   // stats / profiling / debug
@@ -970,7 +973,7 @@ std::vector<float> transpose(const float* src, int rows, int cols) {
 // ================================================================================================
 extern "C" {
 
-int umx_abi_version(void) { return 7; }
+int umx_abi_version(void) { return 8; }
 
 #ifndef UMX_SRC_DIGEST
 #define UMX_SRC_DIGEST "unknown"
@@ -1518,6 +1521,7 @@ static int eval_partitioned(umx_engine* eng, hipStream_t s, const float* d_pos, 
     HIPCHK(eng, hipStreamSynchronize(eng->stream2));
     if (eng->arena) { HIPCHK(eng, hipFree(eng->arena)); eng->arena = nullptr; eng->arena_bytes = 0; }
     HIPCHK(eng, hipMalloc(&eng->arena, total));
+    ++eng->arena_allocs;
     eng->arena_bytes = total;
   }
   eng->cap_nodes = 0; eng->cap_edges = 0;                    // the ordinary path re-carves (and re-sizes) the arena on its next call
@@ -1682,15 +1686,35 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
     const long n_even = (long)((chunks.size() + 1) / 2 * 2);
     CHK(plan((K + n_even - 1) / n_even));
   }
-  if (need_nodes > eng->cap_nodes || need_edges > eng->cap_edges) {
+  // umx_reserve_images: the caller announced batches of up to hint_images images -- size the workspace once for that many images of the
+  // densest image at hand (+5 %) instead of growing it batch by batch (every growth re-allocates the whole region); ignored when it
+  // does not fit the budget
+  long hint_nodes = 0, hint_edges = 0;
+  if (eng->hint_images > 0 && !eng->gp && lanes == 1) {
+    long emax = 0;
+    for (long k = 0; k < K; ++k) emax = std::max(emax, (long)img_edges[k]);
+    hint_nodes = (long)eng->hint_images * N;
+    hint_edges = (long)eng->hint_images * (emax + emax / 20 + 64);
+    if ((hint_nodes <= eng->cap_nodes && hint_edges <= eng->cap_edges) || carve(nullptr, hint_nodes, hint_edges, nullptr, ws_mode(eng)) > budget) hint_nodes = hint_edges = 0;
+  }
+  // (the hint alone triggers ONE allocation; after that it only enlarges a growth the batches themselves ask for -- otherwise every batch
+  // whose densest image is a little denser than the last one's would re-allocate)
+  const bool hint_now = eng->hint_applied != eng->hint_images && (hint_nodes > eng->cap_nodes || hint_edges > eng->cap_edges);
+  if (eng->hint_images > 0 && (hint_nodes || hint_edges || eng->cap_nodes >= (long)eng->hint_images * N)) eng->hint_applied = eng->hint_images;
+  if (need_nodes > eng->cap_nodes || need_edges > eng->cap_edges || hint_now) {
     HIPCHK(eng, hipStreamSynchronize(s));
     HIPCHK(eng, hipStreamSynchronize(eng->stream2));
     if (eng->arena) { HIPCHK(eng, hipFree(eng->arena)); eng->arena = nullptr; eng->arena_bytes = 0; }
-    const long cn = std::max(need_nodes, eng->cap_nodes), ce = std::max(need_edges + need_edges / 50 + 1024, eng->cap_edges);
+    long cn = std::max(std::max(need_nodes, hint_nodes), eng->cap_nodes), ce = std::max(std::max(need_edges + need_edges / 50 + 1024, hint_edges), eng->cap_edges);
     size_t bytes = carve(nullptr, cn, ce, nullptr, ws_mode(eng));
+    if (bytes > budget && (hint_nodes || hint_edges)) {      // hint and need combined overshoot: size for the need alone
+      cn = std::max(need_nodes, eng->cap_nodes); ce = std::max(need_edges + need_edges / 50 + 1024, eng->cap_edges);
+      bytes = carve(nullptr, cn, ce, nullptr, ws_mode(eng));
+    }
     long ce2 = ce;
     if (bytes > budget) { ce2 = std::max(need_edges, 1L); bytes = carve(nullptr, cn, ce2, nullptr, ws_mode(eng)); }
     HIPCHK(eng, hipMalloc(&eng->arena, lanes * bytes));     // one workspace per lane
+    ++eng->arena_allocs;
     eng->arena_bytes = lanes * bytes; eng->cap_nodes = cn; eng->cap_edges = ce2;
   }
   WS wl[2];
@@ -1867,6 +1891,21 @@ int umx_last_graph_stats(const umx_engine* eng, int64_t* n_edges_total, int32_t*
 }
 
 int umx_last_partitions(const umx_engine* eng) { return eng ? eng->last_parts : 0; }
+
+int umx_workspace_stats(const umx_engine* eng, int64_t* bytes, int32_t* allocations) {
+  if (!eng) return UMX_ERR_ARG;
+  if (bytes) *bytes = (int64_t)eng->arena_bytes;
+  if (allocations) *allocations = eng->arena_allocs;
+  return UMX_OK;
+}
+
+int umx_reserve_images(umx_engine* eng, int n_images) {
+  if (!eng) return UMX_ERR_ARG;
+  if (n_images < 0) return fail(eng, UMX_ERR_ARG, "umx_reserve_images: n_images must be >= 0");
+  eng->hint_images = n_images;
+  if (n_images == 0) eng->hint_applied = 0;
+  return UMX_OK;
+}
 
 int umx_profile_enable(umx_engine* eng, int on) {
   if (!eng) return UMX_ERR_ARG;

@@ -80,6 +80,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "umx_synchronize": ([vp], i32),
         "umx_last_graph_stats": ([vp, i64p, C.POINTER(C.c_int32)], i32),
         "umx_last_partitions": ([vp], i32),
+        "umx_reserve_images": ([vp, i32], i32),
+        "umx_workspace_stats": ([vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32)], i32),
         "umx_profile_enable": ([vp, i32], i32),
         "umx_profile_read": ([vp, C.POINTER(ProfileStats), i32], i32),
         "umx_bond_changes": ([vp, i32, dp, dp, dp, C.c_double, C.c_double, C.c_double, dp, dp, C.POINTER(C.c_uint8)], i32),
@@ -117,7 +119,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 EXPORTED_SYMBOLS = (
     "umx_abi_version", "umx_build_digest", "umx_create", "umx_destroy", "umx_last_error", "umx_load_weights", "umx_set_precision", "umx_precision_mode", "umx_set_system",
     "umx_set_workspace_limit", "umx_energy_forces", "umx_energy_forces_dev", "umx_gp_begin", "umx_gp_step", "umx_synchronize",
-    "umx_last_graph_stats", "umx_last_partitions", "umx_profile_enable", "umx_profile_read", "umx_bond_changes", "umx_debug_fetch", "umx_debug_keep",
+    "umx_last_graph_stats", "umx_last_partitions", "umx_reserve_images", "umx_workspace_stats", "umx_profile_enable", "umx_profile_read", "umx_bond_changes", "umx_debug_fetch", "umx_debug_keep",
 )
 
 
@@ -281,6 +283,16 @@ class Engine:
         ne, md = C.c_int64(), C.c_int32()
         self._chk(self.lib.umx_last_graph_stats(self._h, C.byref(ne), C.byref(md)), "umx_last_graph_stats")
         return int(ne.value), int(md.value)
+
+    def reserve_images(self, n_images: int):
+        """Announce batches of up to ``n_images`` images: the next evaluation sizes the workspace once for that many (``umx_reserve_images``)."""
+        self._chk(self.lib.umx_reserve_images(self._h, int(n_images)), "umx_reserve_images")
+
+    def workspace_stats(self) -> Tuple[int, int]:
+        """(bytes of the HBM workspace, number of times it has been (re-)allocated)."""
+        b, n = C.c_int64(), C.c_int32()
+        self._chk(self.lib.umx_workspace_stats(self._h, C.byref(b), C.byref(n)), "umx_workspace_stats")
+        return int(b.value), int(n.value)
 
     def last_partitions(self) -> int:
         """Target-node partitions per image of the most recent evaluation (0: the ordinary path; see ``umx_last_partitions``)."""

@@ -22,6 +22,7 @@ from typing import Any, Callable, Dict, List, Optional, Sequence
 
 import numpy as np
 
+from ._host import with_small_host_math
 from .string import select_hei_index
 
 # reference path_opt.py:168-185
@@ -163,6 +164,8 @@ class GrowingStringDriver:
             raise ValueError("reactant/product must both be (3N,) for the given atoms")
         self.calc, self._evaluate, self.log = calc, evaluate, (log or (lambda s: None))
         self.max_images = int(self.gs["max_nodes"]) + 2
+        if hasattr(calc, "reserve_images"):                  # the string grows to max_images: one workspace allocation instead of one per growth
+            calc.reserve_images(self.max_images)
         step = 1.0 / (self.max_images - 1)
         if self.max_images <= 3:
             self.left, self.right = [r], [p]
@@ -251,6 +254,7 @@ class GrowingStringDriver:
         return grew
 
     # ---- main loop -----------------------------------------------------------------------------------
+    @with_small_host_math
     def run(self) -> GSMResult:
         gs, opt = self.gs, self.opt
         max_f, rms_f, _, _ = THRESH[opt["thresh"]] if isinstance(opt["thresh"], str) else opt["thresh"]

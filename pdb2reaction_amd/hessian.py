@@ -13,6 +13,7 @@ from typing import Callable, Dict, List, Sequence, Tuple
 import numpy as np
 
 from ._calculator_base import ANG2BOHR, AU2EV
+from ._host import with_small_host_math
 
 EV_TO_HARTREE = 1.0 / AU2EV
 EV_PER_ANG_TO_AU = EV_TO_HARTREE / ANG2BOHR
@@ -37,6 +38,7 @@ def mask_frozen(forces: np.ndarray, frozen: Sequence[int]) -> np.ndarray:
     return out
 
 
+@with_small_host_math
 def fd_hessian(batch_forces: Callable[[np.ndarray], np.ndarray], coord_ang: np.ndarray, frozen: Sequence[int], *, device,
                double: bool, partial: bool, batch: int = 64, step: float = FD_STEP_ANG, shard: bool = False, group=None, engine=None):
     """Central-difference Hessian in eV/A^2 as a torch tensor (n_out, 3, n_out, 3) on `device`.

@@ -17,6 +17,7 @@ from typing import Dict, Optional, Sequence, Union
 
 import numpy as np
 
+from ._host import with_small_host_math
 from .gsm import THRESH
 
 
@@ -100,6 +101,7 @@ class BatchedLBFGS:
             ok = np.abs(s).max() <= max_s and np.sqrt(np.mean(s * s)) <= rms_s
         return bool(ok)
 
+    @with_small_host_math
     def run(self) -> Dict[str, np.ndarray]:
         s_hist = [[] for _ in range(self.k)]
         y_hist = [[] for _ in range(self.k)]

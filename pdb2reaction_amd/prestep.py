@@ -15,6 +15,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from ._calculator_base import ANG2BOHR
+from ._host import with_small_host_math
 from .hessian import EV_PER_ANG2_TO_AU
 
 
@@ -209,6 +210,7 @@ def align_second_to_first(ref_bohr: np.ndarray, mob_bohr: np.ndarray, anchors: S
     return out, {"before_A": before, "after_A": after, "n_used": int(use.sum()), "mode": "kabsch"}
 
 
+@with_small_host_math
 def scan_toward_target(calc, elem, ref_bohr: np.ndarray, mob_bohr: np.ndarray, anchors: Sequence[int], *, step_A: float = 0.1,
                        per_step_cycles: int = 50, final_cycles: int = 200, max_steps: int = 1000, thresh="gau", verbose: bool = False):
     """Staged scan of ONE OR MORE mobile images toward their references (reference
@@ -271,6 +273,7 @@ def align_and_refine_pair(calc, elem, ref_bohr, mob_bohr, freeze_ref=(), freeze_
     return out, {"align": a_info, "scan": s_info}
 
 
+@with_small_host_math
 def align_and_refine_sequence(calc, elem, coords_list, freeze_list=None, *, batched: bool = True, **scan_kw):
     """Pairs (g0<-g1), (g1<-g2), ... along a list of geometries (reference ``align_and_refine_sequence_inplace``).
 

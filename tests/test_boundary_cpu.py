@@ -26,11 +26,11 @@ def header_functions():
 def test_library_exports_every_declared_symbol():
     lib = E.load_library()
     names = header_functions()
-    assert len(names) >= 21
+    assert len(names) >= 23
     for n in names:
         assert hasattr(lib, n), f"libumx.so does not export {n} declared in include/umx.h"
     assert sorted(E.EXPORTED_SYMBOLS) == names
-    assert lib.umx_abi_version() == 7
+    assert lib.umx_abi_version() == 8
 
 
 def test_missing_library_is_loud(tmp_path):

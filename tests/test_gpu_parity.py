@@ -637,3 +637,44 @@ def test_two_lane_execution_is_bitwise_identical(weights, monkeypatch):
     e0, f0 = res[("1", "512")]
     for key, (e, f) in res.items():
         assert np.array_equal(e, e0) and np.array_equal(f, f0), key
+
+
+def test_reserve_images_allocates_the_workspace_once(weights):
+    """umx_reserve_images (ABI v8): with the hint the first evaluation sizes the workspace for the announced batch, and batches up to that
+    size no longer re-allocate it (device memory in use stays put); without it every larger batch grows it.  Results are unaffected."""
+    import torch
+    from pdb2reaction_amd.engine import Engine
+
+    z, imgs, _ = synth.make_images(150, 6, seed=4)
+
+    def used():
+        torch.cuda.synchronize()
+        fr, tot = torch.cuda.mem_get_info(0)
+        return tot - fr
+
+    plain, hinted = Engine(0), Engine(0)
+    try:
+        for e_ in (plain, hinted):
+            e_.load_weights(weights)
+            e_.set_system(z)
+        hinted.reserve_images(6)
+        base = used()
+        e2, f2 = hinted.energy_forces(imgs[:2])
+        after_first = used()
+        e4, f4 = hinted.energy_forces(imgs[:4])
+        e6, f6 = hinted.energy_forces(imgs)
+        ws_bytes, n_alloc = hinted.workspace_stats()
+        assert n_alloc == 1 and ws_bytes > 0                    # ONE allocation served the 2-, 4- and 6-image batches
+        assert used() - after_first < 0.05 * ws_bytes           # only the small per-batch I/O buffers grew
+        assert after_first - base >= ws_bytes
+        p2, _ = plain.energy_forces(imgs[:2])
+        mid = used()
+        p6, pf6 = plain.energy_forces(imgs)
+        assert plain.workspace_stats()[1] == 2 and plain.workspace_stats()[0] <= ws_bytes     # without the hint: one allocation per growth
+        assert np.array_equal(p6, e6) and np.array_equal(pf6, f6) and np.array_equal(p2, e2) and np.array_equal(e4, e6[:4])
+        hinted.reserve_images(0)
+        with pytest.raises(Exception):
+            hinted.reserve_images(-1)
+    finally:
+        plain.close()
+        hinted.close()

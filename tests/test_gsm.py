@@ -133,3 +133,26 @@ def test_spline_tangents_follow_the_curve():
     assert err_s < 5e-3 and err_s < 0.1 * err_c                    # one-sided end differences are the weak spot of "central"
     assert np.allclose(np.linalg.norm(ts, axis=1), 1.0)
     assert np.array_equal(_tangents(x[:3], "spline"), _tangents(x[:3], "central"))     # too few images: fallback
+
+
+def test_driver_announces_the_final_string_size_to_the_calculator():
+    """The string grows to max_nodes + 2 images: the driver says so up front (`reserve_images`), so that the engine allocates its workspace
+    once instead of once per growth (seconds each on the GPU); calculators without the method are left alone."""
+    class Announced(MuellerBrown):
+        def __init__(self):
+            super().__init__()
+            self.reserved = []
+
+        def reserve_images(self, n):
+            self.reserved.append(n)
+
+    calc = Announced()
+    GrowingStringDriver(["X"], MIN_A, MIN_B, calc, gs_kw={"max_nodes": 7})
+    assert calc.reserved == [9]
+    GrowingStringDriver(["X"], MIN_A, MIN_B, MuellerBrown(), gs_kw={"max_nodes": 7})      # no such method: nothing happens
+
+    import importlib
+    U = importlib.import_module("pdb2reaction_amd.uma_pysis")
+    c = U.uma_pysis()
+    c.reserve_images(12)                                       # before the engine exists: kept and applied when the core is built
+    assert c._reserve_images == 12 and c._core is None

@@ -43,6 +43,29 @@ def small_host_math(threads=None):
         yield
 
 
+_CAPPED = None
+
+
+def cap_pools_to_usable_cores() -> int:
+    """Once per process: BLAS / OpenMP pools that are larger than the cores this process may use are cut down to that number, for good.
+    A pool sized for the whole machine inside a CPU-quota container is the mis-configuration described in the module docstring; a
+    limit <= the quota measured 56 ms per call where 32 and 64 threads gave 95 (``tools/gpu_batch_latency2.py``).  Called when a
+    calculator creates its engine, so that callers this package does not control (an external optimiser stepping through
+    ``get_forces``) are covered too.  ``UMX_HOST_THREADS=0`` disables it.  Returns the cap applied (0: nothing done)."""
+    global _CAPPED
+    if _CAPPED is not None or os.environ.get("UMX_HOST_THREADS", "1") == "0":
+        return 0
+    try:
+        from threadpoolctl import threadpool_info, threadpool_limits
+    except ImportError:
+        return 0
+    cores = usable_cores()
+    if not any(p.get("num_threads", 0) > cores for p in threadpool_info()):
+        return 0
+    _CAPPED = threadpool_limits(limits=cores)    # kept alive: the limits stay until the process ends
+    return cores
+
+
 def with_small_host_math(fn):
     """Decorator form of :func:`small_host_math` for a driver's entry point."""
     @functools.wraps(fn)

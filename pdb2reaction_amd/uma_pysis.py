@@ -29,6 +29,7 @@ import numpy as np
 
 from ._calculator_base import ANG2BOHR, AU2EV, BOHR2ANG, Calculator  # noqa: F401
 from . import hessian as H
+from ._host import cap_pools_to_usable_cores
 from . import synth
 from . import weights as W
 
@@ -155,6 +156,7 @@ class UMAcore:
         self.z = synth.symbols_to_z(self.elem)
         W.check_merged_for(weights, self.z, charge, spin, task_name)   # a MoLE merge is valid for one system only
         self.engine = Engine(_device_index(device), precision=precision)     # None: UMX_PRECISION (default "auto")
+        cap_pools_to_usable_cores()                       # BLAS pools sized for the machine inside a CPU-quota container starve the GPU feeder
         self.engine.load_weights(weights)
         self.engine.set_system(self.z, charge=charge, spin=spin, task=task_name, radius=radius, max_neigh=max_neigh)
         self._gp = None

@@ -1,6 +1,7 @@
 """Why does a batched call take 97 ms inside a growing-string run and 55 ms in a tight loop?  (dev)  Variants by argv[1]:
 plain | torch (torch.cuda initialised first) | sleep (5 ms of host sleep between calls) | numpy (5 ms of numpy work between calls) |
-calc (through uma_pysis.get_forces_batch)"""
+calc (through uma_pysis.get_forces_batch) | calcnumpy (calc + numpy work: the calculator caps the BLAS pools) |
+numpy<N> (numpy with the pools limited to N threads)"""
 import sys
 import time
 
@@ -8,7 +9,7 @@ import numpy as np
 
 sys.path.insert(0, ".")
 mode = sys.argv[1] if len(sys.argv) > 1 else "plain"
-if mode in ("torch", "calc"):
+if mode in ("torch", "calc", "calcnumpy"):
     import torch
     torch.zeros(1, device="cuda")
 from pdb2reaction_amd import synth, weights as W  # noqa: E402
@@ -16,7 +17,7 @@ from pdb2reaction_amd.engine import Engine  # noqa: E402
 
 z, imgs, _ = synth.make_images(500, 12)
 x10 = imgs[:10].copy()
-if mode == "calc":
+if mode in ("calc", "calcnumpy"):
     import importlib
     U = importlib.import_module("pdb2reaction_amd.uma_pysis")
     calc = U.uma_pysis(model="synthetic")
@@ -28,11 +29,12 @@ else:
     eng.set_system(z)
     call = lambda x: eng.energy_forces(x)
 call(imgs)
-if mode == "numpy1":
+if mode.startswith("numpy") and mode != "numpy":
     from threadpoolctl import threadpool_limits
-    threadpool_limits(limits=1)
+    nthr = int(mode[5:])
+    threadpool_limits(limits=nthr)
     mode = "numpy"
-    label = "numpy, BLAS limited to 1 thread"
+    label = f"numpy, BLAS limited to {nthr} thread(s)"
 else:
     label = mode
 import os
@@ -42,7 +44,7 @@ a = np.random.default_rng(0).normal(size=(600, 600))
 for i in range(12):
     if mode == "sleep":
         time.sleep(0.005)
-    if mode == "numpy":
+    if mode in ("numpy", "calcnumpy"):
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < 0.005:
             a @ a

@@ -169,6 +169,7 @@ def main():
         eng = Engine(local_rank)
         eng.load_weights(weights)
         eng.set_system(z, charge=0, spin=1, task="omol")
+        eng.reserve_images(kl_max)                          # a long run of fixed-size batches: workspace for the whole shard, allocated once
         x = torch.as_tensor(imgs * ANG2BOHR, dtype=torch.float64, device=dev)       # string state: Bohr, float64, in HBM
         pos32 = torch.empty(kl_max, n, 3, dtype=torch.float32, device=dev)
         e_loc = torch.empty(kl_max, dtype=torch.float64, device=dev)

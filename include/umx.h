@@ -90,7 +90,12 @@ const char* umx_precision_mode(const umx_engine* eng);
 int umx_set_system(umx_engine* eng, int n_atoms, const int32_t* atomic_numbers, int charge,
                    int spin, int task_index, float radius, int max_neigh);
 
-/* Optional: cap the device workspace (bytes; 0 = automatic from free HBM).                     */
+/* Optional: cap the device workspace (bytes; 0 = automatic from free HBM).
+ * How much of the cap is used (ABI v8): device memory costs ~45 ms per GiB to allocate on this driver, so the workspace is amortised.
+ * Without a hint it starts at chunks of ~320 000 directed edges (UMX_WS_SOFT_EDGES; at least one image; within 3 % of the speed of the
+ * largest chunks) and is enlarged to hold the whole batch -- up to the cap -- once the engine has been evaluating for 8x as long as that
+ * allocation takes; umx_reserve_images announces a long run of known batches and sizes it at once.  UMX_WS_EAGER=1: always size it for
+ * the whole batch (the behaviour before v8).  Results do not depend on the chunking (bitwise).                                    */
 int umx_set_workspace_limit(umx_engine* eng, size_t bytes);
 
 /* Energy (+ forces) of `n_images` geometries of the bound system in ONE batched evaluation.

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -139,6 +140,9 @@ struct umx_engine {
   int* d_part_deg = nullptr; float* d_part_f = nullptr; long part_cap = 0;
   int last_parts = 0;              // partitions used by the most recent evaluation (0: the ordinary path)
   int arena_allocs = 0;            // how often the workspace has been (re-)allocated (umx_workspace_stats)
+  bool ws_eager = false;           // UMX_WS_EAGER=1: size the workspace for the whole batch at once (the behaviour before ABI v8)
+  long ws_soft_edges = 320000;     // UMX_WS_SOFT_EDGES: directed edges per chunk the workspace starts with when nothing else is known
+  double t_first_eval = -1.0;      // steady-clock seconds of the first evaluation (amortised workspace growth)
   int hint_applied = 0;            // the hint value the workspace has been sized for already
   int hint_images = 0;             // umx_reserve_images: size the workspace for this many images at the next growth
   // host io staging for the host-pointer entry point
@@ -1009,6 +1013,8 @@ int umx_create(umx_engine** out, int device_ordinal) {
   if (const char* ev = std::getenv("UMX_SIDE")) e->side = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_FORCE_PARTS")) e->force_parts = std::max(0, std::min(16, std::atoi(ev)));
   if (const char* ev = std::getenv("UMX_WS_GB")) e->ws_cap_default = (size_t)std::max(0L, std::atol(ev)) << 30;
+  if (const char* ev = std::getenv("UMX_WS_EAGER")) e->ws_eager = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("UMX_WS_SOFT_EDGES")) e->ws_soft_edges = std::max(1L, std::atol(ev));
   if (const char* ev = std::getenv("UMX_AUTO_BF16_ATOMS")) e->auto_atoms = std::max(0, std::atoi(ev));
   if (const char* ev = std::getenv("UMX_NODE_F64")) e->node_f64_on = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_DEG_SPLIT")) e->deg_split = std::atoi(ev) != 0;
@@ -1633,6 +1639,26 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
   }
   int lanes = (eng->n_lanes >= 2 && K >= 2 && !eng->dbg_on && !eng->gp) ? 2 : 1;      // debug captures name ONE chunk's buffers
   budget /= lanes;
+  // Amortised workspace (ABI v8).  Allocating device memory costs ~45 ms per GiB on this driver (it is cleared), so a workspace sized for the
+  // whole batch -- up to the 160 GiB cap: 7 s -- is only worth it for a run that lasts: a one-off finite-difference Hessian of a 500-atom
+  // system spent 11 of its 15 s allocating.  Chunks of ~320 k directed edges already run within 3 % of the largest ones (DESIGN.md section
+  // 7), so without a hint (umx_reserve_images, which announces a long run of known batches) the workspace starts at that size and grows to
+  // what the batch would like only once the engine has been evaluating for 8x as long as the larger allocation takes.
+  {
+    const double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (eng->t_first_eval < 0.0) eng->t_first_eval = now;
+    if (!eng->ws_eager && eng->hint_images == 0 && !eng->gp && !eng->dbg_on && eng->force_parts < 2) {
+      long emax = 1, etot = 0;
+      for (long k = 0; k < K; ++k) { emax = std::max(emax, (long)img_edges[k]); etot += img_edges[k]; }
+      const long per = std::max(1L, (eng->ws_soft_edges + emax - 1) / emax);                      // images per chunk for ~ws_soft_edges
+      const size_t want = carve(nullptr, per * N, per * (emax + emax / 20 + 64), nullptr, ws_mode(eng));
+      const size_t cur = eng->cap_nodes > 0 ? carve(nullptr, eng->cap_nodes, eng->cap_edges, nullptr, ws_mode(eng)) : 0;
+      size_t soft = std::min(budget, std::max(want, cur));
+      const size_t full = std::min(budget, carve(nullptr, K * N, etot + etot / 50 + 1024, nullptr, ws_mode(eng)));
+      if (full > soft && (now - eng->t_first_eval) >= 8.0 * 0.045 * (double)(full >> 20) / 1024.0) soft = full;
+      budget = soft;
+    }
+  }
   long max_chunk = (K + lanes - 1) / lanes;          // at least `lanes` chunks so both streams have work
   if (const char* ev = std::getenv("UMX_MAX_CHUNK_IMAGES")) { long v = std::atol(ev); if (v > 0) max_chunk = std::min(max_chunk, v); }
   std::vector<std::pair<long, long>> chunks;   // [k0, k1)

@@ -52,6 +52,8 @@ class BatchedLBFGS:
     def __init__(self, calc, elem: Sequence[str], coords_bohr: np.ndarray, *, freeze: Optional[Union[Sequence[int], Sequence[Sequence[int]]]] = None,
                  thresh: Union[str, tuple] = "gau", max_cycles: int = 50, max_step: float = 0.2, keep_last: int = 7, beta: float = 1.0):
         self.calc = calc
+        if hasattr(calc, "reserve_images"):               # a long run of K-image batches: one workspace allocation (umx_reserve_images)
+            calc.reserve_images(np.asarray(coords_bohr).shape[0] if np.asarray(coords_bohr).ndim == 3 else 1)
         self.elem = list(elem)
         x = np.array(coords_bohr, dtype=np.float64)
         if x.ndim == 2:

@@ -5,7 +5,7 @@ from pdb2reaction_amd import weights as W, synth
 from pdb2reaction_amd.engine import Engine
 eng = Engine(0); eng.load_weights(W.make_synthetic_weights(0))
 for name, n, k in (("c1", 50, 8), ("c2", 500, 12), ("c3", 2000, 16), ("c4-string", 2000, 24), ("c5", 20000, 8)):
-    z, imgs, _ = synth.make_images(n, k); eng.set_system(z)
+    z, imgs, _ = synth.make_images(n, k); eng.set_system(z); eng.reserve_images(k)
     eng.energy_forces(imgs)
     reps = 20 if n <= 500 else 2
     t = time.time()

@@ -35,6 +35,7 @@ for name in which:
         eng = Engine(0)
         eng.load_weights(w)
         eng.set_system(z)
+        eng.reserve_images(len(pos))
         eng.energy_forces(pos)
         t = time.perf_counter()
         e, f = eng.energy_forces(pos)

@@ -17,6 +17,7 @@ eng = Engine(0)
 eng.load_weights(W.make_synthetic_weights(0))
 z, imgs, _ = synth.make_images(n, k)
 eng.set_system(z)
+eng.reserve_images(k)                      # steady-state timing of fixed batches: workspace for the whole batch, allocated once
 eng.energy_forces(imgs)
 eng.energy_forces(imgs)
 t = time.perf_counter()

@@ -13,6 +13,7 @@ eng.load_weights(w)
 for k in ks:
     z, imgs, frozen = synth.make_images(n, k)
     eng.set_system(z)
+    eng.reserve_images(k)
     p = imgs.astype(np.float32)
     e, f = eng.energy_forces(p)          # warm-up + allocation
     ne, md = eng.graph_stats()

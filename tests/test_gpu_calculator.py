@@ -127,6 +127,19 @@ def test_ase_style_calculator(oracle, setup):
     e_c = calc.get_potential_energy(charged)
     e_cref, _ = oracle.energy_forces(z, imgs[0].astype(np.float32).astype(np.float64), charge=-1, spin=2, forces=False)
     assert abs(e_c - e_cref) <= 1e-4 and abs(e_c - e0) > 1e-3
+    # energy then forces of an UNCHANGED image is one evaluation (torch_dmf asks for both, image by image); any change evaluates again
+    calls = []
+    orig = calc._engine.energy_forces
+    calc._engine.energy_forces = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    im = FakeAtoms(z, imgs[1].astype(np.float32))
+    e1 = calc.get_potential_energy(im)
+    f1 = calc.get_forces(im)
+    assert len(calls) == 1 and calc.get_potential_energy(im) == e1 and len(calls) == 1
+    im._p = im._p + np.float32(0.01)
+    f2 = calc.get_forces(im)
+    assert len(calls) == 2 and not np.array_equal(f1, f2)
+    calc.get_forces(charged)                                   # other charge / spin: re-bound, evaluated
+    assert len(calls) == 3
 
 
 def test_gsm_driver_on_the_engine(tmp_path, setup):

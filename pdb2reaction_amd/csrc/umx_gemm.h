@@ -255,12 +255,15 @@ template <int AMODE>
 __global__ __launch_bounds__(256) void k_gemm_f64acc(const GemmP p) {
   // v_mfma_f64_16x16x4_f64 (same peak as the f64 VALU on this part, but a quarter of the LDS operand traffic per FLOP: a VALU version
   // with 4 x 4 register tiles ran LDS-bound at 26 % of the f64 peak).  64 x 64 tile, 4 waves as 2 x 2, each wave 2 x 2 MFMA tiles;
-  // operands converted to double once, while staging.  LDS rows of 80 doubles: the four k-groups of a fragment read land 32 banks
-  // apart, so each 32-lane half of a ds_read_b64 touches 32 distinct bank pairs.
+  // operands converted to double once, while staging.  LDS tiles are ROW-major [64 rows][32 k] with rows of 34 doubles (68 dwords = 4 banks
+  // past a multiple of 64): a staging store writes 32 consecutive doubles of one row per half-wave (all 64 banks once), a fragment read
+  // takes 16 rows x 2 k per half-wave = bank pairs 4 i + 2 k, all distinct.  (The first version staged k-major with rows of 80 doubles:
+  // conflict-free reads, but the 32 k of a staging store fell on 2 bank pairs -- 16-way conflicts that made the kernel LDS-write bound
+  // at 28 % of the f64 matrix peak.)
   // Lane maps (cdna_hip_programming.md): A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]; D: col = l & 15, row = (l >> 4) + 4 reg.
-  constexpr int LD = 80;
-  __shared__ double As[32][LD];
-  __shared__ double Bs[32][LD];
+  constexpr int LD = 34;
+  __shared__ double As[64][LD];
+  __shared__ double Bs[64][LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lk = lane >> 4;
   const int nN = (p.N + 63) / 64;
@@ -290,8 +293,8 @@ __global__ __launch_bounds__(256) void k_gemm_f64acc(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int idx = tid + 256 * i, r = idx >> 5, kk = idx & 31;
-      As[kk][r] = (double)(AMODE == A_SILU ? silu_f(ra[i]) : ra[i]);
-      Bs[kk][r] = (double)rb[i];
+      As[r][kk] = (double)(AMODE == A_SILU ? silu_f(ra[i]) : ra[i]);
+      Bs[r][kk] = (double)rb[i];
     }
     __syncthreads();
     if (k0 + 32 < p.K) fetch(k0 + 32);
@@ -300,8 +303,8 @@ __global__ __launch_bounds__(256) void k_gemm_f64acc(const GemmP p) {
       double a[2], b[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        a[t] = As[ks * 4 + lk][wm * 32 + t * 16 + l15];
-        b[t] = Bs[ks * 4 + lk][wn * 32 + t * 16 + l15];
+        a[t] = As[wm * 32 + t * 16 + l15][ks * 4 + lk];
+        b[t] = Bs[wn * 32 + t * 16 + l15][ks * 4 + lk];
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)

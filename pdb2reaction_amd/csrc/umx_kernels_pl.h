@@ -14,13 +14,28 @@ namespace umx {
 template <int P> __device__ __forceinline__ long pl_index(int k) { return (long)(k >> 5) * (32 * P) + (k & 31); }
 
 // split 2 adjacent values into P planes and store them (k even): 4-byte store per plane
+// dev switch (-DUMX_NT=1): non-temporal stores for the write-once operand planes (A/B measurement in DESIGN.md section 9)
+#ifndef UMX_NT
+#define UMX_NT 0
+#endif
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_stream(unsigned int* p, unsigned int v) {
+  if (UMX_NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+__device__ __forceinline__ void st_stream(uint2* p, uint2 v) {
+  if (UMX_NT) __builtin_nontemporal_store(u32x2_t{v.x, v.y}, reinterpret_cast<u32x2_t*>(p)); else *p = v;
+}
+__device__ __forceinline__ void st_stream(uint4* p, uint4 v) {
+  if (UMX_NT) __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(p)); else *p = v;
+}
 template <int P> __device__ __forceinline__ void pl_store2(unsigned short* row, int k, float x0, float x1) {
   unsigned short* d = row + pl_index<P>(k);
 #pragma unroll
   for (int q = 0; q < P; ++q) {
     const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
     const unsigned int pk = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
-    *reinterpret_cast<unsigned int*>(d + q * 32) = pk;
+    st_stream(reinterpret_cast<unsigned int*>(d + q * 32), pk);
     x0 -= (float)h0; x1 -= (float)h1;
   }
 }
@@ -33,7 +48,7 @@ template <int P> __device__ __forceinline__ void pl_store4(unsigned short* row, 
     unsigned short hb[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) { const __bf16 h = (__bf16)x[c]; hb[c] = __builtin_bit_cast(unsigned short, h); x[c] -= (float)h; }
-    *reinterpret_cast<uint2*>(d + q * 32) = make_uint2((unsigned int)hb[0] | ((unsigned int)hb[1] << 16), (unsigned int)hb[2] | ((unsigned int)hb[3] << 16));
+    st_stream(reinterpret_cast<uint2*>(d + q * 32), make_uint2((unsigned int)hb[0] | ((unsigned int)hb[1] << 16), (unsigned int)hb[2] | ((unsigned int)hb[3] << 16)));
   }
 }
 
@@ -72,14 +87,14 @@ template <int FMT> __device__ __forceinline__ void q_store2(unsigned short* base
   unsigned int w[QFmt<FMT>::P];
   q_split2<FMT>(x0, x1, w);
 #pragma unroll
-  for (int q = 0; q < QFmt<FMT>::P; ++q) *reinterpret_cast<unsigned int*>(d + q * 16) = w[q];
+  for (int q = 0; q < QFmt<FMT>::P; ++q) st_stream(reinterpret_cast<unsigned int*>(d + q * 16), w[q]);
 }
 template <int FMT> __device__ __forceinline__ void q_store4(unsigned short* base, long row, int cols, int k, float4 v) {
   unsigned short* d = q_ptr<FMT>(base, row, cols, k);
   unsigned int a[QFmt<FMT>::P], b[QFmt<FMT>::P];
   q_split2<FMT>(v.x, v.y, a); q_split2<FMT>(v.z, v.w, b);
 #pragma unroll
-  for (int q = 0; q < QFmt<FMT>::P; ++q) *reinterpret_cast<uint2*>(d + q * 16) = make_uint2(a[q], b[q]);
+  for (int q = 0; q < QFmt<FMT>::P; ++q) st_stream(reinterpret_cast<uint2*>(d + q * 16), make_uint2(a[q], b[q]));
 }
 
 #define UMX_WAVE_ITEM_PL(idx, count)                                                  \
@@ -269,10 +284,13 @@ __global__ __launch_bounds__(256) void k_gate_edge_fwd_q3(const float* __restric
   const float4 s1 = make_float4(sigmoid_f(g1.x), sigmoid_f(g1.y), sigmoid_f(g1.z), sigmoid_f(g1.w));
   const float4 s2 = make_float4(sigmoid_f(g2.x), sigmoid_f(g2.y), sigmoid_f(g2.z), sigmoid_f(g2.w));
   unsigned char* gbase = reinterpret_cast<unsigned char*>(hid) + (e0 >> 2) * (long)(ROW / 16) * BLK;
+  float4 vr[9];                                                                  // all nine rows requested up front: the barriers in the loop
+#pragma unroll                                                                   // below are memory fences the compiler will not move a load across
+  for (int r = 0; r < 9; ++r) vr[r] = *reinterpret_cast<const float4*>(p + 2 * H + r * H + c);
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
     const int buf = r & 1;
-    const float4 v = *reinterpret_cast<const float4*>(p + 2 * H + r * H + c);
+    const float4 v = vr[r];
     float x[4];
     if (r == 0) { x[0] = silu_f(v.x); x[1] = silu_f(v.y); x[2] = silu_f(v.z); x[3] = silu_f(v.w); }
     else {
@@ -294,7 +312,7 @@ __global__ __launch_bounds__(256) void k_gate_edge_fwd_q3(const float* __restric
       const int g = ch / CPG, o = ch % CPG;
       if (ch < 2 * CPG && e0 + 4 * g < ne) {      // the second row group may lie entirely beyond the (4-row padded) buffer
         const uint4 val = reinterpret_cast<const uint4*>(&stage[buf][g][0][0][0])[o];
-        reinterpret_cast<uint4*>(gbase + (long)g * (ROW / 16) * BLK + (long)r * 8 * BLK)[o] = val;
+        st_stream(reinterpret_cast<uint4*>(gbase + (long)g * (ROW / 16) * BLK + (long)r * 8 * BLK) + o, val);
       }
     }
   }

@@ -15,6 +15,7 @@
 #pragma once
 #include "umx_common.h"
 #include "umx_gemm.h"
+#include "umx_gemm_q.h"
 #include "umx_kernels_pl.h"
 
 namespace umx {
@@ -119,12 +120,68 @@ __device__ __forceinline__ void rad_mma(const float* __restrict__ a_lds, const f
   }
 }
 
+// fp16 form of the two small linears (MM = 1, default mode only): the activations of a tile sit in LDS as TWO IEEE-half planes of 16 x
+// (what the large forward GEMMs use, umx_kernels_pl.h QFmt<1>), written ONCE by the row pass that produces them; the weights of the
+// lane's column sit in registers as THREE half planes of s x W (exact: 33 bits; s = a power of two per column).  Four products per
+// 16-k step on v_mfma_f32_32x32x16_f16 -- a_hi w0, a_hi w1, a_lo w0, a_hi w2, as umx_gemm_q.h -- instead of eight v_mfma_f32_32x32x2_f32:
+// a quarter of the matrix-pipe cycles.  Both linears feed a LayerNorm, so a gain error of the half MFMA's adder cancels.
+struct WPlanes { f16x8_t w0, w1, w2; };
+template <int NT>
+__device__ __forceinline__ float rad_load_wplanes(const float* __restrict__ wrow, int h, WPlanes (&out)[NT]) {
+  float x[NT][8];
+  float mx = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const float4 a = *reinterpret_cast<const float4*>(wrow + 16 * t + 8 * h), b = *reinterpret_cast<const float4*>(wrow + 16 * t + 8 * h + 4);
+    x[t][0] = a.x; x[t][1] = a.y; x[t][2] = a.z; x[t][3] = a.w; x[t][4] = b.x; x[t][5] = b.y; x[t][6] = b.z; x[t][7] = b.w;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(x[t][j]));
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));                      // both k-halves of the column
+  int e = 0;
+  if (mx > 0.f) (void)frexpf(mx, &e);                       // mx = m 2^e, m in [0.5, 1)
+  const float sc = ldexpf(1.0f, 15 - e);                    // s |W| < 2^15
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = x[t][j] * sc;
+      const _Float16 a = (_Float16)v;
+      const float r1 = v - (float)a;
+      const _Float16 b = (_Float16)r1;
+      const _Float16 c = (_Float16)(r1 - (float)b);
+      out[t].w0[j] = a; out[t].w1[j] = b; out[t].w2[j] = c;
+    }
+  return 1.0f / (QF16_SCALE * sc);
+}
+// ROWB = bytes per LDS row, PLB = bytes per plane within a row
+template <int NT, int ROWB, int PLB, int TR>
+__device__ __forceinline__ void rad_mma_f16(const unsigned char* __restrict__ a_lds, const WPlanes (&w)[NT], f32x16 (&acc)[TR], int l31, int h) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    f16x8_t ah[TR], al[TR];
+#pragma unroll
+    for (int i = 0; i < TR; ++i) {
+      const unsigned char* p = a_lds + (i * 32 + l31) * ROWB + (16 * t + 8 * h) * 2;
+      ah[i] = *reinterpret_cast<const f16x8_t*>(p);
+      al[i] = *reinterpret_cast<const f16x8_t*>(p + PLB);
+    }
+#pragma unroll
+    for (int i = 0; i < TR; ++i) {
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], w[t].w0, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], w[t].w1, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], w[t].w0, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], w[t].w2, acc[i], 0, 0, 0);
+    }
+  }
+}
+
 // ---- forward: d, Z_src, Z_dst  ->  h1pre, h2pre (kept for the reverse pass) and the fc3 operand --------------------------------
 // OUTQ3 = 1: the fc3 operand as Q3 bf16 planes (umx_gemm_q.h), 2: as fp16 two-plane "Q2H" planes (QFmt<1>);  0: fp32 rows (fp32
 // precision mode, and the edge-degree MLP whose fc3 runs on the fp32 GEMM).   ts / tt: per-element tables of the embedding part of fc1 (tt includes the fc1 bias).
 // TR = 32-row MFMA tiles per workgroup tile (RT = 32 TR edges).  TR = 1 halves the LDS and accumulator footprint so that three
 // workgroups share a CU: the VALU-heavy LayerNorm passes of one overlap the MFMAs of the others (measured against TR = 2 below).
-template <int OUTQ3, int FAST, int TR>
+template <int OUTQ3, int FAST, int TR, int MM = 0>
 __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const float* __restrict__ evec, const int* __restrict__ ez, double gcoef,
                                                         const double* __restrict__ gmu, const float* __restrict__ w1g,
                                                         const double* __restrict__ ts, const double* __restrict__ tt,
@@ -140,11 +197,18 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int col = wave * 32 + l31;                   // the output column this lane owns in both linears
-  float4 W1[NG / 8], W2[RH / 8];
+  float4 W1[MM ? 1 : NG / 8], W2[MM ? 1 : RH / 8];
+  WPlanes P1[MM ? NG / 16 : 1], P2[MM ? RH / 16 : 1];
+  float inv1 = 1.0f, inv2 = 1.0f;                    // 1 / (16 s) of the lane's column (MM = 1)
+  if constexpr (MM == 0) {
 #pragma unroll
-  for (int c = 0; c < NG / 8; ++c) W1[c] = *reinterpret_cast<const float4*>(w1g + col * NG + c * 8 + 4 * h);
+    for (int c = 0; c < NG / 8; ++c) W1[c] = *reinterpret_cast<const float4*>(w1g + col * NG + c * 8 + 4 * h);
 #pragma unroll
-  for (int c = 0; c < RH / 8; ++c) W2[c] = *reinterpret_cast<const float4*>(w2 + col * RH + c * 8 + 4 * h);
+    for (int c = 0; c < RH / 8; ++c) W2[c] = *reinterpret_cast<const float4*>(w2 + col * RH + c * 8 + 4 * h);
+  } else {
+    inv1 = rad_load_wplanes<NG / 16>(w1g + col * NG, h, P1);
+    inv2 = rad_load_wplanes<RH / 16>(w2 + col * RH, h, P2);
+  }
   const float bias2 = b2[col];
   const float2 l1w = *reinterpret_cast<const float2*>(ln1w + 2 * lane), l1b = *reinterpret_cast<const float2*>(ln1b + 2 * lane);
   const float2 l2w = *reinterpret_cast<const float2*>(ln2w + 2 * lane), l2b = *reinterpret_cast<const float2*>(ln2b + 2 * lane);
@@ -175,7 +239,14 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
         t = dd - gmu[c0 + 4 * q + 2]; v.z = r_exp<FAST>((float)(gcoef * t * t));
         t = dd - gmu[c0 + 4 * q + 3]; v.w = r_exp<FAST>((float)(gcoef * t * t));
         }
-        *reinterpret_cast<float4*>(bufA + row * R_LDG + c0 + 4 * q) = v;
+        if constexpr (MM == 0) *reinterpret_cast<float4*>(bufA + row * R_LDG + c0 + 4 * q) = v;
+        else {                                       // two half planes of 16 x gaussian: [64 halfs | 64 halfs] in the row's first 256 B
+          unsigned int wa[2], wb[2];
+          q_split2<1>(v.x, v.y, wa); q_split2<1>(v.z, v.w, wb);
+          unsigned char* pr = reinterpret_cast<unsigned char*>(bufA + row * R_LDG) + (c0 + 4 * q) * 2;
+          *reinterpret_cast<uint2*>(pr) = make_uint2(wa[0], wb[0]);
+          *reinterpret_cast<uint2*>(pr + NG * 2) = make_uint2(wa[1], wb[1]);
+        }
       }
     }
     lds_barrier();
@@ -184,12 +255,15 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
     for (int i = 0; i < TR; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    if (!(UMX_ABL & 1)) rad_mma<NG / 8, R_LDG, TR>(bufA, W1, acc, l31, h);
+    if (!(UMX_ABL & 1)) {
+      if constexpr (MM == 0) rad_mma<NG / 8, R_LDG, TR>(bufA, W1, acc, l31, h);
+      else rad_mma_f16<NG / 16, R_LDG * 4, NG * 2, TR>(reinterpret_cast<const unsigned char*>(bufA), P1, acc, l31, h);
+    }
     // epilogue 1: the raw fc1 tile to bufB; the row pass below adds the element tables, writes h1pre (whole 512-B rows) and normalises
 #pragma unroll
     for (int i = 0; i < TR; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bufB[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * R_LD + col] = acc[i][r];
+      for (int r = 0; r < 16; ++r) bufB[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * R_LD + col] = MM ? acc[i][r] * inv1 : acc[i][r];
     lds_barrier();
     // Pass 1a: + element tables, back into LDS -- global LOADS only.  gfx9 counts loads and stores on one in-order counter (vmcnt), so a
     // table load issued behind an h1pre store cannot be waited for without waiting for that store as well: with the stores in this
@@ -213,19 +287,30 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
       float* p = bufB + row * R_LD + 2 * lane;
       const float2 v = *reinterpret_cast<const float2*>(p);
       if (!(UMX_ABL & 16) && e0 + row < ne) *reinterpret_cast<float2*>(h1pre + (e0 + row) * RH + 2 * lane) = v;
-      *reinterpret_cast<float2*>(p) = (UMX_ABL & 2) ? v : ln_silu_row<FAST>(v, l1w, l1b);
+      const float2 o = (UMX_ABL & 2) ? v : ln_silu_row<FAST>(v, l1w, l1b);
+      if constexpr (MM == 0) *reinterpret_cast<float2*>(p) = o;
+      else {                                         // in place: the wave has read the whole fp32 row (one ds_read) before these two writes
+        unsigned int w[2];
+        q_split2<1>(o.x, o.y, w);
+        unsigned int* pr = reinterpret_cast<unsigned int*>(bufB + row * R_LD);
+        pr[lane] = w[0];
+        pr[RH / 2 + lane] = w[1];
+      }
     }
     lds_barrier();
 #pragma unroll
     for (int i = 0; i < TR; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    if (!(UMX_ABL & 1)) rad_mma<RH / 8, R_LD, TR>(bufB, W2, acc, l31, h);
+    if (!(UMX_ABL & 1)) {
+      if constexpr (MM == 0) rad_mma<RH / 8, R_LD, TR>(bufB, W2, acc, l31, h);
+      else rad_mma_f16<RH / 16, R_LD * 4, RH * 2, TR>(reinterpret_cast<const unsigned char*>(bufB), P2, acc, l31, h);
+    }
     // epilogue 2: fc2 tile + bias to bufA (the gaussian tile is dead: every wave passed the barriers behind fc1)
 #pragma unroll
     for (int i = 0; i < TR; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bufA[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * R_LD + col] = acc[i][r] + bias2;
+      for (int r = 0; r < 16; ++r) bufA[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * R_LD + col] = (MM ? acc[i][r] * inv2 : acc[i][r]) + bias2;
     lds_barrier();
 #pragma unroll 2
     for (int rr = 0; rr < RT / 4; ++rr) {            // h2pre out, LN + SiLU -> the fc3 operand

@@ -140,7 +140,7 @@ struct umx_engine {
   int* d_part_deg = nullptr; float* d_part_f = nullptr; long part_cap = 0;
   int last_parts = 0;              // partitions used by the most recent evaluation (0: the ordinary path)
   int arena_allocs = 0;            // how often the workspace has been (re-)allocated (umx_workspace_stats)
-  bool radial_f16 = false;         // UMX_RADIAL_F16=1: fc1 / fc2 of the fused radial head on four fp16 plane products (default mode, TR = 2, FAST = 0)
+  int radial_f16 = 0;              // UMX_RADIAL_F16: bit 0 = fc1, bit 1 = fc2 of the fused radial head on four fp16 plane products (default mode, TR = 2, FAST = 0)
   bool ws_eager = false;           // UMX_WS_EAGER=1: size the workspace for the whole batch at once (the behaviour before ABI v8)
   long ws_soft_edges = 320000;     // UMX_WS_SOFT_EDGES: directed edges per chunk the workspace starts with when nothing else is known
   double t_first_eval = -1.0;      // steady-clock seconds of the first evaluation (amortised workspace growth)
@@ -477,7 +477,9 @@ int radial_fwd_head(umx_engine* eng, const WS& w, const RadialW& r, int slot, lo
       } else {                                                                                                        \
         if (fm == 2) hipLaunchKernelGGL((k_radial_head<Q, 2, 2>), UMX_RH_ARGS, (void*)(OUT), ne);                      \
         else if (fm == 1) hipLaunchKernelGGL((k_radial_head<Q, 1, 2>), UMX_RH_ARGS, (void*)(OUT), ne);                 \
-        else if (Q == 2 && eng->radial_f16) hipLaunchKernelGGL((k_radial_head<Q, 0, 2, (Q == 2 ? 1 : 0)>), UMX_RH_ARGS, (void*)(OUT), ne); \
+        else if (Q == 2 && eng->radial_f16 == 3) hipLaunchKernelGGL((k_radial_head<Q, 0, 2, (Q == 2 ? 3 : 0)>), UMX_RH_ARGS, (void*)(OUT), ne); \
+        else if (Q == 2 && eng->radial_f16 == 2) hipLaunchKernelGGL((k_radial_head<Q, 0, 2, (Q == 2 ? 2 : 0)>), UMX_RH_ARGS, (void*)(OUT), ne); \
+        else if (Q == 2 && eng->radial_f16 == 1) hipLaunchKernelGGL((k_radial_head<Q, 0, 2, (Q == 2 ? 1 : 0)>), UMX_RH_ARGS, (void*)(OUT), ne); \
         else hipLaunchKernelGGL((k_radial_head<Q, 0, 2>), UMX_RH_ARGS, (void*)(OUT), ne);                              \
       }                                                                                                               \
     } while (0)
@@ -1015,7 +1017,7 @@ int umx_create(umx_engine** out, int device_ordinal) {
   if (const char* ev = std::getenv("UMX_SIDE")) e->side = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_FORCE_PARTS")) e->force_parts = std::max(0, std::min(16, std::atoi(ev)));
   if (const char* ev = std::getenv("UMX_WS_GB")) e->ws_cap_default = (size_t)std::max(0L, std::atol(ev)) << 30;
-  if (const char* ev = std::getenv("UMX_RADIAL_F16")) e->radial_f16 = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("UMX_RADIAL_F16")) e->radial_f16 = std::atoi(ev) & 3;
   if (const char* ev = std::getenv("UMX_WS_EAGER")) e->ws_eager = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_WS_SOFT_EDGES")) e->ws_soft_edges = std::max(1L, std::atol(ev));
   if (const char* ev = std::getenv("UMX_AUTO_BF16_ATOMS")) e->auto_atoms = std::max(0, std::atoi(ev));

@@ -197,18 +197,18 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int col = wave * 32 + l31;                   // the output column this lane owns in both linears
-  float4 W1[MM ? 1 : NG / 8], W2[MM ? 1 : RH / 8];
-  WPlanes P1[MM ? NG / 16 : 1], P2[MM ? RH / 16 : 1];
-  float inv1 = 1.0f, inv2 = 1.0f;                    // 1 / (16 s) of the lane's column (MM = 1)
-  if constexpr (MM == 0) {
+  constexpr bool M1 = (MM & 1) != 0, M2 = (MM & 2) != 0;      // MM: bit 0 = fc1, bit 1 = fc2 on fp16 plane products
+  float4 W1[M1 ? 1 : NG / 8], W2[M2 ? 1 : RH / 8];
+  WPlanes P1[M1 ? NG / 16 : 1], P2[M2 ? RH / 16 : 1];
+  float inv1 = 1.0f, inv2 = 1.0f;                    // 1 / (16 s) of the lane's column
+  if constexpr (!M1) {
 #pragma unroll
     for (int c = 0; c < NG / 8; ++c) W1[c] = *reinterpret_cast<const float4*>(w1g + col * NG + c * 8 + 4 * h);
+  } else inv1 = rad_load_wplanes<NG / 16>(w1g + col * NG, h, P1);
+  if constexpr (!M2) {
 #pragma unroll
     for (int c = 0; c < RH / 8; ++c) W2[c] = *reinterpret_cast<const float4*>(w2 + col * RH + c * 8 + 4 * h);
-  } else {
-    inv1 = rad_load_wplanes<NG / 16>(w1g + col * NG, h, P1);
-    inv2 = rad_load_wplanes<RH / 16>(w2 + col * RH, h, P2);
-  }
+  } else inv2 = rad_load_wplanes<RH / 16>(w2 + col * RH, h, P2);
   const float bias2 = b2[col];
   const float2 l1w = *reinterpret_cast<const float2*>(ln1w + 2 * lane), l1b = *reinterpret_cast<const float2*>(ln1b + 2 * lane);
   const float2 l2w = *reinterpret_cast<const float2*>(ln2w + 2 * lane), l2b = *reinterpret_cast<const float2*>(ln2b + 2 * lane);
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
         t = dd - gmu[c0 + 4 * q + 2]; v.z = r_exp<FAST>((float)(gcoef * t * t));
         t = dd - gmu[c0 + 4 * q + 3]; v.w = r_exp<FAST>((float)(gcoef * t * t));
         }
-        if constexpr (MM == 0) *reinterpret_cast<float4*>(bufA + row * R_LDG + c0 + 4 * q) = v;
+        if constexpr (!M1) *reinterpret_cast<float4*>(bufA + row * R_LDG + c0 + 4 * q) = v;
         else {                                       // two half planes of 16 x gaussian: [64 halfs | 64 halfs] in the row's first 256 B
           unsigned int wa[2], wb[2];
           q_split2<1>(v.x, v.y, wa); q_split2<1>(v.z, v.w, wb);
@@ -256,14 +256,14 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     if (!(UMX_ABL & 1)) {
-      if constexpr (MM == 0) rad_mma<NG / 8, R_LDG, TR>(bufA, W1, acc, l31, h);
+      if constexpr (!M1) rad_mma<NG / 8, R_LDG, TR>(bufA, W1, acc, l31, h);
       else rad_mma_f16<NG / 16, R_LDG * 4, NG * 2, TR>(reinterpret_cast<const unsigned char*>(bufA), P1, acc, l31, h);
     }
     // epilogue 1: the raw fc1 tile to bufB; the row pass below adds the element tables, writes h1pre (whole 512-B rows) and normalises
 #pragma unroll
     for (int i = 0; i < TR; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bufB[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * R_LD + col] = MM ? acc[i][r] * inv1 : acc[i][r];
+      for (int r = 0; r < 16; ++r) bufB[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * R_LD + col] = M1 ? acc[i][r] * inv1 : acc[i][r];
     lds_barrier();
     // Pass 1a: + element tables, back into LDS -- global LOADS only.  gfx9 counts loads and stores on one in-order counter (vmcnt), so a
     // table load issued behind an h1pre store cannot be waited for without waiting for that store as well: with the stores in this
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
       const float2 v = *reinterpret_cast<const float2*>(p);
       if (!(UMX_ABL & 16) && e0 + row < ne) *reinterpret_cast<float2*>(h1pre + (e0 + row) * RH + 2 * lane) = v;
       const float2 o = (UMX_ABL & 2) ? v : ln_silu_row<FAST>(v, l1w, l1b);
-      if constexpr (MM == 0) *reinterpret_cast<float2*>(p) = o;
+      if constexpr (!M2) *reinterpret_cast<float2*>(p) = o;
       else {                                         // in place: the wave has read the whole fp32 row (one ds_read) before these two writes
         unsigned int w[2];
         q_split2<1>(o.x, o.y, w);
@@ -303,14 +303,14 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     if (!(UMX_ABL & 1)) {
-      if constexpr (MM == 0) rad_mma<RH / 8, R_LD, TR>(bufB, W2, acc, l31, h);
+      if constexpr (!M2) rad_mma<RH / 8, R_LD, TR>(bufB, W2, acc, l31, h);
       else rad_mma_f16<RH / 16, R_LD * 4, RH * 2, TR>(reinterpret_cast<const unsigned char*>(bufB), P2, acc, l31, h);
     }
     // epilogue 2: fc2 tile + bias to bufA (the gaussian tile is dead: every wave passed the barriers behind fc1)
 #pragma unroll
     for (int i = 0; i < TR; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bufA[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * R_LD + col] = (MM ? acc[i][r] * inv2 : acc[i][r]) + bias2;
+      for (int r = 0; r < 16; ++r) bufA[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * R_LD + col] = (M2 ? acc[i][r] * inv2 : acc[i][r]) + bias2;
     lds_barrier();
 #pragma unroll 2
     for (int rr = 0; rr < RT / 4; ++rr) {            // h2pre out, LN + SiLU -> the fc3 operand

@@ -79,8 +79,72 @@ static int pmc_mode(int reps) {
   return 0;
 }
 
+__global__ void k_count_diff(const unsigned int* __restrict__ a, const unsigned int* __restrict__ b, size_t n, unsigned long long* __restrict__ out) {
+  unsigned long long c = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) c += a[i] != b[i];
+  if (c) atomicAdd(out, c);
+}
+
+// verify mode: is every split GEMM bitwise reproducible when another kernel shares the chip?  Each of the 14 launches of an evaluation is
+// run alone (reference C), then `iters` times beside a full-grid copy kernel on a second stream, and C is compared dword by dword.
+static int verify_mode(long M, int iters) {
+  const long M4 = (M + 3) / 4 * 4;
+  unsigned char *y1, *w; float *C, *Cref;
+  const size_t cbytes = (size_t)M * 2304 * 4;
+  CK(hipMalloc(&y1, (size_t)M4 * 2304 * 6)); CK(hipMalloc(&w, (size_t)1536 * 768 * 6)); CK(hipMalloc(&C, cbytes)); CK(hipMalloc(&Cref, cbytes));
+  std::vector<unsigned short> h(1 << 22);
+  for (auto& v : h) v = (unsigned short)(0x3c00 + (rand() & 0x3ff) + ((rand() & 1) << 15));
+  for (size_t o = 0; o < (size_t)M4 * 2304 * 6; o += h.size() * 2) CK(hipMemcpy(y1 + o, h.data(), std::min(h.size() * 2, (size_t)M4 * 2304 * 6 - o), hipMemcpyHostToDevice));
+  CK(hipMemcpy(w, h.data() + 17, (size_t)1536 * 768 * 6, hipMemcpyHostToDevice));
+  const long n4 = (long)(2.0e9 / 16);
+  float4 *src, *dst; unsigned long long* d_cnt;
+  CK(hipMalloc(&src, n4 * 16)); CK(hipMalloc(&dst, n4 * 16)); CK(hipMemset(src, 1, n4 * 16)); CK(hipMalloc(&d_cnt, 8));
+  hipStream_t sa, sb; CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+  auto mk = [&](int P, int a_cols, int offA0, int offA1, int bHalf, long ldc, int offC, int offCi, int N, int K) {
+    GemmPL q; std::memset(&q, 0, sizeof(q));
+    q.Apl = reinterpret_cast<const unsigned short*>(y1); q.lda = (long)a_cols * P; q.offA0 = offA0; q.offA1 = offA1;
+    q.Bpl = reinterpret_cast<const unsigned short*>(w); q.ldb = (long)K * P; q.bHalf = bHalf; q.Cp = C; q.ldc = ldc; q.offC = offC; q.offCi = offCi;
+    q.conj = 1.f; q.cscale = 1.f; q.M = (int)M; q.N = N; q.K = K;
+    return q;
+  };
+  auto grid = [&](int cplx, int wide, int N) {
+    const int bmr = cplx ? 128 : 256, bnc = wide ? (cplx ? 128 : 256) : (cplx ? 64 : 128);
+    const long nM = (M + bmr - 1) / bmr, nN = (N + bnc - 1) / bnc;
+    return dim3((unsigned)(((nM + 7) / 8) * 8 * nN));
+  };
+  struct L { const char* name; std::function<void()> f; };
+  std::vector<L> ls;
+  ls.push_back({"fwd conv1 m0  q<0,0>", [&] { hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0, 2, 2, 1, 4, 3>), grid(0, 0, 640), dim3(512), 0, sa, mk(2, 2304, 0, 0, 0, 1408, 0, 0, 640, 768)); }});
+  ls.push_back({"fwd conv1 m1  q<1,1>", [&] { hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1, 2, 2, 1, 4, 3>), grid(1, 1, 256), dim3(512), 0, sa, mk(2, 2304, 768, 1280, 256, 1408, 640, 896, 256, 512)); }});
+  ls.push_back({"fwd fc3       q<0,1>", [&] { hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 2, 2, 1, 4, 3>), grid(0, 1, 1536), dim3(512), 0, sa, mk(2, 128, 0, 0, 0, 1536, 0, 0, 1536, 128)); }});
+  ls.push_back({"rev conv2T m0 pl16<0,2,3,4,2,2,2>", [&] { hipLaunchKernelGGL((umx_gemm_pl16_kernel<0, 2, 3, 4, 2, 2, 2>), grid(0, 0, 384), dim3(512), 0, sa, mk(2, 1152, 0, 0, 0, 1152, 0, 0, 384, 384)); }});
+  ls.push_back({"rev conv2T m1 pl16<1,2,2,4,2,2,4>", [&] { hipLaunchKernelGGL((umx_gemm_pl16_kernel<1, 2, 2, 4, 2, 2, 4>), grid(1, 1, 256), dim3(512), 0, sa, mk(2, 1152, 384, 640, 256, 1152, 384, 640, 256, 256)); }});
+  ls.push_back({"rev conv1T m0 pl16<0,2,2,4,2,2,4>", [&] { hipLaunchKernelGGL((umx_gemm_pl16_kernel<0, 2, 2, 4, 2, 2, 4>), grid(0, 1, 768), dim3(512), 0, sa, mk(2, 1408, 0, 0, 0, 2304, 0, 0, 768, 640)); }});
+  ls.push_back({"rev conv1T m1 pl16<1,2,2,4,2,2,4>", [&] { hipLaunchKernelGGL((umx_gemm_pl16_kernel<1, 2, 2, 4, 2, 2, 4>), grid(1, 1, 512), dim3(512), 0, sa, mk(2, 1408, 640, 896, 512, 2304, 768, 1280, 512, 256)); }});
+  ls.push_back({"rev fc3T      pl<0,2,3,4,2,2,2>", [&] { hipLaunchKernelGGL((umx_gemm_pl_kernel<0, 2, 3, 4, 2, 2, 2>), grid(0, 0, 128), dim3(512), 0, sa, mk(2, 1536, 0, 0, 0, 128, 0, 0, 128, 1536)); }});
+  for (auto& l : ls) {
+    CK(hipMemset(C, 0, cbytes)); CK(hipDeviceSynchronize());
+    l.f(); CK(hipDeviceSynchronize());
+    CK(hipMemcpy(Cref, C, cbytes, hipMemcpyDeviceToDevice));
+    int bad_runs = 0; unsigned long long worst = 0;
+    for (int it = 0; it < iters; ++it) {
+      CK(hipMemset(C, 0, cbytes)); CK(hipMemset(d_cnt, 0, 8)); CK(hipDeviceSynchronize());
+      hipLaunchKernelGGL(k_copy_full, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, sb, src, dst, n4);
+      l.f();
+      CK(hipDeviceSynchronize());
+      hipLaunchKernelGGL(k_count_diff, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const unsigned int*>(C), reinterpret_cast<const unsigned int*>(Cref), cbytes / 4, d_cnt);
+      unsigned long long c = 0; CK(hipMemcpy(&c, d_cnt, 8, hipMemcpyDeviceToHost));
+      if (c) { ++bad_runs; worst = std::max(worst, c); }
+    }
+    printf("%-36s beside a copy kernel: %d of %d runs differ from the solo result (worst: %llu dwords)\n", l.name, bad_runs, iters, worst);
+    fflush(stdout);
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc > 1 && !strcmp(argv[1], "pmc")) return pmc_mode(argc > 2 ? atoi(argv[2]) : 2);
+  if (argc > 1 && !strcmp(argv[1], "verify")) return verify_mode(argc > 2 ? atol(argv[2]) : 100000, argc > 3 ? atoi(argv[3]) : 40);
   const long M = argc > 1 ? atol(argv[1]) : 569632; const int N = argc > 2 ? atoi(argv[2]) : 512, K = argc > 3 ? atoi(argv[3]) : 512;
   const double copy_gb = argc > 4 ? atof(argv[4]) : 8.0;
   const int R = 8;

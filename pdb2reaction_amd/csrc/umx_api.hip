@@ -1775,7 +1775,9 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
                d_forces ? d_forces + k0 * N * 3 : nullptr, P);
   };
   if (lanes == 2) {          // chunks in pairs, one per lane, matrix segments alternating between the lanes (run_plans_alternating)
-    hipStream_t sts[2] = {s, eng->stream2};
+    // UMX_LANES_ONE_STREAM=1 (tests): both lanes' segments in the same alternating order on ONE stream -- the two-lane plan without any
+    // concurrency (what results must be bitwise equal to; with real concurrency see DESIGN.md section 5, item 14)
+    hipStream_t sts[2] = {s, std::getenv("UMX_LANES_ONE_STREAM") ? s : eng->stream2};
     hipEvent_t tok[2] = {eng->ev_tok[0], eng->ev_tok[1]};
     for (size_t ci = 0; ci < chunks.size() && st == UMX_OK; ci += 2) {
       Plan P[2];

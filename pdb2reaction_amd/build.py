@@ -13,13 +13,19 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libumx.so")
 SOURCES = ["umx_api.hip"]
 ABI_HEADER = os.path.normpath(os.path.join(HERE, "..", "include", "umx.h"))
+# -fno-slp-vectorize: hipcc's SLP vectoriser turns adjacent float operations into packed-fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 /
+# v_pk_fma_f32).  On gfx950 with this toolchain (ROCm 7.2) a kernel made of them is TIMING-SENSITIVE: alone on the chip it is bitwise
+# reproducible, but while other kernels share its SIMDs -- a second stream, another process -- single waves come out 0.1-1 % off (round 3:
+# k_norm_bwd, reproduced stand-alone in csrc/norm_bwd_repro.hip: 27-788 of 40 000 launches beside four busy processes, 0 of 80 000 without
+# the packed instructions).  The flags are part of the source digest.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize"]
 
 
 def dependencies() -> list:
     """Every file the library is compiled from: all of csrc/*.h and csrc/*.hip (umx_api.hip includes the headers; a
     hand-kept list once missed the default forward GEMM, so the stale git-ignored .so shipped) plus the ABI header."""
     deps = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip")))
-    deps = [d for d in deps if os.path.basename(d) not in ("gemm_bench.hip", "overlap_bench.hip", "func_bias.hip", "norm_bwd_repro.hip")]     # stand-alone dev benchmarks, not part of the library
+    deps = [d for d in deps if os.path.basename(d) not in ("gemm_bench.hip", "overlap_bench.hip", "func_bias.hip", "norm_bwd_repro.hip", "corun_probe.hip")]     # stand-alone dev benchmarks, not part of the library
     return deps + [ABI_HEADER]
 
 
@@ -28,6 +34,7 @@ def source_digest() -> str:
     (``umx_build_digest()``), written next to it (``libumx.so.digest``) and recorded with every committed PMC summary, so a
     stale prebuilt .so or a stale traffic figure is detected by content rather than by mtime."""
     h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode() + b"\0")
     for d in dependencies():
         h.update(os.path.basename(d).encode() + b"\0")
         with open(d, "rb") as f:
@@ -60,7 +67,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return OUT
     digest = source_digest()
-    cmd = [find_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", CSRC,
+    cmd = [find_hipcc(), *FLAGS, "-fPIC", "-shared", "-I", CSRC,
            f'-DUMX_SRC_DIGEST="{digest}"', *[os.path.join(CSRC, s) for s in SOURCES], "-o", OUT]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)

@@ -55,5 +55,6 @@ int main(int argc, char** argv) {
     }
   }
   printf("k_norm_bwd: %d of %d launches differ from the first\n", bad, iters);
+  fflush(stdout);
   return 0;
 }

@@ -285,3 +285,23 @@ def test_prebuilt_library_without_sources_still_loads(monkeypatch, tmp_path):
     with pytest.warns(RuntimeWarning, match="cannot be checked"):
         E.load_library()
     monkeypatch.setattr(E, "_lib", None)
+
+
+def test_library_has_no_packed_fp32(tmp_path):
+    """Round 3: packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, what hipcc's SLP vectoriser makes of adjacent
+    float operations) give timing-dependent results on gfx950 when other kernels share the SIMDs -- the library is compiled with
+    -fno-slp-vectorize (build.FLAGS, part of the source digest).  Compile the smallest kernel header to assembly with those flags and
+    check that none is left (a future flag or compiler change must not bring them back unnoticed)."""
+    import re
+    import subprocess
+
+    from pdb2reaction_amd import build
+
+    assert "-fno-slp-vectorize" in build.FLAGS
+    src = tmp_path / "probe.hip"
+    src.write_text('#include "umx_kernels_pl.h"\n#include "umx_kernels.h"\n')
+    out = tmp_path / "probe.s"
+    subprocess.run([build.find_hipcc(), *build.FLAGS, "-I", build.CSRC, "-S", "--cuda-device-only", str(src), "-o", str(out)], check=True, timeout=600)
+    text = out.read_text()
+    assert "k_norm_bwd" in text and "global_load" in text                      # device code of the kernels is really in there
+    assert not re.search(r"\bv_pk_(mul|add|fma)_f32\b", text)

@@ -619,17 +619,17 @@ def test_c5_size_invariants(engine):
 
 def test_two_lane_execution_is_bitwise_identical(weights, monkeypatch):
     """UMX_STREAMS=2 (two chunks in flight, matrix segments alternating through an event token, capped grids of the grid-stride
-    stream kernels): same kernels, same per-item arithmetic, only the issue order differs -- so with the two lanes' segments issued
-    in that alternating order on ONE stream (UMX_LANES_ONE_STREAM=1: the plan without concurrency) not a single bit may change.
-    With real concurrency the comparison is held to the BASELINE tolerances instead: round 3 found that on this platform a kernel that
-    shares the chip with other kernels occasionally (~1e-5 per launch) returns single rows 0.1-1 % off -- reproduced with ONE wave-per-row
-    kernel in a stand-alone program beside another process (csrc/norm_bwd_repro.hip); the engine alone on
-    its GPU (one lane, one process per GPU: the default) is bitwise reproducible (test_results_are_deterministic...)."""
+    stream kernels) must not change a single bit: same kernels, same per-item arithmetic, only the issue order differs -- with the two
+    lanes really overlapping and with their segments issued on one stream (UMX_LANES_ONE_STREAM=1).
+    Round 3: this test failed about once in ten suite runs (forces of one image 1e-6...1e-4 eV/A off).  Cause: the packed-fp32
+    instructions hipcc's SLP vectoriser emits (v_pk_mul/add/fma_f32) are timing-sensitive on gfx950 -- beside other kernels on the same
+    SIMDs single waves come out 0.1-1 % off (csrc/norm_bwd_repro.hip); the library is built with -fno-slp-vectorize since
+    (build.py).  test_library_has_no_packed_fp32 keeps it that way."""
     from pdb2reaction_amd.engine import Engine
 
     z, imgs, _ = synth.make_images(260, 5, seed=21)
     res = {}
-    for lanes, cap, one_stream in (("1", "512", False), ("2", "512", True), ("2", "64", True), ("2", "0", True), ("2", "512", False)):
+    for lanes, cap, one_stream in (("1", "512", False), ("2", "512", False), ("2", "64", False), ("2", "0", False), ("2", "512", True)):
         monkeypatch.setenv("UMX_STREAMS", lanes)
         monkeypatch.setenv("UMX_STREAM_BLOCKS", cap)
         if one_stream:
@@ -645,10 +645,7 @@ def test_two_lane_execution_is_bitwise_identical(weights, monkeypatch):
             eng.close()
     e0, f0 = res[("1", "512", False)]
     for key, (e, f) in res.items():
-        if key[2] or key[0] == "1":
-            assert np.array_equal(e, e0) and np.array_equal(f, f0), key
-        else:
-            assert np.abs(e - e0).max() <= TOL_E and np.abs(f - f0).max() <= TOL_F, key
+        assert np.array_equal(e, e0) and np.array_equal(f, f0), key
 
 
 def test_reserve_images_allocates_the_workspace_once(weights):

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round-3 profile collection on the GPU box (run from the repository root through gpurun).  Writes raw rocprofv3 output under
 # gpurun_out/prof/ and the judged summaries under profiles/ (copied back by the caller from gpurun_out/prof/profiles_out/).
+# Needs build/overlap_bench (the stand-alone GEMM driver of the counter passes), built here in the container with the library's flags:
+#   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I pdb2reaction_amd/csrc pdb2reaction_amd/csrc/overlap_bench.hip -o build/overlap_bench
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof; P=$O/profiles_out
 mkdir -p $O $P

@@ -217,7 +217,7 @@ def main():
 
     mode_req = os.environ.get("UMX_PRECISION", "auto")           # "auto": split-f16 up to 4096 atoms per image, split-bf16 above (include/umx.h)
     dt, prof, ne_local, maxdeg, resolved = run(mode_req, args.steps, args.warmup)
-    mode = {"split-f16": "split", "split-bf16": "split-bf16", "fp32": "fp32"}[resolved]
+    mode = {"split-f16": "split", "split-bf16": "split-bf16", "bf16x3": "bf16x3", "fp32": "fp32"}[resolved]
     tt = torch.tensor([dt, float(ne_local)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         tmax = tt.clone()

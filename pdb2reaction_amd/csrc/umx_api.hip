@@ -74,6 +74,7 @@ struct umx_engine {
   int q3_stages = 2;               // UMX_Q3S: LDS ring depth of the forward Q3 GEMMs (2 or 3)
   bool q3_wide = true;             // UMX_Q3WIDE=0 (dev): 256x128 tiles for every forward GEMM
   bool q3 = true;                  // UMX_Q3=0: forward operands in the 32-column PL layout + 256x128 tiles (set before umx_load_weights)
+  int rev_planes = 2;              // bf16 planes of the REVERSE-pass operands: 2 (3 products, 16-bit) or 3 (6 products, 24-bit: UMX_PRECISION=bf16x3)
   int fwd_fmt = 1;                 // forward operand format (QFmt, umx_kernels_pl.h): 1 = two fp16 planes (UMX_PRECISION=split), 0 = three bf16 planes (split-bf16)
   std::string precision;           // umx_set_precision: overrides UMX_PRECISION when non-empty
   bool node_ctx = false;           // set around the node-level launches (NodeCtx): only those take the float64-accumulating kernel
@@ -272,6 +273,8 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
   auto it = eng->planes.find(Wkey);
   if (it == eng->planes.end()) return fail(eng, UMX_ERR_ARG, "gemm_pl: weight has no PL copy");
   if (K % 32 != 0) return fail(eng, UMX_ERR_ARG, "gemm_pl: K not a multiple of 32");
+  const bool fwd = (P == 3);                 // the call sites say 3 = forward product, 2 = reverse product; the reverse plane count is the engine's
+  if (!fwd) P = eng->rev_planes;
   GemmPL q;
   std::memset(&q, 0, sizeof(q));
   q.Apl = Apl; q.lda = (long)a_cols * P; q.offA0 = offA0; q.offA1 = offA1; q.Bpl = it->second; q.ldb = (long)K * P; q.bHalf = bHalf;
@@ -283,7 +286,7 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
   const int bmr = cplx ? 128 : 256;
   const long nM = (M + bmr - 1) / bmr;
   const bool fills = nM * (N / (cplx ? 128 : 256)) >= 256;          // wide grid >= one workgroup per CU
-  const bool wide = eng->wide_tiles && P == 2 && N % (cplx ? 128 : 256) == 0 && fills;
+  const bool wide = eng->wide_tiles && !fwd && P == 2 && N % (cplx ? 128 : 256) == 0 && fills;
   const int bnc = wide ? (cplx ? 128 : 256) : (cplx ? 64 : 128);
   const long nN = (N + bnc - 1) / bnc;
   dim3 grid((unsigned)(((nM + 7) / 8) * 8 * nN)), block(512);
@@ -295,13 +298,13 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
     pr = &eng->prof[eng->prof_used++];
     pr->flops = cplx ? 8.0 * M * (double)N * K : 2.0 * M * (double)N * K;
     pr->M = (int)M; pr->N = N; pr->K = K; pr->amode = 9; pr->cplx = cplx; pr->gz = 1;
-    pr->prec = (P == 3 && eng->q3 && eng->fwd_fmt == 1) ? 20 + eng->f16_prod : P;      // 23 / 24: two fp16 planes, 3 / 4 products
+    pr->prec = (fwd && eng->q3 && eng->fwd_fmt == 1) ? 20 + eng->f16_prod : P;      // 23 / 24: two fp16 planes, 3 / 4 products; 3 / 2: bf16 planes, 6 / 3 products
     HIPCHK(eng, hipEventRecord(pr->a, eng->stream));
   }
   // MFMA shape per GEMM (measured in the c3 pipeline): 16x16x32 wins 1-7 % on the complex SO(2) GEMMs and on K >= 512,
   // 32x32x16 wins 5-10 % on the short-K plain ones (radial fc3 and its transpose, conv-2 m=0)
   const bool use16 = eng->mfma16 >= 2 || (eng->mfma16 == 1 && (cplx || K >= 512));
-  if (P == 3 && eng->q3) {
+  if (fwd && eng->q3) {
     // forward operands in the quad-row layout: 256x256 tiles where N fills them, else 256x128 (umx_gemm_q.h)
     const bool wq = eng->q3_wide && N % (cplx ? 128 : 256) == 0 && fills;
     const int bnq = wq ? (cplx ? 128 : 256) : (cplx ? 64 : 128);
@@ -389,7 +392,8 @@ struct Bump {
   }
 };
 
-inline int ws_mode(const umx_engine* eng) { return !eng->pl ? 0 : (eng->q3 && eng->fwd_fmt == 1) ? 2 : 3; }
+// workspace mode: 0 = fp32 path, else (planes of the forward operands) + 16 when the reverse operands have three planes
+inline int ws_mode(const umx_engine* eng) { return !eng->pl ? 0 : ((eng->q3 && eng->fwd_fmt == 1) ? 2 : 3) + (eng->rev_planes == 3 ? 16 : 0); }
 
 // Workspace layout.  PERSISTENT buffers live from the forward to the reverse pass of an evaluation (node-level state, the graph, and the
 // per-edge activations of all four layers: ~72 KB per directed edge); TRANSIENT buffers are the operands between a producer and a GEMM
@@ -426,10 +430,10 @@ void carve_trans(Bump& b, long ne, WS& t, int pl) {
   if (pl) {
     t.gmsg = b.take<float>(ne * 3 * C);                      // only the edge-degree backward uses fp32 g_msg (E x 384)
     const long ne4 = (ne + 3) / 4 * 4;          // the quad-row (Q3) layout stores rows in groups of four
-    const long fp = pl;                                          // planes of the forward operands
+    const long fp = pl & 15, rp = (pl & 16) ? 3 : 2;             // planes of the forward / reverse operands
     t.y1pl = b.take<unsigned short>(ne4 * XROT * fp); t.hidpl = b.take<unsigned short>(ne4 * ROW * fp);
-    t.a2pl = b.take<unsigned short>(ne4 * RH * fp); t.gmsgpl = b.take<unsigned short>(ne * ROW * 2);
-    t.ghgpl = b.take<unsigned short>(ne * HG * 2); t.gradpl = b.take<unsigned short>(ne * RAD * 2);
+    t.a2pl = b.take<unsigned short>(ne4 * RH * fp); t.gmsgpl = b.take<unsigned short>(ne * ROW * rp);
+    t.ghgpl = b.take<unsigned short>(ne * HG * rp); t.gradpl = b.take<unsigned short>(ne * RAD * rp);
   } else {
     t.xrot = b.take<float>(ne * XROT); t.gmsg = b.take<float>(ne * ROW);
     t.ghg = b.take<float>(ne * HG); t.grad = b.take<float>(ne * RAD);
@@ -798,7 +802,10 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       HIPCHK(eng, hipGetLastError());
       DBG("g_xmid" + t, w.G2, nn * ROW);
       if (ne > 0 && eng->pl)
-        hipLaunchKernelGGL(k_rotate_back_bwd_pl<2>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne);
+      {
+        if (eng->rev_planes == 3) hipLaunchKernelGGL(k_rotate_back_bwd_pl<3>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne);
+        else hipLaunchKernelGGL(k_rotate_back_bwd_pl<2>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne);
+      }
       HIPCHK(eng, hipGetLastError());
       return UMX_OK;
     });
@@ -814,7 +821,8 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
         // the radial tail of the layer ABOVE (it feeds only dE/dd) beside this HBM-bound kernel -- not right behind its fc3^T GEMM, where
         // it would run next to the node-level and SO(2) GEMMs and slow those down by as much as it hides (measured)
         if (side && i + 1 < NL) CHK(side_launch(eng->ev_stail, [=, &w]() -> int { return radial_bwd_tail(eng, w, eng->lw[i + 1].rad, i + 1, ne); }));
-        hipLaunchKernelGGL(k_gate_edge_bwd_pl<2>, dim3(vgrid(eng, nblk(ne * (H / 4), 256))), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne);
+        if (eng->rev_planes == 3) hipLaunchKernelGGL(k_gate_edge_bwd_pl<3>, dim3(vgrid(eng, nblk(ne * (H / 4), 256))), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne);
+        else hipLaunchKernelGGL(k_gate_edge_bwd_pl<2>, dim3(vgrid(eng, nblk(ne * (H / 4), 256))), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne);
         HIPCHK(eng, hipGetLastError());
         return UMX_OK;
       });
@@ -828,10 +836,13 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       P.matrix([=, &w]() -> int {
         hipStream_t s = eng->stream;
         if (eng->fuse_modrot) {       // one node-centric kernel: modulation backward + rotate-back + segmented sum (g_xrot stays in registers)
-          hipLaunchKernelGGL(k_modrot_bwd_pl<2>, dim3((unsigned)nn), B256, 0, s, w.gy1, w.xn[i], w.frame, w.rad[i], w.row_ptr, w.out_ptr, w.out_edge,
-                             w.gradpl, w.tau, w.tau2, w.G1, nn);
+          if (eng->rev_planes == 3) hipLaunchKernelGGL(k_modrot_bwd_pl<3>, dim3((unsigned)nn), B256, 0, s, w.gy1, w.xn[i], w.frame, w.rad[i], w.row_ptr, w.out_ptr, w.out_edge,
+                                                       w.gradpl, w.tau, w.tau2, w.G1, nn);
+          else hipLaunchKernelGGL(k_modrot_bwd_pl<2>, dim3((unsigned)nn), B256, 0, s, w.gy1, w.xn[i], w.frame, w.rad[i], w.row_ptr, w.out_ptr, w.out_edge,
+                                  w.gradpl, w.tau, w.tau2, w.G1, nn);
         } else {
-          hipLaunchKernelGGL(k_modulate_bwd_pl<2>, dim3(nblk(ne, 4)), B256, 0, s, w.gy1, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.gradpl, w.tau, ne);
+          if (eng->rev_planes == 3) hipLaunchKernelGGL(k_modulate_bwd_pl<3>, dim3(nblk(ne, 4)), B256, 0, s, w.gy1, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.gradpl, w.tau, ne);
+          else hipLaunchKernelGGL(k_modulate_bwd_pl<2>, dim3(nblk(ne, 4)), B256, 0, s, w.gy1, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.gradpl, w.tau, ne);
           DBG("g_xrot." + std::to_string(i), w.gy1, ne * XROT);
         }
         HIPCHK(eng, hipGetLastError());
@@ -893,8 +904,10 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
     if (ne > 0) {
       // split path: the gradient of the edge-degree radial output goes straight into the PL planes of the fc3^T GEMM (gmsgpl is free here)
       const bool dpl = eng->pl && eng->planes.count(eng->rdeg.w3T) != 0;
-      if (dpl) hipLaunchKernelGGL((k_rotate_back_bwd<3, true>), dim3(nblk(ne, 4)), B256, 0, s, w.G0, w.rad_deg, w.frame, w.edst,
-                                  reinterpret_cast<float*>(w.gmsgpl), w.dedd, w.tau, ne, DEG_RESCALE);
+      if (dpl && eng->rev_planes == 3) hipLaunchKernelGGL((k_rotate_back_bwd<3, 3>), dim3(nblk(ne, 4)), B256, 0, s, w.G0, w.rad_deg, w.frame, w.edst,
+                                                          reinterpret_cast<float*>(w.gmsgpl), w.dedd, w.tau, ne, DEG_RESCALE);
+      else if (dpl) hipLaunchKernelGGL((k_rotate_back_bwd<3, 2>), dim3(nblk(ne, 4)), B256, 0, s, w.G0, w.rad_deg, w.frame, w.edst,
+                                       reinterpret_cast<float*>(w.gmsgpl), w.dedd, w.tau, ne, DEG_RESCALE);
       else hipLaunchKernelGGL(k_rotate_back_bwd<3>, dim3(nblk(ne, 4)), B256, 0, s, w.G0, w.rad_deg, w.frame, w.edst, w.gmsg, w.dedd, w.tau, ne,
                               DEG_RESCALE);
       if (side) HIPCHK(eng, hipStreamWaitEvent(s, eng->ev_stail, 0));        // join: layer 1's tail, the last one issued on the side stream (e128a, dedd_rad)
@@ -1233,11 +1246,14 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes, i
     const char* pv = std::getenv("UMX_PRECISION");
     const std::string mode = !eng->precision.empty() ? eng->precision : (pv && *pv ? pv : "auto");
     eng->auto_fmt = false;
+    bool rev3 = false;
     if (mode == "fp32") eng->pl = false;
     else if (mode == "auto") { eng->pl = true; eng->fwd_fmt = eng->q3 ? 1 : 0; eng->auto_fmt = eng->q3; }   // fp16 planes until a bound system says otherwise
     else if (mode == "split" || mode == "split-f16") { eng->pl = true; eng->fwd_fmt = eng->q3 ? 1 : 0; }   // (the dev layout UMX_Q3=0 has bf16 planes only)
     else if (mode == "split-bf16") { eng->pl = true; eng->fwd_fmt = 0; }
-    else return fail(eng, UMX_ERR_ARG, "UMX_PRECISION must be auto, split (= split-f16), split-bf16 or fp32");
+    else if (mode == "bf16x3" || mode == "split-exact") { eng->pl = true; eng->fwd_fmt = 0; rev3 = true; }   // 24-bit products in BOTH passes
+    else return fail(eng, UMX_ERR_ARG, "UMX_PRECISION must be auto, split (= split-f16), split-bf16, bf16x3 (= split-exact) or fp32");
+    eng->rev_planes = (eng->pl && rev3) ? 3 : 2;
     if (mode == "split-f16" && !eng->q3) return fail(eng, UMX_ERR_ARG, "UMX_PRECISION=split-f16 needs the quad-row operand layout (UMX_Q3=1)");
     if (force_fmt >= 0 && eng->pl) eng->fwd_fmt = force_fmt;
     // a precision change alters the workspace carve-up: force a re-carve on the next call
@@ -1289,8 +1305,12 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes, i
       }
     preq.push_back(r);
   };
+  // P = 3: a forward weight (quad-row layout / fp16 planes as the mode says); P = 2: a transposed (reverse-pass) weight -- always the PL
+  // layout, with the engine's reverse plane count
   auto want_planes = [&](const float* host, const float* dev, int rows, int K, int P) {
-    if (P == 3 && eng->q3 && eng->fwd_fmt == 1) { want_planes_f16(host, dev, rows, K); return; }
+    const bool fwdw = (P == 3);
+    if (!fwdw) P = eng->rev_planes;
+    if (fwdw && eng->q3 && eng->fwd_fmt == 1) { want_planes_f16(host, dev, rows, K); return; }
     PlaneReq r{dev, (bw.size() + 63) & ~size_t(63)};
     bw.resize(r.off + (size_t)rows * K * P);
     for (int rr = 0; rr < rows; ++rr)
@@ -1300,7 +1320,7 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes, i
           uint32_t u; std::memcpy(&u, &x, 4);
           const uint32_t rnd = u + 0x7FFFu + ((u >> 16) & 1u);
           const unsigned short hb = (unsigned short)(rnd >> 16);
-          if (P == 3 && eng->q3)     // quad-row layout (umx_gemm_q.h), index in bf16 units; rows are multiples of 4 here
+          if (fwdw && eng->q3)       // quad-row layout (umx_gemm_q.h), index in bf16 units; rows are multiples of 4 here
             bw[r.off + (((size_t)(rr / 4) * (K / 16) + k / 16) * 384 + (size_t)(rr % 4) * 96 + (size_t)q * 32 + (size_t)(k % 16) * 2) / 2] = hb;
           else
             bw[r.off + (size_t)rr * K * P + (size_t)(k / 32) * 32 * P + (size_t)q * 32 + (k % 32)] = hb;
@@ -1384,7 +1404,7 @@ int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes) {
 
 const char* umx_precision_mode(const umx_engine* eng) {
   if (!eng || !eng->have_weights) return "";
-  return !eng->pl ? "fp32" : (eng->q3 && eng->fwd_fmt == 1) ? "split-f16" : "split-bf16";
+  return !eng->pl ? "fp32" : (eng->q3 && eng->fwd_fmt == 1) ? "split-f16" : eng->rev_planes == 3 ? "bf16x3" : "split-bf16";
 }
 
 int umx_set_system(umx_engine* eng, int n_atoms, const int32_t* z, int charge, int spin, int task_index, float radius, int max_neigh) {
@@ -1910,8 +1930,8 @@ int umx_energy_forces(umx_engine* eng, int n_images, const float* pos, double* e
 int umx_set_precision(umx_engine* eng, const char* mode) {
   if (!eng) return UMX_ERR_ARG;
   const std::string m = mode ? mode : "";
-  if (!m.empty() && m != "auto" && m != "split" && m != "split-f16" && m != "split-bf16" && m != "fp32")
-    return fail(eng, UMX_ERR_ARG, "umx_set_precision: mode must be auto, split, split-f16, split-bf16 or fp32");
+  if (!m.empty() && m != "auto" && m != "split" && m != "split-f16" && m != "split-bf16" && m != "bf16x3" && m != "split-exact" && m != "fp32")
+    return fail(eng, UMX_ERR_ARG, "umx_set_precision: mode must be auto, split, split-f16, split-bf16, bf16x3 (= split-exact) or fp32");
   eng->precision = m;
   return UMX_OK;
 }

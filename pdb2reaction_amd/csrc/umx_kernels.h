@@ -568,8 +568,8 @@ __global__ __launch_bounds__(256) void k_rotate_back_reduce(const float* __restr
 
 // backward of K7b: g_msg[e] = scale env_e (W_e g[dst e]) ; dedd[e] += denv_e scale <W g, msg>;
 // tau[e] -= <g_msg, L msg>.   msg has NROWS rows (rows >= NROWS are zero); g_msg stores NROWS rows -- as fp32 rows, or (PLOUT, gmsg is
-// then an unsigned short buffer) as two bf16 planes in the PL layout: the A operand of the split fc3^T GEMM of the edge-degree MLP.
-template <int NROWS, bool PLOUT = false>
+// then an unsigned short buffer) as PLP (2 or 3) bf16 planes in the PL layout: the A operand of the split fc3^T GEMM of the edge-degree MLP.
+template <int NROWS, int PLP = 0>
 __global__ __launch_bounds__(256) void k_rotate_back_bwd(const float* __restrict__ gnode, const float* __restrict__ msg,
                                                          const float* __restrict__ frame, const int* __restrict__ edst,
                                                          float* __restrict__ gmsg, float* __restrict__ dedd,
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256) void k_rotate_back_bwd(const float* __restrict
   torque_acc(ly, my, -1.0f, tx, ty, tz);
 #pragma unroll
   for (int r = 0; r < NROWS; ++r) {
-    if (PLOUT) pl_store2<2>(reinterpret_cast<unsigned short*>(gmsg) + e * (long)(NROWS * C * 2), r * C + c0, lx[r], ly[r]);
+    if (PLP) pl_store2<(PLP ? PLP : 2)>(reinterpret_cast<unsigned short*>(gmsg) + e * (long)(NROWS * C * PLP), r * C + c0, lx[r], ly[r]);
     else *reinterpret_cast<float2*>(gmsg + e * (NROWS * C) + r * C + c0) = make_float2(lx[r], ly[r]);
   }
   s = wave_sum(s); tx = wave_sum(tx); ty = wave_sum(ty); tz = wave_sum(tz);

@@ -32,7 +32,7 @@ def gold():
     return load_golden("c3c4_n2000")
 
 
-@pytest.mark.parametrize("mode", ["split", "split-bf16", "fp32"])
+@pytest.mark.parametrize("mode", ["split", "split-bf16", "bf16x3", "fp32"])
 def test_c3_energy_and_forces_against_f64_oracle(weights, gold, mode, monkeypatch):
     """The headline configuration: E and F of 2000-atom images vs the float64 oracle, every precision mode (split = fp16 forward
     planes, the default; split-bf16 = three bf16 forward planes; fp32 = fp32 MFMA everywhere)."""

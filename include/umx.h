@@ -59,27 +59,32 @@ const char* umx_last_error(const umx_engine* eng);
 /* Load a merged UMA-S parameter set from a host-memory UMXW0001 blob
  * (pdb2reaction_amd/weights.py documents the layout).
  * Replaces: pretrained_mlip.get_predict_unit(model, device), uma_pysis.py:246-250.
- * The environment variable UMX_PRECISION is read here and fixes the arithmetic of the large SO(2)/radial GEMMs:
- *   auto (default, ABI v7): the engine's choice for the bound system, decided (and the weight planes re-packed if need be) at
- *                umx_set_system.  Today that is split-f16 at every size: measured against the float64 oracle both split forms carry
- *                the same systematic energy error of <= 1e-8 eV per atom (20 000 atoms: -1.5e-4 eV split-f16, -1.9e-4 eV
- *                split-bf16), so the wider form buys range, not accuracy.  UMX_AUTO_BF16_ATOMS=<n> makes "auto" take split-bf16
- *                above n atoms per image.  ENERGY ERROR BOUND of the split modes: max(1e-4 eV, 1e-8 eV x atoms) against float64
- *                arithmetic on the same weights (fp32 mode: 3e-8 eV per atom; a plain float32 evaluation in the reference's
- *                style: 1.2e-7 eV per atom).
- *   split (= split-f16): forward operands as two fp16 planes (activations) x three fp16 planes (weights, exact),
- *                4 MFMA products; reverse pass two bf16 planes, 3 products.  fp32-level accuracy; operand range +-4094.
- *   split-bf16 : forward operands as three bf16 planes, 6 products (beyond fp32 accuracy, no range limit, ~12 % slower).
- *   fp32       : every GEMM on the fp32 MFMA.                                                                          */
+ * The environment variable UMX_PRECISION is read here and fixes the arithmetic of the large SO(2)/radial GEMMs (everything
+ * else -- gather / rotate / gate / norms, the fused radial layers -- is float32 VALU / fp32-MFMA work in every mode, the node-level
+ * linears are float64-accumulated):
+ *   auto (default) = bf16x3.  The reference evaluates UMA in float32 (fairchem inference settings "default", uma_pysis.py:229,246-250);
+ *                bf16x3 is the mode in which EVERY product of both passes carries >= 24 significant bits, i.e. the like-for-like
+ *                arithmetic on the 16-bit matrix cores (ABI v9; until v8 "auto" meant split-f16).
+ *   bf16x3 (= split-exact): operands of the forward AND the reverse GEMMs as three bf16 planes (an exact split of the float32 value:
+ *                x = x0 + x1 + x2), the 6 plane products of order <= 2 on v_mfma_f32_*_bf16 (dropped terms: 2^-24 of the leading
+ *                one), fp32 accumulation.  float32's range.
+ *   split (= split-f16): the FAST mode, narrower than float32: forward operands as two fp16 planes of 16 x activation (22-23
+ *                significant bits) x three fp16 planes (weights, exact), 4 MFMA products; reverse pass two bf16 planes, 3 products
+ *                (16-bit).  Meets the tolerances with a 250x margin on forces; operand range +-4094 (UMX_ERR_RANGE beyond).
+ *   split-bf16 : forward as bf16x3 (6 products), reverse as split (3 products).
+ *   fp32       : every GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * ENERGY ERROR BOUND against float64 arithmetic on the same weights (pre-registered; tests/test_gpu_baseline_sizes.py asserts
+ * exactly these): UMX_ENERGY_TOL_EV(n_atoms) below.  A plain float32 evaluation in the reference's op style measures 1.2e-7 eV
+ * per atom.                                                                                                              */
 int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes);
 
-/* Precision mode for the NEXT umx_load_weights ("auto", "split", "split-f16", "split-bf16", "fp32"); NULL or "" = back to
+/* Precision mode for the NEXT umx_load_weights ("auto", "bf16x3" (= "split-exact"), "split" (= "split-f16"), "split-bf16", "fp32"); NULL or "" = back to
  * the UMX_PRECISION environment variable.  The Python binding uses it to re-load an engine in split-bf16 when an evaluation
  * returned UMX_ERR_RANGE (ABI v6).                                                                                   */
 int umx_set_precision(umx_engine* eng, const char* mode);
 
-/* The arithmetic the engine is in NOW: "split-f16", "split-bf16" or "fp32" ("" before weights are loaded) -- what "auto"
- * resolved to for the bound system (ABI v7).  The returned string is static.                                         */
+/* The arithmetic the engine is in NOW: "bf16x3", "split-f16", "split-bf16" or "fp32" ("" before weights are loaded) -- what "auto"
+ * resolved to (ABI v7).  The returned string is static.                                                              */
 const char* umx_precision_mode(const umx_engine* eng);
 
 /* Bind the chemical system shared by every image: atomic numbers, total charge, spin

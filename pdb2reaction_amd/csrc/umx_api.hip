@@ -82,9 +82,6 @@ struct umx_engine {
                                    // fp32 MFMA instead of the float64-accumulating kernel (k_gemm_f64acc).  Measured (round 3): the fp32-MFMA form of
                                    // these 14 chained GEMMs shifts the energy by a one-signed -2e-8 eV per atom; the double form costs +1 % at c3
   bool deg_split = true;           // UMX_DEG_SPLIT=0 (dev): edge-degree fc3 / fc3^T on the fp32-MFMA GEMM instead of the split path
-  bool auto_fmt = false;           // precision mode "auto": the forward plane format follows the system size (umx_set_system)
-  int auto_atoms = 0;              // UMX_AUTO_BF16_ATOMS (0 = never): above this many atoms per image "auto" takes three bf16 forward planes
-  std::vector<char> blob;          // the weight blob as handed in (re-packed when "auto" changes the forward plane format)
   int f16_prod = 4;                // plane products of the fp16 form (UMX_F16_PRODUCTS): 4 = exact three-plane weights (hh, hl, lh, h.lo2),
                                    // 3 = two-plane weights (hh, hl, lh; biases the energy by ~2.5e-8 eV/atom)
   std::map<const float*, float> plane_scale;             // fp16 form: power-of-two scale folded into the weight planes
@@ -1033,7 +1030,6 @@ int umx_create(umx_engine** out, int device_ordinal) {
   if (const char* ev = std::getenv("UMX_RADIAL_F16")) e->radial_f16 = std::atoi(ev) & 3;
   if (const char* ev = std::getenv("UMX_WS_EAGER")) e->ws_eager = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_WS_SOFT_EDGES")) e->ws_soft_edges = std::max(1L, std::atol(ev));
-  if (const char* ev = std::getenv("UMX_AUTO_BF16_ATOMS")) e->auto_atoms = std::max(0, std::atoi(ev));
   if (const char* ev = std::getenv("UMX_NODE_F64")) e->node_f64_on = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_DEG_SPLIT")) e->deg_split = std::atoi(ev) != 0;
   e->stream_cap = 512;
@@ -1085,9 +1081,7 @@ int umx_set_workspace_limit(umx_engine* eng, size_t bytes) {
   return UMX_OK;
 }
 
-// force_fmt: -1 = the forward plane format of the precision mode; 0 / 1 = re-pack for three bf16 / two fp16 forward planes
-// (umx_set_system in "auto" mode, when the system size asks for the other format than the one loaded)
-static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes, int force_fmt) {
+static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
   HIPCHK(eng, hipSetDevice(eng->dev));
   const char* b = static_cast<const char*>(blob);
   if (nbytes < 16 || std::memcmp(b, "UMXW0001", 8) != 0) return fail(eng, UMX_ERR_WEIGHTS, "weight blob: bad magic");
@@ -1245,17 +1239,18 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes, i
   {
     const char* pv = std::getenv("UMX_PRECISION");
     const std::string mode = !eng->precision.empty() ? eng->precision : (pv && *pv ? pv : "auto");
-    eng->auto_fmt = false;
+    // "auto" (the default) = bf16x3: the reference runs fairchem's float32 inference settings (uma_pysis.py:229,246-250), and bf16x3 is the
+    // mode whose every product, forward and reverse, carries >= 24 significant bits -- the like-for-like arithmetic.  The faster split-f16
+    // (22-bit forward activations, 16-bit reverse products) meets the tolerances with margin but is narrower: an explicit choice.
     bool rev3 = false;
     if (mode == "fp32") eng->pl = false;
-    else if (mode == "auto") { eng->pl = true; eng->fwd_fmt = eng->q3 ? 1 : 0; eng->auto_fmt = eng->q3; }   // fp16 planes until a bound system says otherwise
+    else if (mode == "auto") { eng->pl = true; eng->fwd_fmt = 0; rev3 = true; }
     else if (mode == "split" || mode == "split-f16") { eng->pl = true; eng->fwd_fmt = eng->q3 ? 1 : 0; }   // (the dev layout UMX_Q3=0 has bf16 planes only)
     else if (mode == "split-bf16") { eng->pl = true; eng->fwd_fmt = 0; }
     else if (mode == "bf16x3" || mode == "split-exact") { eng->pl = true; eng->fwd_fmt = 0; rev3 = true; }   // 24-bit products in BOTH passes
     else return fail(eng, UMX_ERR_ARG, "UMX_PRECISION must be auto, split (= split-f16), split-bf16, bf16x3 (= split-exact) or fp32");
     eng->rev_planes = (eng->pl && rev3) ? 3 : 2;
     if (mode == "split-f16" && !eng->q3) return fail(eng, UMX_ERR_ARG, "UMX_PRECISION=split-f16 needs the quad-row operand layout (UMX_Q3=1)");
-    if (force_fmt >= 0 && eng->pl) eng->fwd_fmt = force_fmt;
     // a precision change alters the workspace carve-up: force a re-carve on the next call
     eng->cap_nodes = 0; eng->cap_edges = 0;
   }
@@ -1395,11 +1390,7 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes, i
 
 int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes) {
   if (!eng || !blob) return UMX_ERR_ARG;
-  const int st = load_weights_impl(eng, blob, nbytes, -1);
-  if (st != UMX_OK) return st;
-  if (eng->auto_fmt) eng->blob.assign(static_cast<const char*>(blob), static_cast<const char*>(blob) + nbytes);   // kept for a re-pack at umx_set_system
-  else { eng->blob.clear(); eng->blob.shrink_to_fit(); }
-  return UMX_OK;
+  return load_weights_impl(eng, blob, nbytes);
 }
 
 const char* umx_precision_mode(const umx_engine* eng) {
@@ -1421,17 +1412,6 @@ int umx_set_system(umx_engine* eng, int n_atoms, const int32_t* z, int charge, i
     rs += eng->elem_refs[z[i]];
   }
   HIPCHK(eng, hipStreamSynchronize(eng->stream));
-  if (eng->auto_fmt && !eng->blob.empty()) {
-    // "auto": the engine's choice of the forward plane format for the bound system.  Round 3 measured (after the shared-constant
-    // errors were removed, DESIGN.md section 5 "Energy error vs N") that the fp16-plane form is no less accurate than the bf16 form at
-    // any size (c5: -6.4e-9 against -9.8e-9 eV per atom), so by default auto = split-f16 everywhere; UMX_AUTO_BF16_ATOMS=<n> makes it
-    // take three bf16 planes above n atoms per image (wider operand range at ~12 % of the time); the weight planes are re-packed here.
-    const int want = (eng->auto_atoms > 0 && n_atoms > eng->auto_atoms) ? 0 : 1;
-    if (want != eng->fwd_fmt) {
-      const std::vector<char> keep = eng->blob;
-      CHK(load_weights_impl(eng, keep.data(), keep.size(), want));       // (element references, hence `rs`, are unchanged by a re-pack)
-    }
-  }
   if (eng->d_z) { HIPCHK(eng, hipFree(eng->d_z)); eng->d_z = nullptr; }
   HIPCHK(eng, hipMalloc(&eng->d_z, n_atoms * sizeof(int)));
   HIPCHK(eng, hipMemcpy(eng->d_z, z, n_atoms * sizeof(int), hipMemcpyHostToDevice));

@@ -104,6 +104,10 @@ def fd_hessian(batch_forces: Callable[[np.ndarray], np.ndarray], coord_ang: np.n
 
     was_wide = bool(getattr(engine, "widened", False))
     my_columns()
+    if world == 1 and engine is not None and bool(getattr(engine, "widened", False)) and not was_wide:
+        # the engine left the fp16 operand range in the middle of THIS Hessian and widened itself: the columns computed before the switch
+        # are in the narrower arithmetic -- compute all of them again, so that one Hessian never mixes two arithmetics
+        my_columns()
     if world > 1 and engine is not None:
         flag = torch.tensor([1.0 if engine.widened else 0.0], dtype=torch.float64,
                             device="cpu" if dist.get_backend(group) == "gloo" else device)

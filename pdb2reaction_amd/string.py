@@ -50,8 +50,7 @@ def string_step(x: torch.Tensor, f: torch.Tensor, max_step: float = 0.1, alpha: 
         fp[-1] = 0.0
     step = alpha * fp
     big = step.abs().max()
-    if float(big) > max_step:
-        step = step * (max_step / big)
+    step = step * torch.clamp(max_step / big.clamp_min(1e-300), max=1.0)       # scaled on the device: no host synchronisation
     return reparametrize_equal(x + step)
 
 

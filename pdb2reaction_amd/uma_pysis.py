@@ -315,17 +315,30 @@ class uma_pysis(Calculator):
     def enable_graph_parallel(self, elem: Sequence[str], on: bool = True, group=None) -> None:
         """Reference ``workers > 1`` semantics on the engine: partition the graph of each geometry over the ranks of `group`
         (see ``UMAcore.enable_graph_parallel``).  Every later ``get_energy / get_forces / get_hessian`` call is then a collective."""
+        if on and self._hess_shard:
+            raise RuntimeError("enable_graph_parallel: FD-Hessian column sharding is on (enable_hessian_sharding); the two cannot be combined")
         self._ensure_core(elem).enable_graph_parallel(on, group)
 
     def enable_hessian_sharding(self, on: bool = True, group=None) -> None:
         """Deal the FD-Hessian columns over the ranks of `group` (default: the world) -- c4's "freq Hessian (3N force
         batches) on 8 GPUs".  From then on ``get_hessian`` is a COLLECTIVE: every rank of the group must call it with the
         same geometry (checked).  Off by default, so a Hessian requested by one rank only stays a local computation."""
+        if on and self._core is not None and getattr(self._core, "_gp", None) is not None:
+            raise RuntimeError("enable_hessian_sharding: this calculator evaluates in graph-parallel mode (workers == world size, or "
+                               "enable_graph_parallel) -- every force call is already a collective over all ranks on the SAME geometry, "
+                               "so the columns cannot be dealt to different ranks.  Use one or the other (UMX_WORKERS_GP=0 keeps "
+                               "workers>1 from switching the graph-parallel mode on)")
         self._hess_shard, self._hess_group = bool(on), group
 
     def _fd_hessian_ev(self, elem: Sequence[str], coord_ang: np.ndarray) -> Dict[str, Any]:
         """Base-point E/F plus the finite-difference Hessian (eV/A^2, torch on the core's device); hessian.fd_hessian."""
         core = self._ensure_core(elem)
+        if self._hess_shard and getattr(core, "_gp", None) is not None:
+            # ADVICE r3: with both on, every rank would displace DIFFERENT columns and enter a different number of graph-parallel
+            # collectives -- a hang, or partial sums mixed across geometries.  The graph-parallel mode wins (it may be the only way the
+            # structure fits); the columns are computed by all ranks together, un-sharded.
+            raise RuntimeError("FD Hessian: column sharding (enable_hessian_sharding) and the graph-parallel mode (workers == world size / "
+                               "enable_graph_parallel) cannot be combined: in graph-parallel mode every force call is a collective on one geometry")
         base = core.compute(coord_ang, forces=True, hessian=False)
         hess = H.fd_hessian(lambda c: core.compute_batch(c, forces=True)["forces"], coord_ang, self.freeze_atoms, device=core.device,
                             double=self.hessian_double, partial=self.return_partial_hessian, batch=FD_BATCH,

@@ -208,6 +208,24 @@ def test_analytical_request_falls_back_to_fd():
     assert h.shape == (9, 9)
 
 
+def test_graph_parallel_and_hessian_sharding_refuse_each_other():
+    """workers == world switches the graph-parallel mode on (every force call a collective on ONE geometry); dealing FD
+    columns over the ranks on top of that would hang or mix geometries.  The combination is refused in both orders."""
+    n = 3
+    c = make_calc(n)
+    c._core._gp = object()                                    # what UMAcore.enable_graph_parallel leaves behind
+    with pytest.raises(RuntimeError, match="graph-parallel"):
+        c.enable_hessian_sharding(True)
+    c._hess_shard = True                                      # switched on before the core existed / before the mode was entered
+    with pytest.raises(RuntimeError, match="cannot be combined"):
+        c.get_hessian(["H"] * n, np.ones(3 * n))
+    with pytest.raises(RuntimeError, match="cannot be combined"):
+        c.enable_graph_parallel(["H"] * n, True)
+    c._hess_shard = False
+    c._core._gp = None
+    assert c.get_hessian(["H"] * n, np.ones(3 * n))["hessian"].shape == (9, 9)
+
+
 def test_symbols_to_z():
     from pdb2reaction_amd.synth import symbols_to_z
 

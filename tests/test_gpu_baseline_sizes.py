@@ -189,7 +189,7 @@ def test_c2_c3_gsm_driver_at_baseline_sizes(n_atoms, n_img, gold):
     calc.close()
 
 
-@pytest.mark.parametrize("mode", ["auto", "split-bf16", "fp32"])
+@pytest.mark.parametrize("mode", ["auto", "split", "fp32"])
 def test_c5_energy_and_forces_against_f64_oracle(weights, mode, monkeypatch):
     """BASELINE configs[4]: a 20 000-atom image (1.6 M directed edges; one image needs more workspace than the default cap -- the
     engine then takes the full budget).  E and F against the float64 oracle (tools/make_golden_c5.py).
@@ -213,14 +213,14 @@ def test_c5_energy_and_forces_against_f64_oracle(weights, mode, monkeypatch):
     try:
         eng.load_weights(weights)
         eng.set_system(g["z"])
-        assert eng.precision_mode() == {"auto": "split-f16", "split-bf16": "split-bf16", "fp32": "fp32"}[mode]
+        assert eng.precision_mode() == {"auto": "bf16x3", "split": "split-f16", "fp32": "fp32"}[mode]
         e, f = eng.energy_forces(g["pos"][None])
         ne, maxdeg = eng.graph_stats()
         assert ne > 1_500_000 and maxdeg <= 300
         de = abs(e[0] - g["energy"][0])
         df = np.abs(f[0].astype(np.float64) - g["forces"][0])
         print(f"[c5 {mode}] |dE| = {de:.2e} eV ({de / 20000:.1e} eV/atom), max|dF| = {df.max():.2e} eV/A, rms dF = {np.sqrt((df ** 2).mean()):.2e}")
-        assert de <= max(TOL_E, {"auto": 1.0e-8, "split-bf16": 1.25e-8, "fp32": 3.0e-8}[mode] * 20000), (mode, de)
+        assert de <= max(TOL_E, {"auto": 1.25e-8, "split": 1.0e-8, "fp32": 3.0e-8}[mode] * 20000), (mode, de)
         assert df.max() <= TOL_F, (mode, df.max())
         assert not eng.widened
     finally:

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_json_line_contract():
-    out = subprocess.run([sys.executable, "bench.py", "--atoms", "60", "--images", "4", "--steps", "2", "--warmup", "1"],
+    out = subprocess.run([sys.executable, "bench.py", "--atoms", "60", "--images", "4", "--steps", "2", "--warmup", "1", "--driver", "gsm", "--gsm-cycles", "4"],
                          cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -29,14 +29,22 @@ def test_bench_json_line_contract():
     assert r["bound"] in ("hbm", "mfma") and 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     # frac is ALGORITHMIC (2*M*N*K per product / time / peak); the executed split products are the separate, larger figure
     assert abs(r["achieved"] * 1e12 - r["algorithmic_flops_per_launch"] / (r["avg_launch_ms"] * 1e-3)) <= 1e-6 * r["achieved"] * 1e12
-    assert r["mfma_pipe_util"] >= 3.0 * r["frac"] * 0.999 and r["peak"] == 2500.0
+    assert r["mfma_pipe_util"] == pytest.approx(6.0 * r["frac"], rel=1e-9) and r["peak"] == 2500.0   # bf16x3: six plane products in BOTH passes
     assert r["traffic"] is None and r["hbm_regime"]["traffic_per_step"] is None       # no PMC summary exists for this tiny workload
     hb = r["hbm_regime"]                                                             # edge kernels and fused radial kernels timed apart
     assert hb["bound"] == "hbm" and hb["ms_per_step"] > 0 and hb["radial"]["ms_per_step"] > 0 and hb["radial"]["launches"] == 2 * 10
     assert hb["ms_per_step"] + hb["radial"]["ms_per_step"] + r["ms_per_step"] + r["other_gemm_family"]["ms_per_step"] == pytest.approx(d["ms_per_step"], rel=1e-9)
-    assert d["precision_requested"] == "auto" and d["precision_mode"] == "split" and d["dtype"] == "f16-split"
-    f = d["fp32_mode"]                                                               # strict same-arithmetic figure, same clock
+    # the headline is the like-for-like mode: >= 24-bit products in both passes
+    assert d["precision_requested"] == "auto" and d["precision_mode"] == "bf16x3" and d["dtype"] == "bf16x3-split"
+    f = d["fp32_mode"]                                                               # the fp32-MFMA figure, same clock
     assert f["value"] > 0 and f["dtype"].startswith("f32") and 0.0 < f["gemm_frac"] < 1.0 and f["steps"] >= 5 and f["warmup"] >= 2
+    fm = d["fast_mode"]                                                              # the opt-in narrower mode, reported beside, never as `value`
+    assert fm["value"] > 0 and fm["precision_mode"] == "split-f16" and "narrower" in fm["dtype"]
+    g = d["gsm"]                                                                     # the real driver on the fully grown string
+    assert "error" not in g, g
+    for leg in ("climb_off", "climb_on"):
+        assert g[leg]["fully_grown"] and g[leg]["images"] == 4 and g[leg]["cycles_timed"] >= 3 and g[leg]["cycle_ms"] > 0
+        assert g[leg]["driver_overhead_ms"] == pytest.approx(g[leg]["cycle_ms"] - g["evaluation_only_ms"], rel=1e-9)
     assert len(d["build_digest"]) == 64
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):

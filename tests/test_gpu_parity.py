@@ -93,16 +93,18 @@ def switch_case(oracle):
 
 
 @pytest.mark.parametrize("env", [
-    {"UMX_FUSED_RADIAL": "0"},                                   # separate radial launches; fc3 operand written by k_ln_silu_fwd_pl<2, true>
+    {"UMX_FUSED_RADIAL": "0"},                                   # separate radial launches; fc3 operand written by k_ln_silu_fwd_pl<3, true>
+    {"UMX_FUSED_RADIAL": "0", "UMX_PRECISION": "split"},         # ... by k_ln_silu_fwd_pl<2, true>
     {"UMX_FUSED_RADIAL": "0", "UMX_PRECISION": "split-bf16"},
-    {"UMX_Q3": "0"},                                             # dev layout: bf16 PL planes + 256x128 tiles ("split" falls back to bf16 there)
-    {"UMX_Q3WIDE": "0"},
-    {"UMX_Q3S": "3"},
+    {"UMX_Q3": "0"},                                             # dev layout: bf16 PL planes + 256x128 tiles in both passes
+    {"UMX_Q3": "0", "UMX_PRECISION": "split"},                   # ("split" falls back to bf16 forward planes there)
+    {"UMX_Q3WIDE": "0"}, {"UMX_Q3WIDE": "0", "UMX_PRECISION": "split"},
+    {"UMX_Q3S": "3"}, {"UMX_Q3S": "3", "UMX_PRECISION": "split"},
     {"UMX_Q3S": "3", "UMX_PRECISION": "split-bf16"},
-    {"UMX_F16_PRODUCTS": "3"},                                   # two-plane fp16 weights
-    {"UMX_MFMA16": "0"}, {"UMX_MFMA16": "2"}, {"UMX_WIDE": "0"},
-    {"UMX_RADIAL_TR": "1"}, {"UMX_RADIAL_FAST": "2"}, {"UMX_FUSE_MODROT": "0"},
-    {"UMX_PRECISION": "bf16x3", "UMX_FUSE_MODROT": "0"}, {"UMX_PRECISION": "bf16x3", "UMX_MFMA16": "0"}, {"UMX_PRECISION": "bf16x3", "UMX_Q3": "0"},
+    {"UMX_F16_PRODUCTS": "3", "UMX_PRECISION": "split"},         # two-plane fp16 weights
+    {"UMX_MFMA16": "0"}, {"UMX_MFMA16": "2"}, {"UMX_WIDE": "0", "UMX_PRECISION": "split"},
+    {"UMX_MFMA16": "0", "UMX_PRECISION": "split"}, {"UMX_MFMA16": "2", "UMX_PRECISION": "split"},
+    {"UMX_RADIAL_TR": "1"}, {"UMX_RADIAL_FAST": "2"}, {"UMX_FUSE_MODROT": "0"}, {"UMX_FUSE_MODROT": "0", "UMX_PRECISION": "split"},
 ], ids=lambda e: ",".join(f"{k[4:]}={v}" for k, v in e.items()))
 def test_documented_switches_hold_the_tolerances(weights, switch_case, env, monkeypatch):
     """Every run-time switch of README.md selects other kernels or tilings; each combination must stay inside the north-star tolerances."""
@@ -192,7 +194,7 @@ def test_device_pointer_entry_reports_range_violations(weights, monkeypatch):
     e_t = torch.zeros(2, dtype=torch.float64, device=dev)
     f_t = torch.zeros(2, 40, 3, dtype=torch.float32, device=dev)
     ref = Engine(0, precision="split-bf16")
-    eng = Engine(0)                                             # default mode: "auto" -> fp16 planes at this size
+    eng = Engine(0, precision="split")                          # the fast mode: fp16 forward planes
     try:
         ref.load_weights(big); ref.set_system(z)
         e0, f0 = ref.energy_forces(imgs)
@@ -226,7 +228,7 @@ def test_device_pointer_entry_reports_range_violations(weights, monkeypatch):
         assert eng.widened and eng.precision_mode() == "split-bf16"
         assert np.array_equal(e.cpu().numpy(), e0) and np.array_equal(f.cpu().numpy(), f0.astype(np.float64))
         monkeypatch.setenv("UMX_NO_WIDEN", "1")
-        eng2 = Engine(0)
+        eng2 = Engine(0, precision="split")
         try:
             eng2.load_weights(big); eng2.set_system(z)
 
@@ -244,32 +246,35 @@ def test_device_pointer_entry_reports_range_violations(weights, monkeypatch):
         ref.close()
 
 
-def test_auto_precision_follows_the_system_size(weights, monkeypatch):
-    """UMX_PRECISION=auto (the default): fp16 forward planes up to UMX_AUTO_BF16_ATOMS atoms per image, three bf16 planes above --
-    decided at umx_set_system, which re-packs the weight planes; either way bitwise what the explicitly chosen mode computes."""
+def test_auto_precision_is_the_like_for_like_mode(weights, monkeypatch):
+    """UMX_PRECISION=auto (the default) resolves to bf16x3 -- every product of both passes with >= 24 significant bits, the like-for-like
+    arithmetic to the reference's float32 (uma_pysis.py:229,246-250) -- at every system size, bitwise what the explicitly chosen mode
+    computes; an explicit mode is never changed behind the caller's back."""
     from pdb2reaction_amd.engine import Engine
 
     monkeypatch.delenv("UMX_PRECISION", raising=False)
-    monkeypatch.setenv("UMX_AUTO_BF16_ATOMS", "60")
     z_s, img_s, _ = synth.make_images(40, 2, seed=3)
     z_l, img_l, _ = synth.make_images(90, 2, seed=4)
-    auto, f16, b16 = Engine(0), Engine(0, precision="split"), Engine(0, precision="split-bf16")
+    auto, x3, f16 = Engine(0), Engine(0, precision="bf16x3"), Engine(0, precision="split")
     try:
-        for e in (auto, f16, b16):
+        for e in (auto, x3, f16):
             e.load_weights(weights)
-        assert (auto.precision_mode(), f16.precision_mode(), b16.precision_mode()) == ("split-f16", "split-f16", "split-bf16")
-        for z, img, want, same in ((z_s, img_s, "split-f16", f16), (z_l, img_l, "split-bf16", b16), (z_s, img_s, "split-f16", f16),
-                                   (z_l, img_l, "split-bf16", b16)):
-            auto.set_system(z)
-            assert auto.precision_mode() == want
-            same.set_system(z)
+        assert (auto.precision_mode(), x3.precision_mode(), f16.precision_mode()) == ("bf16x3", "bf16x3", "split-f16")
+        for z, img in ((z_s, img_s), (z_l, img_l)):
+            auto.set_system(z); x3.set_system(z); f16.set_system(z)
+            assert auto.precision_mode() == "bf16x3" and f16.precision_mode() == "split-f16"
             ea, fa = auto.energy_forces(img)
-            er, fr = same.energy_forces(img)
+            er, fr = x3.energy_forces(img)
             assert np.array_equal(ea, er) and np.array_equal(fa, fr)
-        f16.set_system(z_l)                                      # an explicit mode is never changed behind the caller's back
-        assert f16.precision_mode() == "split-f16" and not auto.widened
+        assert not auto.widened
+        alias = Engine(0, precision="split-exact")
+        try:
+            alias.load_weights(weights)
+            assert alias.precision_mode() == "bf16x3"
+        finally:
+            alias.close()
     finally:
-        for e in (auto, f16, b16):
+        for e in (auto, x3, f16):
             e.close()
 
 

@@ -156,3 +156,102 @@ def test_driver_announces_the_final_string_size_to_the_calculator():
     c = U.uma_pysis()
     c.reserve_images(12)                                       # before the engine exists: kept and applied when the core is built
     assert c._reserve_images == 12 and c._core is None
+
+
+# ---- round 4: the driver's arithmetic lives on torch tensors (the engine's device on a GPU box) ----------------------------------
+def test_spline_derivative_equals_scipy_not_a_knot():
+    import torch
+    from scipy.interpolate import CubicSpline, make_interp_spline
+    from pdb2reaction_amd.gsm import spline_derivative_t
+
+    rng = np.random.default_rng(0)
+    for k in (4, 5, 9, 16):
+        x = np.cumsum(rng.standard_normal((k, 7)), axis=0)
+        u = np.concatenate([[0.0], np.cumsum(rng.uniform(0.3, 2.0, k - 1))])
+        d = spline_derivative_t(torch.as_tensor(u), torch.as_tensor(x)).numpy()
+        ref = make_interp_spline(u, x, k=3)(u, 1)
+        np.testing.assert_allclose(d, ref, rtol=0, atol=5e-12 * max(1.0, np.abs(ref).max()))
+        np.testing.assert_allclose(d, CubicSpline(u, x, bc_type="not-a-knot")(u, 1), rtol=0, atol=5e-12 * max(1.0, np.abs(ref).max()))
+
+
+def test_compact_lbfgs_equals_the_two_loop_recursion():
+    import torch
+    from pdb2reaction_amd.gsm import lbfgs_direction_t, lbfgs_two_loop_t
+
+    g = torch.Generator().manual_seed(5)
+    n = 60
+    m0 = torch.randn(n, n, dtype=torch.float64, generator=g)
+    hess = m0 @ m0.T / n + torch.eye(n, dtype=torch.float64)            # s.y > 0 for every pair
+    for m in (1, 2, 5, 10):
+        s_hist = torch.randn(m, n, dtype=torch.float64, generator=g)
+        y_hist = s_hist @ hess
+        grad = torch.randn(n, dtype=torch.float64, generator=g)
+        a, b = lbfgs_direction_t(s_hist, y_hist, grad), lbfgs_two_loop_t(s_hist, y_hist, grad)
+        assert float((a - b).abs().max()) <= 1e-11 * float(b.abs().max()) and float(a @ grad) < 0
+    assert torch.equal(lbfgs_direction_t(s_hist[:0], y_hist[:0], grad), -grad)
+
+
+def test_device_side_helpers_match_their_host_definitions():
+    import torch
+    from pdb2reaction_amd.gsm import hei_index_t, place_t
+    from pdb2reaction_amd.string import select_hei_index
+
+    rng = np.random.default_rng(1)
+    for n in (2, 3, 4, 9, 16):
+        for _ in range(40):
+            e = rng.standard_normal(n)
+            if rng.random() < 0.3:
+                e = np.sort(e)                                               # monotone: no internal maximum
+            assert int(hei_index_t(torch.as_tensor(e))) == select_hei_index(e)
+    x = np.cumsum(rng.standard_normal((7, 5)), axis=0)
+    seg = np.linalg.norm(np.diff(x, axis=0), axis=1)
+    s = np.concatenate([[0.0], np.cumsum(seg)])
+    tg = np.array([0.0, 0.1, 0.37, 0.5, 0.93, 1.0])
+    out = place_t(torch.as_tensor(x), torch.as_tensor(tg)).numpy()
+    for o, t in zip(out, tg):
+        uu = t * s[-1]
+        i = int(np.clip(np.searchsorted(s, uu, side="right"), 1, len(s) - 1))
+        w = (uu - s[i - 1]) / (s[i] - s[i - 1])
+        np.testing.assert_allclose(o, x[i - 1] * (1 - w) + x[i] * w, atol=1e-13)
+
+
+def test_device_evaluator_contract_and_timing_split():
+    """evaluate_device: torch in, torch out, same results as the numpy evaluator; the result says where the wall time went."""
+    import torch
+
+    calc = MuellerBrown()
+    kw = dict(gs_kw={"max_nodes": 9, "perp_thresh": 2e-2, "climb_rms": 5e-3}, stopt_kw={"thresh": "gau", "max_step": 0.05, "max_cycles": 400})
+    ref = GrowingStringDriver(["X"], MIN_A, MIN_B, calc, **kw).run()
+    seen = []
+
+    def evaluate_device(x):
+        assert torch.is_tensor(x) and x.dtype == torch.float64
+        seen.append(int(x.shape[0]))
+        r = calc.get_forces_batch(["X"], x.numpy())
+        return torch.as_tensor(r["energy"]), torch.as_tensor(r["forces"])
+
+    res = GrowingStringDriver(["X"], MIN_A, MIN_B, calc=None, evaluate_device=evaluate_device, device=torch.device("cpu"), **kw).run()
+    assert res.converged and res.cycles == ref.cycles and np.array_equal(res.coords, ref.coords) and np.array_equal(res.energies, ref.energies)
+    assert seen and res.force_evaluations == sum(seen)
+    t = res.timing
+    assert t["total_s"] > 0 and 0 <= t["evaluator_s"] <= t["total_s"] and abs(t["host_s"] + t["evaluator_s"] - t["total_s"]) < 1e-9
+    with pytest.raises(ValueError, match="evaluate_device"):
+        GrowingStringDriver(["X"], MIN_A, MIN_B, calc, device=torch.device("cuda", 0))
+
+
+def test_unimplemented_keywords_are_refused_or_warned_about():
+    """a reference keyword this driver ignores must not be accepted in silence when it carries a non-default value."""
+    calc = MuellerBrown()
+    for kw in ({"gs_kw": {"climb_fixed": True}}, {"gs_kw": {"scheduler": object()}}, {"stopt_kw": {"align": True}},
+               {"stopt_kw": {"scale_step": "per_image"}}, {"geom_kw": {"coord_type": "dlc"}}, {"gs_kw": {"param": "energy"}}):
+        with pytest.raises(NotImplementedError):
+            GrowingStringDriver(["X"], MIN_A, MIN_B, calc, **kw)
+    for kw, word in (({"gs_kw": {"reparam_check": "norm"}}, "reparam_check"), ({"gs_kw": {"max_micro_cycles": 25}}, "max_micro_cycles"),
+                     ({"gs_kw": {"reset_dlc": False}}, "reset_dlc"), ({"stopt_kw": {"coord_diff_thresh": 1e-3}}, "coord_diff_thresh"),
+                     ({"stopt_kw": {"reparam_thresh": 1e-3}}, "reparam_thresh"), ({"stopt_kw": {"dump": True}}, "dump")):
+        with pytest.warns(RuntimeWarning, match=word):
+            GrowingStringDriver(["X"], MIN_A, MIN_B, calc, **kw)
+    import warnings as _w
+    with _w.catch_warnings():
+        _w.simplefilter("error")                                           # the reference's own defaults pass without a word
+        GrowingStringDriver(["X"], MIN_A, MIN_B, calc, gs_kw=dict(GS_KW), stopt_kw=dict(STOPT_KW), geom_kw={"coord_type": "cart", "freeze_atoms": []})

@@ -255,3 +255,120 @@ def test_sharded_fd_hessian_never_mixes_two_arithmetics():
         assert calls[-3:] == [True, True, True] and len(calls) == 6  # 3 batches (6 DOF / 2 per batch) done twice
         assert wide_calls == 0                                       # already wide everywhere: no repetition, no widen call
     assert np.array_equal(out[0][0], out[1][0])
+
+
+# ---- a rank-local failure must not leave the peers blocked in the collective ----------------------------------------
+def _raise_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import datetime
+
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        k, n = 5, 4
+        g = torch.Generator().manual_seed(2)
+        coords = torch.randn(k, n, 3, dtype=torch.float64, generator=g)
+        state = {"n": 0}
+
+        def local(c):                                          # rank 1 fails in its SECOND call only (e.g. the sticky UMX_ERR_RANGE)
+            state["n"] += 1
+            if rank == 1 and state["n"] == 2:
+                raise ValueError("rank-local failure: non-finite position (image 0)")
+            return toy(c)
+
+        msgs = []
+        for check in ("sync", "deferred"):
+            state["n"] = 0
+            ev = ShardedImageEvaluator(local, k, n, torch.device("cpu"), check=check)
+            e, f = ev(coords)                                   # call 1: fine everywhere
+            ok = bool(torch.equal(e, toy(coords)[0]))
+            try:
+                ev(coords)                                      # call 2: rank 1 raises, rank 0 must come back too
+                if check == "deferred":
+                    ev(coords)                                  # ... at the latest at the start of the next call
+                msgs.append((ok, "no error"))
+            except Exception as exc:  # noqa: BLE001
+                msgs.append((ok, f"{type(exc).__name__}: {exc}"))
+        # a collective after the failures still works: nobody is stuck in, or has skipped, an all-gather
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        out[rank] = (msgs, float(t[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_local_failure_completes_the_collective_and_raises_everywhere():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_raise_worker, args=(2, port, out), nprocs=2, join=True)
+    (m0, t0), (m1, t1) = out[0], out[1]
+    assert t0 == t1 == 3.0
+    for ok, _ in m0 + m1:
+        assert ok
+    # sync mode: the failing rank re-raises its own exception, the peer names the failing rank -- in the same call
+    assert m1[0][1].startswith("ValueError: rank-local failure") and "raised on rank(s) [1]" in m0[0][1] and "this is rank 0" in m0[0][1]
+    # deferred mode: same for the failing rank; the peer learns it at the start of its next call
+    assert m1[1][1].startswith("ValueError: rank-local failure") and "raised on a peer rank in call 2" in m0[1][1]
+
+
+def test_deferred_check_reports_a_non_finite_energy_one_call_later():
+    eng = FakeEngine()
+    state = {"bad": False}
+
+    def local(c):
+        e, f = toy(c)
+        if state["bad"]:
+            e = e.clone()
+            e[1] = float("nan")
+        return e, f
+
+    c = torch.arange(36, dtype=torch.float64).reshape(3, 4, 3)
+    ev = ShardedImageEvaluator(local, 3, 4, torch.device("cpu"), engine=eng, check="deferred")
+    e, f = ev(c)
+    assert torch.equal(e, toy(c)[0]) and torch.equal(f, toy(c)[1])
+    ev.flush()                                                   # nothing wrong so far
+    state["bad"] = True
+    e, _ = ev(c)                                                 # returned as computed: no host look in deferred mode
+    assert not torch.isfinite(e).all() and eng.widen_calls == 0
+    state["bad"] = False
+    with pytest.raises(RuntimeError, match="non-finite energy in call 2"):
+        ev(c)
+    assert eng.flag_reads == 1
+    e, _ = ev(c)                                                 # usable again afterwards
+    assert torch.isfinite(e).all()
+    state["bad"] = True
+    ev(c)
+    with pytest.raises(RuntimeError, match="deferred check"):
+        ev.flush()
+    with pytest.raises(ValueError, match="check must be"):
+        ShardedImageEvaluator(local, 3, 4, torch.device("cpu"), check="never")
+
+
+def test_single_rank_fd_hessian_never_mixes_two_arithmetics():
+    """the repair of a Hessian whose engine widened half-way applies to the default single-rank case as well."""
+    from pdb2reaction_amd.hessian import fd_hessian
+
+    n = 4
+    rng = np.random.default_rng(0)
+    m = rng.standard_normal((3 * n, 3 * n))
+    a = m @ m.T / (3 * n) + np.eye(3 * n)
+    eng = FakeEngine()
+    calls = []
+
+    def forces(c):
+        calls.append(eng.widened)
+        if len(calls) == 3 and not eng.widened:
+            eng.widened = True
+        scale = 1.0 if eng.widened else 1.01
+        return (-(c.reshape(len(c), -1) @ a) * scale).reshape(c.shape).astype(np.float32)
+
+    x0 = rng.standard_normal((n, 3))
+    h = fd_hessian(forces, x0, [], device=torch.device("cpu"), double=True, partial=False, batch=4, engine=eng)
+    wide = FakeEngine()
+    wide.widened = True
+    h_wide = fd_hessian(lambda c: (-(c.reshape(len(c), -1) @ a)).reshape(c.shape).astype(np.float32), x0, [], device=torch.device("cpu"),
+                        double=True, partial=False, batch=4, engine=wide)
+    assert torch.equal(h, h_wide) and len(calls) == 12 and calls[6:] == [True] * 6

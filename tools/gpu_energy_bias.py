@@ -14,11 +14,8 @@ from pdb2reaction_amd.engine import Engine  # noqa: E402
 
 GOLD = os.path.join("tests", "golden")
 VARIANTS = [
-    {"UMX_PRECISION": "auto", "UMX_NODE_F64": "0"}, {"UMX_PRECISION": "auto", "UMX_NODE_F64": "1"},
-    {"UMX_PRECISION": "auto", "UMX_NODE_F64": "0", "UMX_DEG_SPLIT": "0"}, {"UMX_PRECISION": "auto", "UMX_NODE_F64": "1", "UMX_DEG_SPLIT": "0"},
-    {"UMX_PRECISION": "split-bf16", "UMX_NODE_F64": "0"}, {"UMX_PRECISION": "split-bf16", "UMX_NODE_F64": "1"},
-    {"UMX_PRECISION": "split", "UMX_NODE_F64": "0"}, {"UMX_PRECISION": "split", "UMX_NODE_F64": "1"},
-    {"UMX_PRECISION": "fp32", "UMX_NODE_F64": "0"}, {"UMX_PRECISION": "fp32", "UMX_NODE_F64": "1"},
+    {"UMX_PRECISION": "bf16x3"}, {"UMX_PRECISION": "split"}, {"UMX_PRECISION": "fp32"},
+    {"UMX_PRECISION": "bf16x3", "UMX_NODE_F64": "0"},
 ]
 which = sys.argv[1:] or ["c3", "c5"]
 w = W.make_synthetic_weights(0)

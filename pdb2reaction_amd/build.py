@@ -63,6 +63,41 @@ def needs_build() -> bool:
         return True
 
 
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+PACKED_FP32 = r"\bv_pk_(mul|add|fma)_f32\b"
+
+
+def device_disassembly(lib_path: str = OUT) -> str:
+    """llvm-objdump -d of the gfx950 code object inside a built library: the .hip_fatbin section is cut out (llvm-objcopy), the
+    offload bundle unbundled (clang-offload-bundler) and the device ELF disassembled -- the code that actually ships, every kernel
+    of every header, not a re-compilation of some of them."""
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as td:
+        fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "dev.co")
+        subprocess.run([os.path.join(LLVM_BIN, "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", lib_path, os.path.join(td, "copy.so")], check=True)
+        subprocess.run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+        return subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", co], check=True, capture_output=True, text=True).stdout
+
+
+def check_no_packed_fp32(lib_path: str = OUT) -> int:
+    """Fail when the shipped device code contains a packed-fp32 VALU instruction (timing-dependent results on gfx950 while other
+    kernels share the SIMDs; profiles/r04_k_norm_bwd_isa_diff.txt): the SLP vectoriser is off, but the
+    loop vectoriser, explicit float2 arithmetic or a compiler update could bring them back.  Returns the number of kernels checked."""
+    import re
+
+    text = device_disassembly(lib_path)
+    hits = re.findall(PACKED_FP32, text)
+    kernels = len(re.findall(r"^[0-9a-f]+ <[^>]+>:", text, flags=re.M))
+    if hits:
+        raise RuntimeError(f"{lib_path}: {len(hits)} packed-fp32 instructions (v_pk_mul/add/fma_f32) in the gfx950 code object -- "
+                           "build.FLAGS must keep them out (-fno-slp-vectorize); see DESIGN.md section 5 item 14")
+    if kernels == 0:
+        raise RuntimeError(f"{lib_path}: no kernel found in the gfx950 code object (disassembly failed?)")
+    return kernels
+
+
 def build_library(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return OUT
@@ -72,6 +107,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    check_no_packed_fp32(OUT)                    # on the linked library itself; raises and leaves no digest file behind
     with open(OUT + ".digest", "w") as f:
         f.write(digest + "\n")
     return OUT

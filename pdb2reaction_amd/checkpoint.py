@@ -23,13 +23,125 @@ from fairchem itself, which is the safer path until the restatement has been che
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, Mapping, Optional, Union
+import warnings
+from typing import Any, Callable, Dict, List, Mapping, Optional, Tuple, Union
 
 import numpy as np
 
 from . import weights as W
 
 Array = np.ndarray
+
+ASSUME_UMA_S = "assume-uma-s"
+
+
+class UnsupportedCheckpoint(ValueError):
+    """The checkpoint's own model config asks for something libumx does not implement."""
+
+
+# ---- the checkpoint's model config: read it, take what is a free parameter, refuse what the engine does not implement ----------
+# What the HIP engine IS (csrc/umx_common.h constants, weights.py).  Every hyper-parameter below is compiled into the kernels; a
+# checkpoint that says otherwise cannot be evaluated by this library and must be refused -- not evaluated as if it were UMA-S
+# (VERDICT r3 item 6).  Names are fairchem's eSCN-MD backbone keywords as recalled in SURVEY.md Appendix A [3P-UNVERIFIED]; aliases cover
+# the spellings seen in public configs.  A config that does not mention a key leaves that key unchecked (listed in the blob's
+# ``model.unchecked_engine_keys``).
+ENGINE_CONFIG: Dict[str, Any] = {
+    "sphere_channels": W.SPHERE_CHANNELS, "hidden_channels": W.HIDDEN_CHANNELS, "edge_channels": W.EDGE_CHANNELS,
+    "lmax": W.LMAX, "mmax": W.MMAX, "num_layers": W.NUM_LAYERS, "num_distance_basis": W.NUM_DISTANCE_BASIS,
+    "distance_function": "gaussian", "norm_type": "rms_norm_sh", "act_type": "gate", "ff_type": "spectral",
+    "chg_spin_emb_type": "rand_emb", "max_num_elements": W.MAX_NUM_ELEMENTS, "direct_forces": False, "regress_stress": False,
+    "always_use_pbc": False, "use_pbc": False, "use_pbc_single": False,
+}
+_ALIASES = {"num_sphere_channels": "sphere_channels", "n_layers": "num_layers", "num_gaussians": "num_distance_basis",
+            "max_neighbours": "max_neighbors", "max_neigh": "max_neighbors", "radius": "cutoff", "cutoff_radius": "cutoff"}
+# free parameters the engine takes FROM the checkpoint (umx_set_system defaults; the reference reads them from the backbone,
+# uma_pysis.py:301-309): validated for type / range only
+_TAKEN = ("cutoff", "max_neighbors", "dataset_list", "num_experts")
+# keys that do not change the arithmetic of an inference call
+_BENIGN = {"name", "model", "otf_graph", "activation_checkpointing", "regress_forces", "regress_energy", "use_compile", "compile",
+           "use_dataset_embedding", "heads", "backbone", "freeze_backbone", "pass_through_head_outputs", "model_id", "finetune"}
+
+
+def find_model_config(ckpt: Mapping[str, Any]) -> Optional[Dict[str, Any]]:
+    """The backbone's hyper-parameter dict inside a checkpoint mapping: the first dict (breadth first) that has both ``lmax`` and
+    ``sphere_channels`` (or their aliases) -- wherever the trainer nested it (``config.model.backbone``, ``model_config``,
+    ``hyper_parameters`` ... [3P-UNVERIFIED]).  None when the checkpoint carries no such dict."""
+    queue: List[Any] = [ckpt]
+    seen = 0
+    while queue and seen < 10000:
+        node = queue.pop(0)
+        seen += 1
+        if isinstance(node, Mapping):
+            keys = {_ALIASES.get(str(k), str(k)) for k in node.keys()}
+            if "lmax" in keys and "sphere_channels" in keys:
+                return {str(k): v for k, v in node.items()}
+            queue.extend(v for k, v in node.items() if isinstance(v, (Mapping, list, tuple)) and "state_dict" not in str(k))
+        elif isinstance(node, (list, tuple)):
+            queue.extend(v for v in node if isinstance(v, (Mapping, list, tuple)))
+    return None
+
+
+def validate_model_config(config: Mapping[str, Any], *, strict_unknown: bool = False) -> Dict[str, Any]:
+    """Hold a checkpoint's model config against what the engine implements.  Returns the ``model`` record that goes into the blob
+    trailer: ``{"cutoff", "max_neighbors", "num_experts", "checked": [...], "unchecked_engine_keys": [...], "unknown_keys": [...]}``.
+
+    * a key of :data:`ENGINE_CONFIG` with another value -> :class:`UnsupportedCheckpoint` naming EVERY mismatch (``ff_type='grid'``:
+      there is no kernel for the grid feed-forward; ``lmax=3``: the Wigner blocks, the 9-row layouts and every GEMM shape are lmax=2);
+    * ``cutoff`` / ``max_neighbors`` are the checkpoint's to choose (any positive value: they are run-time arguments of
+      ``umx_set_system``), ``dataset_list`` must be the engine's task order (the dataset embedding rows are indexed by it);
+    * keys nobody knows are reported (warning, or an error with ``strict_unknown``) -- they may or may not change the arithmetic."""
+    cfg = {_ALIASES.get(str(k), str(k)): v for k, v in config.items()}
+    bad, checked = [], []
+    for key, want in ENGINE_CONFIG.items():
+        if key not in cfg:
+            continue
+        have = cfg[key]
+        same = (str(have).lower().replace("-", "_") == str(want).lower()) if isinstance(want, str) else (have == want and type(have) in (type(want), int, bool, float))
+        if isinstance(want, bool):
+            same = bool(have) == want
+        (checked if same else bad).append(key if same else f"{key}={have!r} (the engine implements {want!r})")
+    model: Dict[str, Any] = {}
+    if "cutoff" in cfg:
+        c = float(cfg["cutoff"])
+        if not (0.0 < c < 100.0):
+            bad.append(f"cutoff={cfg['cutoff']!r} (must be a positive radius in Angstrom)")
+        model["cutoff"] = c
+    if "max_neighbors" in cfg:
+        m = int(cfg["max_neighbors"])
+        if m <= 0:
+            bad.append(f"max_neighbors={cfg['max_neighbors']!r} (must be positive)")
+        model["max_neighbors"] = m
+    if "dataset_list" in cfg:
+        dl = tuple(str(x) for x in cfg["dataset_list"])
+        if dl != tuple(W.DATASET_LIST):
+            bad.append(f"dataset_list={list(dl)!r} (the engine's dataset embedding is indexed in the order {list(W.DATASET_LIST)!r})")
+    if "num_experts" in cfg:
+        model["num_experts"] = int(cfg["num_experts"])
+    if bad:
+        raise UnsupportedCheckpoint("this checkpoint's model config is not the UMA-S (eSCN-MD, lmax = mmax = 2) model libumx implements: " + "; ".join(bad))
+    unknown = sorted(k for k in cfg if k not in ENGINE_CONFIG and k not in _TAKEN and k not in _BENIGN)
+    if unknown:
+        msg = (f"checkpoint model config has {len(unknown)} key(s) this loader does not know: {unknown[:12]}{' ...' if len(unknown) > 12 else ''} -- "
+               "they are NOT checked against the engine")
+        if strict_unknown:
+            raise UnsupportedCheckpoint(msg)
+        warnings.warn(msg, RuntimeWarning, stacklevel=2)
+    model["checked"] = sorted(checked)
+    model["unchecked_engine_keys"] = sorted(k for k in ENGINE_CONFIG if k not in cfg)
+    model["unknown_keys"] = unknown
+    return model
+
+
+def _model_record(model_config: Union[None, str, Mapping[str, Any]], strict_unknown: bool) -> Dict[str, Any]:
+    if model_config is None:
+        raise ValueError("convert: pass model_config= the checkpoint's own model config (checkpoint.find_model_config(ckpt)) so that it can be "
+                         f"held against the engine, or model_config={ASSUME_UMA_S!r} to state explicitly that the tensors are UMA-S "
+                         "(cutoff 6.0 A, max_neighbors 300, spectral feed-forward ...) without a config to prove it")
+    if isinstance(model_config, str):
+        if model_config != ASSUME_UMA_S:
+            raise ValueError(f"model_config must be a mapping or {ASSUME_UMA_S!r}")
+        return {"cutoff": W.CUTOFF, "max_neighbors": W.MAX_NEIGHBORS, "assumed": True}
+    return validate_model_config(model_config, strict_unknown=strict_unknown)
 
 
 def _np(t) -> Array:
@@ -155,13 +267,53 @@ def convert_for_system(state: Mapping[str, object], atomic_numbers, charge: int,
     return convert(state, coefficients=alpha, merged_for=W.system_record(atomic_numbers, charge, spin, task), rename=rename, **kw)
 
 
-def convert(state: Mapping[str, object], *, merged_for: Optional[Mapping[str, object]] = None, **kw) -> bytes:
+def convert(state: Mapping[str, object], *, merged_for: Optional[Mapping[str, object]] = None,
+            model_config: Union[None, str, Mapping[str, Any]] = None, strict_unknown: bool = False, **kw) -> bytes:
     """State dict -> UMXW0001 blob (``weights.pack_blob`` of ``from_state_dict``).
+
+    ``model_config`` (REQUIRED): the checkpoint's own hyper-parameters (:func:`find_model_config`) -- held against the engine
+    (:func:`validate_model_config`: anything libumx does not implement raises :class:`UnsupportedCheckpoint`), and its ``cutoff`` /
+    ``max_neighbors`` go into the blob trailer (``model``), from where ``UMAcore`` takes them as the defaults of ``umx_set_system``
+    exactly as the reference takes them from the backbone (``uma_pysis.py:301-309``).  ``"assume-uma-s"`` states the assumption
+    explicitly for tensors that come without a config.  The normaliser (``normalizer.rmsd``) and the element references
+    (``element_refs``) are mandatory (``extra=``): the reference applies them (``uma_pysis.py:231-239``), so a blob without them would
+    return energies on another scale.
 
     ``merged_for`` = ``weights.system_record(atomic_numbers, charge, spin, task)`` of the system the MoLE coefficients were
     computed for; it is stored in the blob trailer and checked whenever the blob is bound to a system.  It is REQUIRED when
     ``coefficients`` are given: a merged parameter set is only valid for that one (composition, charge, spin, task)."""
     if kw.get("coefficients") is not None and merged_for is None:
         raise ValueError("convert(coefficients=...) needs merged_for=weights.system_record(...): a MoLE merge is valid for one system only")
-    meta = {"merged_for": dict(merged_for)} if merged_for is not None else None
+    model = _model_record(model_config, strict_unknown)
+    have = set(kw.get("extra") or {}) | set(state)
+    for need in ("normalizer.rmsd", "element_refs"):
+        if not any(k == need or k.endswith("." + need) for k in have):
+            raise KeyError(f"convert: {need!r} is mandatory (extra={{...}}): the energy normaliser and the per-element reference energies of the "
+                           "task are part of the model's answer (reference uma_pysis.py:231-239)")
+    meta: Dict[str, Any] = {"model": model}
+    if merged_for is not None:
+        meta["merged_for"] = dict(merged_for)
     return W.pack_blob(from_state_dict(state, **kw), meta=meta)
+
+
+def convert_checkpoint(ckpt: Mapping[str, Any], atomic_numbers, charge: int, spin: int, task: str, *, state_key: Optional[str] = None,
+                       **kw) -> bytes:
+    """A whole checkpoint mapping (what ``torch.load`` returns: model config + state dict [+ normaliser / references]) -> merged blob
+    for one system.  The model config is FOUND in the checkpoint (:func:`find_model_config`) -- a checkpoint without one is refused
+    unless ``model_config=`` is given -- validated, and the state dict is taken from ``state_key`` or the first of
+    ``ema_state_dict`` / ``state_dict`` / ``model_state_dict`` / ``model`` that holds tensors [3P-UNVERIFIED]."""
+    cfg = kw.pop("model_config", None)
+    if cfg is None:
+        cfg = find_model_config(ckpt)
+        if cfg is None:
+            raise UnsupportedCheckpoint("the checkpoint carries no model config (no mapping with 'lmax' and 'sphere_channels'): it cannot be "
+                                        f"checked against the engine; pass model_config=... (or {ASSUME_UMA_S!r}) explicitly")
+    state = None
+    for key in ([state_key] if state_key else ["ema_state_dict", "state_dict", "model_state_dict", "model"]):
+        cand = ckpt.get(key)
+        if isinstance(cand, Mapping) and any(hasattr(v, "shape") for v in cand.values()):
+            state = cand
+            break
+    if state is None:
+        raise KeyError("convert_checkpoint: no state dict found in the checkpoint (tried " + (state_key or "ema_state_dict, state_dict, model_state_dict, model") + ")")
+    return convert_for_system(state, atomic_numbers, charge, spin, task, model_config=cfg, **kw)

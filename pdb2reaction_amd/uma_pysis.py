@@ -153,6 +153,24 @@ class UMAcore:
         self._r_edges_user = r_edges
 
         weights = resolve_weights(model)                    # raises FileNotFoundError before any GPU work
+        # graph defaults come from the MODEL, as in the reference (backbone.cutoff / backbone.max_neighbors, fallback 6.0 A;
+        # uma_pysis.py:301-309): a converted checkpoint records them in the blob trailer (checkpoint.validate_model_config)
+        model_rec = (getattr(weights, "meta", None) or {}).get("model") or {}
+        if radius is None and model_rec.get("cutoff") is not None:
+            radius = float(model_rec["cutoff"])
+        if max_neigh is None and model_rec.get("max_neighbors") is not None:
+            max_neigh = int(model_rec["max_neighbors"])
+        self.model_record = dict(model_rec)
+        if r_edges:
+            import warnings
+            warnings.warn("uma_pysis: r_edges=True has no effect here: the radius graph is always built on the device for every call "
+                          "(the reference collates with otf_graph=True as well, uma_pysis.py:322, so pre-computed edges are not what its model uses)",
+                          RuntimeWarning, stacklevel=3)
+        if self.workers_per_node != 1:
+            import warnings
+            warnings.warn(f"uma_pysis: workers_per_node={self.workers_per_node} has no effect here: there are no Ray actors to place "
+                          "(uma_pysis.py:228-242); under torch.distributed the launcher decides which rank runs on which node",
+                          RuntimeWarning, stacklevel=3)
         self.z = synth.symbols_to_z(self.elem)
         W.check_merged_for(weights, self.z, charge, spin, task_name)   # a MoLE merge is valid for one system only
         self.engine = Engine(_device_index(device), precision=precision)     # None: UMX_PRECISION (default "auto")

@@ -9,6 +9,13 @@ from pdb2reaction_amd import weights as W
 
 CK = importlib.import_module("pdb2reaction_amd.checkpoint")
 
+# a model config as a fairchem eSCN-MD backbone would carry it ([3P-UNVERIFIED] names)
+UMA_S_CONFIG = {"model": "escnmd_backbone", "sphere_channels": 128, "hidden_channels": 128, "edge_channels": 128, "lmax": 2, "mmax": 2,
+                "num_layers": 4, "num_distance_basis": 64, "distance_function": "gaussian", "norm_type": "rms_norm_sh", "act_type": "gate",
+                "ff_type": "spectral", "chg_spin_emb_type": "rand_emb", "cutoff": 6.0, "max_neighbors": 300, "max_num_elements": 100,
+                "otf_graph": True, "direct_forces": False, "regress_stress": False, "always_use_pbc": False,
+                "dataset_list": ["oc20", "omol", "omat", "odac", "omc"], "num_experts": 4, "use_dataset_embedding": True}
+
 
 def _fake_state(w, n_exp=4, seed=3):
     """Split every SO(2) linear into n_exp random experts whose alpha-weighted sum is the merged weight."""
@@ -37,9 +44,11 @@ def test_merge_and_roundtrip():
         assert got[k].dtype == np.float32
         np.testing.assert_allclose(got[k], w[k], rtol=0, atol=2e-6 * max(1.0, np.abs(w[k]).max()))
     with pytest.raises(ValueError, match="merged_for"):
-        CK.convert(state, coefficients=alpha, extra=extra)                  # a merge without its system record is refused
+        CK.convert(state, coefficients=alpha, extra=extra, model_config=CK.ASSUME_UMA_S)   # a merge without its system record is refused
     rec = W.system_record([1, 1, 6, 8, 1], 0, 1, "omol")
-    blob = CK.convert(state, coefficients=alpha, extra=extra, merged_for=rec)
+    with pytest.raises(ValueError, match="model_config"):
+        CK.convert(state, coefficients=alpha, extra=extra, merged_for=rec)  # no config, no stated assumption: refused
+    blob = CK.convert(state, coefficients=alpha, extra=extra, merged_for=rec, model_config=CK.ASSUME_UMA_S)
     back = W.unpack_blob(blob)
     assert all(np.array_equal(back[k], got[k]) for k in got)
     # the blob remembers the system the experts were merged for and refuses any other
@@ -107,7 +116,7 @@ def test_mole_routing_and_convert_for_system():
     h = sd["routing_mlp.2.weight"] @ silu(sd["routing_mlp.0.weight"] @ x + sd["routing_mlp.0.bias"]) + sd["routing_mlp.2.bias"]
     np.testing.assert_allclose(a, np.exp(h - h.max()) / np.exp(h - h.max()).sum(), rtol=1e-12)
     # full conversion: merged with alpha, routing tensors dropped, bound to the system
-    blob = CK.convert_for_system(state, z, 0, 1, "omol", extra=extra)
+    blob = CK.convert_for_system(state, z, 0, 1, "omol", extra=extra, model_config=UMA_S_CONFIG)
     back = W.unpack_blob(blob)
     assert set(back) == set(W.param_shapes()) and back.meta["merged_for"] == W.system_record(z, 0, 1, "omol")
     key = "blocks.0.edge_wise.so2_conv_1.fc_m0.weight"
@@ -117,3 +126,90 @@ def test_mole_routing_and_convert_for_system():
         W.check_merged_for(back, z + [1], 0, 1, "omol")
     with pytest.raises(KeyError, match="routing"):
         CK.mole_coefficients({k: v for k, v in state.items() if "routing_mlp" not in k}, z, 0, 1, "omol")
+
+
+def test_model_config_is_read_and_held_against_the_engine():
+    """the loader reads the checkpoint's OWN model config, takes cutoff / max_neighbors from it and refuses
+    everything libumx does not implement -- one synthetic checkpoint per mismatch."""
+    model = CK.validate_model_config(UMA_S_CONFIG)
+    assert model["cutoff"] == 6.0 and model["max_neighbors"] == 300 and model["num_experts"] == 4
+    assert "ff_type" in model["checked"] and "lmax" in model["checked"] and model["unknown_keys"] == []
+    assert "use_pbc" in model["unchecked_engine_keys"]                      # not mentioned by this config: reported, not assumed
+    for key, val, word in [("ff_type", "grid", "ff_type='grid'"), ("lmax", 3, "lmax=3"), ("mmax", 1, "mmax=1"), ("sphere_channels", 256, "sphere_channels=256"),
+                           ("hidden_channels", 64, "hidden_channels"), ("edge_channels", 64, "edge_channels"), ("num_layers", 6, "num_layers=6"),
+                           ("num_distance_basis", 128, "num_distance_basis=128"), ("distance_function", "bessel", "distance_function"),
+                           ("norm_type", "layer_norm_sh", "norm_type"), ("act_type", "s2", "act_type"), ("chg_spin_emb_type", "pos_emb", "chg_spin_emb_type"),
+                           ("direct_forces", True, "direct_forces"), ("regress_stress", True, "regress_stress"), ("always_use_pbc", True, "always_use_pbc"),
+                           ("max_num_elements", 118, "max_num_elements"), ("cutoff", -1.0, "cutoff"), ("max_neighbors", 0, "max_neighbors"),
+                           ("dataset_list", ["omol", "oc20", "omat", "odac", "omc"], "dataset_list")]:
+        with pytest.raises(CK.UnsupportedCheckpoint, match=word.split("=")[0]) as ei:
+            CK.validate_model_config({**UMA_S_CONFIG, key: val})
+        assert word.split("=")[0] in str(ei.value)
+    with pytest.raises(CK.UnsupportedCheckpoint) as ei:                      # every mismatch is named, not just the first
+        CK.validate_model_config({**UMA_S_CONFIG, "ff_type": "grid", "lmax": 4})
+    assert "ff_type" in str(ei.value) and "lmax" in str(ei.value)
+    # free parameters: taken over, aliases understood
+    m2 = CK.validate_model_config({**{k: v for k, v in UMA_S_CONFIG.items() if k not in ("cutoff", "max_neighbors")}, "radius": 5.0, "max_neigh": 40})
+    assert m2["cutoff"] == 5.0 and m2["max_neighbors"] == 40
+    # unknown keys: reported, or refused on request
+    with pytest.warns(RuntimeWarning, match="does not know"):
+        m3 = CK.validate_model_config({**UMA_S_CONFIG, "so2_attention": True})
+    assert m3["unknown_keys"] == ["so2_attention"]
+    with pytest.raises(CK.UnsupportedCheckpoint, match="so2_attention"):
+        CK.validate_model_config({**UMA_S_CONFIG, "so2_attention": True}, strict_unknown=True)
+
+
+def test_convert_checkpoint_finds_the_config_and_the_blob_carries_the_graph_defaults():
+    w = W.make_synthetic_weights(0)
+    state, _, extra = _fake_state(w)
+    rng = np.random.default_rng(11)
+    n_exp = next(v.shape[0] for k, v in state.items() if k.endswith(".weights"))
+    c = W.SPHERE_CHANNELS
+    state["backbone.composition_embedding.weight"] = torch.tensor(rng.standard_normal((W.MAX_NUM_ELEMENTS, c)))
+    state["backbone.routing_mlp.0.weight"] = torch.tensor(rng.standard_normal((n_exp, 2 * c)) / np.sqrt(2 * c))
+    state["backbone.routing_mlp.0.bias"] = torch.tensor(0.1 * rng.standard_normal(n_exp))
+    z = [8, 1, 1]
+    cfg = {**UMA_S_CONFIG, "cutoff": 5.5, "max_neighbors": 120}
+    ckpt = {"epoch": 3, "config": {"optim": {"lr": 1e-3}, "model": {"name": "hydra", "backbone": cfg, "heads": {"energy": {"module": "mlp_efs"}}}},
+            "ema_state_dict": state}
+    assert CK.find_model_config(ckpt) == cfg and CK.find_model_config({"state_dict": state}) is None
+    blob = CK.convert_checkpoint(ckpt, z, 0, 1, "omol", extra=extra)
+    back = W.unpack_blob(blob)
+    assert back.meta["model"]["cutoff"] == 5.5 and back.meta["model"]["max_neighbors"] == 120 and back.meta["merged_for"] == W.system_record(z, 0, 1, "omol")
+    with pytest.raises(CK.UnsupportedCheckpoint, match="no model config"):
+        CK.convert_checkpoint({"state_dict": state}, z, 0, 1, "omol", extra=extra)
+    with pytest.raises(CK.UnsupportedCheckpoint, match="ff_type"):
+        CK.convert_checkpoint({**ckpt, "config": {"model": {"backbone": {**cfg, "ff_type": "grid"}}}}, z, 0, 1, "omol", extra=extra)
+    with pytest.raises(KeyError, match="normalizer.rmsd"):
+        CK.convert_checkpoint(ckpt, z, 0, 1, "omol")                        # normaliser / element references are mandatory
+    with pytest.raises(KeyError, match="no state dict"):
+        CK.convert_checkpoint({"config": ckpt["config"]}, z, 0, 1, "omol", extra=extra)
+    # the calculator takes the graph defaults from the blob (reference: backbone.cutoff / backbone.max_neighbors, uma_pysis.py:301-309)
+    import importlib as _il
+    U = _il.import_module("pdb2reaction_amd.uma_pysis")
+    seen = {}
+
+    class FakeEngine:
+        def __init__(self, *a, **k): pass
+        def load_weights(self, wts): seen["meta"] = getattr(wts, "meta", {})
+        def set_system(self, zz, charge=0, spin=1, task="omol", radius=None, max_neigh=None): seen.update(radius=radius, max_neigh=max_neigh)
+
+    import pdb2reaction_amd.engine as E
+    import tempfile, os as _os
+    with tempfile.TemporaryDirectory() as td:
+        path = _os.path.join(td, "m.umxw")
+        with open(path, "wb") as f:
+            f.write(blob)
+        real = E.Engine
+        E.Engine = FakeEngine
+        try:
+            core = U.UMAcore(["O", "H", "H"], model=path)
+            assert seen["radius"] == 5.5 and seen["max_neigh"] == 120 and core.model_record["cutoff"] == 5.5
+            U.UMAcore(["O", "H", "H"], model=path, radius=4.0, max_neigh=10)          # the caller's values win, as in the reference
+            assert seen["radius"] == 4.0 and seen["max_neigh"] == 10
+            with pytest.warns(RuntimeWarning, match="r_edges"):
+                U.UMAcore(["O", "H", "H"], model=path, r_edges=True)
+            with pytest.warns(RuntimeWarning, match="workers_per_node"):
+                U.UMAcore(["O", "H", "H"], model=path, workers_per_node=4)
+        finally:
+            E.Engine = real

@@ -248,7 +248,11 @@ def test_real_checkpoint_path_end_to_end(tmp_path, monkeypatch, oracle, setup):
     state["backbone.routing_mlp.0.bias"] = T.tensor(0.1 * rng.standard_normal(32))
     state["backbone.routing_mlp.2.weight"] = T.tensor(rng.standard_normal((n_exp, 32)) / 6.0)
     state["backbone.routing_mlp.2.bias"] = T.tensor(0.1 * rng.standard_normal(n_exp))
-    blob = CK.convert_for_system(state, z, 0, 1, "omol", extra=extra)
+    from test_checkpoint import UMA_S_CONFIG
+    # the checkpoint says cutoff 5.0 A / 40 neighbours: the calculator must evaluate with THOSE (reference: backbone.cutoff /
+    # backbone.max_neighbors, uma_pysis.py:301-309), and the oracle below is run with the same graph
+    ckpt = {"config": {"model": {"backbone": {**UMA_S_CONFIG, "cutoff": 5.0, "max_neighbors": 40}}}, "state_dict": state}
+    blob = CK.convert_checkpoint(ckpt, z, 0, 1, "omol", extra=extra)
     (tmp_path / "uma-s-1p1.umxw").write_bytes(blob)
     monkeypatch.setenv("UMX_WEIGHTS_DIR", str(tmp_path))
     monkeypatch.delenv("UMX_ALLOW_SYNTHETIC", raising=False)
@@ -257,7 +261,10 @@ def test_real_checkpoint_path_end_to_end(tmp_path, monkeypatch, oracle, setup):
     r = calc.get_forces(elem, x_bohr)
     from oracle.escn_md_oracle import Oracle
     merged = W.unpack_blob(blob)
-    e_ref, f_ref = Oracle(merged).energy_forces(z, imgs[0].astype(np.float32).astype(np.float64))
+    assert merged.meta["model"]["cutoff"] == 5.0 and calc._core.model_record["max_neighbors"] == 40
+    e_ref, f_ref = Oracle(merged, cutoff=5.0, max_neigh=40).energy_forces(z, imgs[0].astype(np.float32).astype(np.float64))
+    e_6, _ = Oracle(merged).energy_forces(z, imgs[0].astype(np.float32).astype(np.float64))
+    assert abs(e_6 - e_ref) > 1e-3                              # the default 6.0 A / 300 graph gives another energy: the blob's values matter
     assert abs(r["energy"] / U.EV2AU - e_ref) <= 1e-4
     assert np.abs(r["forces"].reshape(-1, 3) / U.F_EVAA_2_AU - f_ref).max() <= 1e-3
     # the merged experts differ from the un-routed synthetic set, so this really is the file's physics

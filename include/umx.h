@@ -73,9 +73,14 @@ const char* umx_last_error(const umx_engine* eng);
  *                (16-bit).  Meets the tolerances with a 250x margin on forces; operand range +-4094 (UMX_ERR_RANGE beyond).
  *   split-bf16 : forward as bf16x3 (6 products), reverse as split (3 products).
  *   fp32       : every GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32).
- * ENERGY ERROR BOUND against float64 arithmetic on the same weights (pre-registered; tests/test_gpu_baseline_sizes.py asserts
- * exactly these): UMX_ENERGY_TOL_EV(n_atoms) below.  A plain float32 evaluation in the reference's op style measures 1.2e-7 eV
- * per atom.                                                                                                              */
+ * ENERGY ERROR BOUNDS against float64 arithmetic on the same weights (pre-registered here; tests/test_gpu_baseline_sizes.py asserts
+ * exactly these): UMX_ENERGY_TOL_EV in the default and the split modes at every BASELINE size (up to 20 000 atoms per image),
+ * UMX_ENERGY_TOL_EV_FP32(n_atoms) in the fp32 mode.  A plain float32 evaluation in the reference's op style measures 1.2e-7 eV per atom. */
+#define UMX_ENERGY_TOL_EV 1.0e-4                 /* the north-star tolerance */
+#define UMX_FORCE_TOL_EV_PER_A 1.0e-3
+/* fp32 mode: its large GEMMs are float32 fma chains on the fp32 matrix pipe; the bound is half a float32 unit round-off (2^-24 / 2) of a
+ * 1 eV atomic energy per atom once that exceeds the absolute tolerance -- an a-priori figure, not a fit */
+#define UMX_ENERGY_TOL_EV_FP32(n_atoms) ((n_atoms) * 2.98023223876953125e-8 > 1.0e-4 ? (n_atoms) * 2.98023223876953125e-8 : 1.0e-4)
 int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes);
 
 /* Precision mode for the NEXT umx_load_weights ("auto", "bf16x3" (= "split-exact"), "split" (= "split-f16"), "split-bf16", "fp32"); NULL or "" = back to

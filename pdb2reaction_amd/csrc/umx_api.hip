@@ -74,6 +74,7 @@ struct umx_engine {
   int q3_stages = 2;               // UMX_Q3S: LDS ring depth of the forward Q3 GEMMs (2 or 3)
   bool q3_wide = true;             // UMX_Q3WIDE=0 (dev): 256x128 tiles for every forward GEMM
   bool q3 = true;                  // UMX_Q3=0: forward operands in the 32-column PL layout + 256x128 tiles (set before umx_load_weights)
+  float odd_sign = -1.0f;          // sign-alternating operand rows (umx_kernels_pl.h): -1 = on (default), +1 = off (UMX_ALT_ROWS=0, dev A/B)
   int rev_planes = 2;              // bf16 planes of the REVERSE-pass operands: 2 (3 products, 16-bit) or 3 (6 products, 24-bit: UMX_PRECISION=bf16x3)
   int fwd_fmt = 1;                 // forward operand format (QFmt, umx_kernels_pl.h): 1 = two fp16 planes (UMX_PRECISION=split), 0 = three bf16 planes (split-bf16)
   std::string precision;           // umx_set_precision: overrides UMX_PRECISION when non-empty
@@ -276,6 +277,7 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
   std::memset(&q, 0, sizeof(q));
   q.Apl = Apl; q.lda = (long)a_cols * P; q.offA0 = offA0; q.offA1 = offA1; q.Bpl = it->second; q.ldb = (long)K * P; q.bHalf = bHalf;
   q.Cp = Cp; q.ldc = ldc; q.offC = offC; q.offCi = offCi; q.bias = bias; q.conj = conj; q.M = (int)M; q.N = N; q.K = K;
+  q.odd_sign = eng->odd_sign;
   // reverse pass (P=2: two ring stages of a 256x256 tile fit the LDS): the wide tile needs a third less L2->LDS fill per FLOP and
   // measured 9-11 % faster wherever N fills whole tiles (UMX_WIDE=0 disables)
   // Small systems (c1: 50 atoms x 8 images = 13 k edges = 51 row tiles): a launch whose wide grid does not even put one workgroup on
@@ -472,16 +474,16 @@ int radial_fwd_head(umx_engine* eng, const WS& w, const RadialW& r, int slot, lo
     do {                                                                                                              \
       const int fm = eng->radial_fast;                                                                                \
       if (TR == 1) {                                                                                                  \
-        if (fm == 2) hipLaunchKernelGGL((k_radial_head<Q, 2, 1>), UMX_RH_ARGS, (void*)(OUT), ne);                      \
-        else if (fm == 1) hipLaunchKernelGGL((k_radial_head<Q, 1, 1>), UMX_RH_ARGS, (void*)(OUT), ne);                 \
-        else hipLaunchKernelGGL((k_radial_head<Q, 0, 1>), UMX_RH_ARGS, (void*)(OUT), ne);                              \
+        if (fm == 2) hipLaunchKernelGGL((k_radial_head<Q, 2, 1>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign);                      \
+        else if (fm == 1) hipLaunchKernelGGL((k_radial_head<Q, 1, 1>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign);                 \
+        else hipLaunchKernelGGL((k_radial_head<Q, 0, 1>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign);                              \
       } else {                                                                                                        \
-        if (fm == 2) hipLaunchKernelGGL((k_radial_head<Q, 2, 2>), UMX_RH_ARGS, (void*)(OUT), ne);                      \
-        else if (fm == 1) hipLaunchKernelGGL((k_radial_head<Q, 1, 2>), UMX_RH_ARGS, (void*)(OUT), ne);                 \
-        else if (Q == 2 && eng->radial_f16 == 3) hipLaunchKernelGGL((k_radial_head<Q, 0, 2, (Q == 2 ? 3 : 0)>), UMX_RH_ARGS, (void*)(OUT), ne); \
-        else if (Q == 2 && eng->radial_f16 == 2) hipLaunchKernelGGL((k_radial_head<Q, 0, 2, (Q == 2 ? 2 : 0)>), UMX_RH_ARGS, (void*)(OUT), ne); \
-        else if (Q == 2 && eng->radial_f16 == 1) hipLaunchKernelGGL((k_radial_head<Q, 0, 2, (Q == 2 ? 1 : 0)>), UMX_RH_ARGS, (void*)(OUT), ne); \
-        else hipLaunchKernelGGL((k_radial_head<Q, 0, 2>), UMX_RH_ARGS, (void*)(OUT), ne);                              \
+        if (fm == 2) hipLaunchKernelGGL((k_radial_head<Q, 2, 2>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign);                      \
+        else if (fm == 1) hipLaunchKernelGGL((k_radial_head<Q, 1, 2>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign);                 \
+        else if (Q == 2 && eng->radial_f16 == 3) hipLaunchKernelGGL((k_radial_head<Q, 0, 2, (Q == 2 ? 3 : 0)>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign); \
+        else if (Q == 2 && eng->radial_f16 == 2) hipLaunchKernelGGL((k_radial_head<Q, 0, 2, (Q == 2 ? 2 : 0)>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign); \
+        else if (Q == 2 && eng->radial_f16 == 1) hipLaunchKernelGGL((k_radial_head<Q, 0, 2, (Q == 2 ? 1 : 0)>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign); \
+        else hipLaunchKernelGGL((k_radial_head<Q, 0, 2>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign);                              \
       }                                                                                                               \
     } while (0)
     ProfRec* pr = prof_open(eng, 2.0 * ne * ((double)NG * RH + (double)RH * RH), -1, ne, RH, NG + RH);
@@ -500,9 +502,9 @@ int radial_fwd_head(umx_engine* eng, const WS& w, const RadialW& r, int slot, lo
   hipLaunchKernelGGL(k_ln_silu_fwd, dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h1pre[slot], r.ln1w, r.ln1b, w.ra, ne);
   CHK(gemm_plain(eng, w.ra, RH, 0, r.w2, RH, r.b2, w.h2pre[slot], RH, 0, ne, RH, RH));
   if (eng->pl && eng->planes.count(r.w3)) {
-    if (eng->q3 && eng->fwd_fmt == 1) hipLaunchKernelGGL((k_ln_silu_fwd_pl<2, true>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne);
-    else if (eng->q3) hipLaunchKernelGGL((k_ln_silu_fwd_pl<3, true>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne);
-    else hipLaunchKernelGGL((k_ln_silu_fwd_pl<3, false>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne);
+    if (eng->q3 && eng->fwd_fmt == 1) hipLaunchKernelGGL((k_ln_silu_fwd_pl<2, true>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne, eng->odd_sign);
+    else if (eng->q3) hipLaunchKernelGGL((k_ln_silu_fwd_pl<3, true>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne, eng->odd_sign);
+    else hipLaunchKernelGGL((k_ln_silu_fwd_pl<3, false>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne, eng->odd_sign);
   } else {
     hipLaunchKernelGGL(k_ln_silu_fwd, dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.ra, ne);
   }
@@ -668,9 +670,9 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
         hipStream_t s = eng->stream;
         // the NEXT layer's radial head (geometry only; a2pl is free: this layer's fc3 has consumed it) beside this HBM-bound kernel
         if (side && i + 1 < NL) CHK(side_launch(eng->ev_shead, [=, &w]() -> int { return radial_fwd_head(eng, w, eng->lw[i + 1].rad, i + 1, ne); }));
-        if (eng->q3 && eng->fwd_fmt == 1) hipLaunchKernelGGL(k_gather_rotate_mod_q3<1>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne);
-        else if (eng->q3) hipLaunchKernelGGL(k_gather_rotate_mod_q3<0>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne);
-        else hipLaunchKernelGGL((k_gather_rotate_mod_pl<3, false>), dim3((nblk(ne, 4) + 7) / 8 * 8), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne);
+        if (eng->q3 && eng->fwd_fmt == 1) hipLaunchKernelGGL(k_gather_rotate_mod_q3<1>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne, eng->odd_sign);
+        else if (eng->q3) hipLaunchKernelGGL(k_gather_rotate_mod_q3<0>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne, eng->odd_sign);
+        else hipLaunchKernelGGL((k_gather_rotate_mod_pl<3, false>), dim3((nblk(ne, 4) + 7) / 8 * 8), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne, eng->odd_sign);
         HIPCHK(eng, hipGetLastError());
         return UMX_OK;
       });
@@ -682,9 +684,9 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       });
       P.stream([=, &w]() -> int {
         hipStream_t s = eng->stream;
-        if (eng->q3 && eng->fwd_fmt == 1) hipLaunchKernelGGL(k_gate_edge_fwd_q3<1>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hg[i], w.hidpl, ne);
-        else if (eng->q3) hipLaunchKernelGGL(k_gate_edge_fwd_q3<0>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hg[i], w.hidpl, ne);
-        else hipLaunchKernelGGL((k_gate_edge_fwd_pl<3, false>), dim3(nblk(ne * (H / 4), 256)), B256, 0, s, w.hg[i], w.hidpl, ne);
+        if (eng->q3 && eng->fwd_fmt == 1) hipLaunchKernelGGL(k_gate_edge_fwd_q3<1>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hg[i], w.hidpl, ne, eng->odd_sign);
+        else if (eng->q3) hipLaunchKernelGGL(k_gate_edge_fwd_q3<0>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hg[i], w.hidpl, ne, eng->odd_sign);
+        else hipLaunchKernelGGL((k_gate_edge_fwd_pl<3, false>), dim3(nblk(ne * (H / 4), 256)), B256, 0, s, w.hg[i], w.hidpl, ne, eng->odd_sign);
         HIPCHK(eng, hipGetLastError());
         return UMX_OK;
       });
@@ -800,8 +802,8 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       DBG("g_xmid" + t, w.G2, nn * ROW);
       if (ne > 0 && eng->pl)
       {
-        if (eng->rev_planes == 3) hipLaunchKernelGGL(k_rotate_back_bwd_pl<3>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne);
-        else hipLaunchKernelGGL(k_rotate_back_bwd_pl<2>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne);
+        if (eng->rev_planes == 3) hipLaunchKernelGGL(k_rotate_back_bwd_pl<3>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne, eng->odd_sign);
+        else hipLaunchKernelGGL(k_rotate_back_bwd_pl<2>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne, eng->odd_sign);
       }
       HIPCHK(eng, hipGetLastError());
       return UMX_OK;
@@ -818,8 +820,8 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
         // the radial tail of the layer ABOVE (it feeds only dE/dd) beside this HBM-bound kernel -- not right behind its fc3^T GEMM, where
         // it would run next to the node-level and SO(2) GEMMs and slow those down by as much as it hides (measured)
         if (side && i + 1 < NL) CHK(side_launch(eng->ev_stail, [=, &w]() -> int { return radial_bwd_tail(eng, w, eng->lw[i + 1].rad, i + 1, ne); }));
-        if (eng->rev_planes == 3) hipLaunchKernelGGL(k_gate_edge_bwd_pl<3>, dim3(vgrid(eng, nblk(ne * (H / 4), 256))), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne);
-        else hipLaunchKernelGGL(k_gate_edge_bwd_pl<2>, dim3(vgrid(eng, nblk(ne * (H / 4), 256))), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne);
+        if (eng->rev_planes == 3) hipLaunchKernelGGL(k_gate_edge_bwd_pl<3>, dim3(vgrid(eng, nblk(ne * (H / 4), 256))), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne, eng->odd_sign);
+        else hipLaunchKernelGGL(k_gate_edge_bwd_pl<2>, dim3(vgrid(eng, nblk(ne * (H / 4), 256))), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne, eng->odd_sign);
         HIPCHK(eng, hipGetLastError());
         return UMX_OK;
       });
@@ -834,12 +836,12 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
         hipStream_t s = eng->stream;
         if (eng->fuse_modrot) {       // one node-centric kernel: modulation backward + rotate-back + segmented sum (g_xrot stays in registers)
           if (eng->rev_planes == 3) hipLaunchKernelGGL(k_modrot_bwd_pl<3>, dim3((unsigned)nn), B256, 0, s, w.gy1, w.xn[i], w.frame, w.rad[i], w.row_ptr, w.out_ptr, w.out_edge,
-                                                       w.gradpl, w.tau, w.tau2, w.G1, nn);
+                                                       w.gradpl, w.tau, w.tau2, w.G1, nn, eng->odd_sign);
           else hipLaunchKernelGGL(k_modrot_bwd_pl<2>, dim3((unsigned)nn), B256, 0, s, w.gy1, w.xn[i], w.frame, w.rad[i], w.row_ptr, w.out_ptr, w.out_edge,
-                                  w.gradpl, w.tau, w.tau2, w.G1, nn);
+                                  w.gradpl, w.tau, w.tau2, w.G1, nn, eng->odd_sign);
         } else {
-          if (eng->rev_planes == 3) hipLaunchKernelGGL(k_modulate_bwd_pl<3>, dim3(nblk(ne, 4)), B256, 0, s, w.gy1, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.gradpl, w.tau, ne);
-          else hipLaunchKernelGGL(k_modulate_bwd_pl<2>, dim3(nblk(ne, 4)), B256, 0, s, w.gy1, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.gradpl, w.tau, ne);
+          if (eng->rev_planes == 3) hipLaunchKernelGGL(k_modulate_bwd_pl<3>, dim3(nblk(ne, 4)), B256, 0, s, w.gy1, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.gradpl, w.tau, ne, eng->odd_sign);
+          else hipLaunchKernelGGL(k_modulate_bwd_pl<2>, dim3(nblk(ne, 4)), B256, 0, s, w.gy1, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.gradpl, w.tau, ne, eng->odd_sign);
           DBG("g_xrot." + std::to_string(i), w.gy1, ne * XROT);
         }
         HIPCHK(eng, hipGetLastError());
@@ -902,9 +904,9 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       // split path: the gradient of the edge-degree radial output goes straight into the PL planes of the fc3^T GEMM (gmsgpl is free here)
       const bool dpl = eng->pl && eng->planes.count(eng->rdeg.w3T) != 0;
       if (dpl && eng->rev_planes == 3) hipLaunchKernelGGL((k_rotate_back_bwd<3, 3>), dim3(nblk(ne, 4)), B256, 0, s, w.G0, w.rad_deg, w.frame, w.edst,
-                                                          reinterpret_cast<float*>(w.gmsgpl), w.dedd, w.tau, ne, DEG_RESCALE);
+                                                          reinterpret_cast<float*>(w.gmsgpl), w.dedd, w.tau, ne, DEG_RESCALE, eng->odd_sign);
       else if (dpl) hipLaunchKernelGGL((k_rotate_back_bwd<3, 2>), dim3(nblk(ne, 4)), B256, 0, s, w.G0, w.rad_deg, w.frame, w.edst,
-                                       reinterpret_cast<float*>(w.gmsgpl), w.dedd, w.tau, ne, DEG_RESCALE);
+                                       reinterpret_cast<float*>(w.gmsgpl), w.dedd, w.tau, ne, DEG_RESCALE, eng->odd_sign);
       else hipLaunchKernelGGL(k_rotate_back_bwd<3>, dim3(nblk(ne, 4)), B256, 0, s, w.G0, w.rad_deg, w.frame, w.edst, w.gmsg, w.dedd, w.tau, ne,
                               DEG_RESCALE);
       if (side) HIPCHK(eng, hipStreamWaitEvent(s, eng->ev_stail, 0));        // join: layer 1's tail, the last one issued on the side stream (e128a, dedd_rad)
@@ -991,7 +993,7 @@ std::vector<float> transpose(const float* src, int rows, int cols) {
 // ================================================================================================
 extern "C" {
 
-int umx_abi_version(void) { return 8; }
+int umx_abi_version(void) { return 9; }
 
 #ifndef UMX_SRC_DIGEST
 #define UMX_SRC_DIGEST "unknown"
@@ -1031,6 +1033,7 @@ int umx_create(umx_engine** out, int device_ordinal) {
   if (const char* ev = std::getenv("UMX_WS_EAGER")) e->ws_eager = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_WS_SOFT_EDGES")) e->ws_soft_edges = std::max(1L, std::atol(ev));
   if (const char* ev = std::getenv("UMX_NODE_F64")) e->node_f64_on = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("UMX_ALT_ROWS")) e->odd_sign = std::atoi(ev) != 0 ? -1.0f : 1.0f;
   if (const char* ev = std::getenv("UMX_DEG_SPLIT")) e->deg_split = std::atoi(ev) != 0;
   e->stream_cap = 512;
   if (const char* ev = std::getenv("UMX_STREAM_BLOCKS")) e->stream_cap = std::max(0, std::atoi(ev)) / 8 * 8;

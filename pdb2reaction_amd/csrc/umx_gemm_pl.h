@@ -43,6 +43,9 @@ struct GemmPL {
   float conj;
   int M, N, K;       // CPLX: M = edges, N = channels per half
   float cscale;      // fp16-plane kernels only (umx_gemm_q.h, F16 = 1): C = cscale * (A' . B'^T) undoes the power-of-two operand scales
+  float odd_sign;    // +1, or -1 when the producer stored the A rows of ODD index negated (sign-alternating rows, umx_kernels_pl.h): the
+                     // epilogue multiplies the accumulators of odd rows by it, so C is what it would be -- with the matrix core's one-sided
+                     // rounding error reversed on every second row.  0 is read as +1 (dev programs that memset the struct).
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -190,6 +193,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, 1) void umx_gemm_pl_kernel(const Ge
   // ---- epilogue (C/D map of 32x32 tiles: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)); straight-line
   //      stores on the block-uniform fast path, see gemm_epilogue in umx_gemm.h
   const bool full = ((long)mt * BMR + BMR <= p.M) && (nt * BNC + BNC <= p.N);
+  const float osg = p.odd_sign < 0.f ? -1.0f : 1.0f;
   if (ABL & 4) {
     float sum = 0.f;
     for (int i = 0; i < WMT; ++i) for (int j = 0; j < WNT; ++j) for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
@@ -208,8 +212,9 @@ __global__ __launch_bounds__(64 * WVM * WVN, 1) void umx_gemm_pl_kernel(const Ge
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float* cr = c + (long)((r & 3) + 8 * (r >> 2)) * p.ldc;
-            cr[p.offC] = acc[eg][cg][r] - p.conj * acc[WMT / 2 + eg][WNT / 2 + cg][r];
-            cr[p.offCi] = acc[WMT / 2 + eg][cg][r] + p.conj * acc[eg][WNT / 2 + cg][r];
+            const float sg = (r & 1) ? osg : 1.0f;                         // row parity = r & 1 (tile origins are even)
+            cr[p.offC] = sg * (acc[eg][cg][r] - p.conj * acc[WMT / 2 + eg][WNT / 2 + cg][r]);
+            cr[p.offCi] = sg * (acc[WMT / 2 + eg][cg][r] + p.conj * acc[eg][WNT / 2 + cg][r]);
           }
         } else if (chan < p.N) {
 #pragma unroll
@@ -217,8 +222,9 @@ __global__ __launch_bounds__(64 * WVM * WVN, 1) void umx_gemm_pl_kernel(const Ge
             const int dr = (r & 3) + 8 * (r >> 2);
             if (e0 + dr < p.M) {
               float* cr = c + (long)dr * p.ldc;
-              cr[p.offC] = acc[eg][cg][r] - p.conj * acc[WMT / 2 + eg][WNT / 2 + cg][r];
-              cr[p.offCi] = acc[WMT / 2 + eg][cg][r] + p.conj * acc[eg][WNT / 2 + cg][r];
+              const float sg = (r & 1) ? osg : 1.0f;
+              cr[p.offC] = sg * (acc[eg][cg][r] - p.conj * acc[WMT / 2 + eg][WNT / 2 + cg][r]);
+              cr[p.offCi] = sg * (acc[WMT / 2 + eg][cg][r] + p.conj * acc[eg][WNT / 2 + cg][r]);
             }
           }
         }
@@ -239,12 +245,12 @@ __global__ __launch_bounds__(64 * WVM * WVN, 1) void umx_gemm_pl_kernel(const Ge
         float* c = p.Cp + row0 * p.ldc + p.offC + col;
         if (full) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) c[(long)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[i][j][r] + bv[j];
+          for (int r = 0; r < 16; ++r) c[(long)((r & 3) + 8 * (r >> 2)) * p.ldc] = ((r & 1) ? osg : 1.0f) * acc[i][j][r] + bv[j];
         } else if (col < p.N) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int dr = (r & 3) + 8 * (r >> 2);
-            if (row0 + dr < p.M) c[(long)dr * p.ldc] = acc[i][j][r] + bv[j];
+            if (row0 + dr < p.M) c[(long)dr * p.ldc] = ((r & 1) ? osg : 1.0f) * acc[i][j][r] + bv[j];
           }
         }
       }
@@ -356,8 +362,9 @@ __global__ __launch_bounds__(64 * WVM * WVN, 1) void umx_gemm_pl16_kernel(const 
       }
   }
 
-  // ---- epilogue (C/D map of 16x16 tiles: col = lane&15, row = reg + 4*(lane>>4))
+  // ---- epilogue (C/D map of 16x16 tiles: col = lane&15, row = reg + 4*(lane>>4): row parity = reg & 1)
   const bool full = ((long)mt * BMR + BMR <= p.M) && (nt * BNC + BNC <= p.N);
+  const float osg = p.odd_sign < 0.f ? -1.0f : 1.0f;
   if (CPLX) {
 #pragma unroll
     for (int eg = 0; eg < TM / 2; ++eg)
@@ -370,16 +377,18 @@ __global__ __launch_bounds__(64 * WVM * WVN, 1) void umx_gemm_pl16_kernel(const 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float* cr = c + (long)r * p.ldc;
-            cr[p.offC] = acc[eg][cg][r] - p.conj * acc[TM / 2 + eg][TN / 2 + cg][r];
-            cr[p.offCi] = acc[TM / 2 + eg][cg][r] + p.conj * acc[eg][TN / 2 + cg][r];
+            const float sg = (r & 1) ? osg : 1.0f;
+            cr[p.offC] = sg * (acc[eg][cg][r] - p.conj * acc[TM / 2 + eg][TN / 2 + cg][r]);
+            cr[p.offCi] = sg * (acc[TM / 2 + eg][cg][r] + p.conj * acc[eg][TN / 2 + cg][r]);
           }
         } else if (chan < p.N) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if (e0 + r < p.M) {
               float* cr = c + (long)r * p.ldc;
-              cr[p.offC] = acc[eg][cg][r] - p.conj * acc[TM / 2 + eg][TN / 2 + cg][r];
-              cr[p.offCi] = acc[TM / 2 + eg][cg][r] + p.conj * acc[eg][TN / 2 + cg][r];
+              const float sg = (r & 1) ? osg : 1.0f;
+              cr[p.offC] = sg * (acc[eg][cg][r] - p.conj * acc[TM / 2 + eg][TN / 2 + cg][r]);
+              cr[p.offCi] = sg * (acc[TM / 2 + eg][cg][r] + p.conj * acc[eg][TN / 2 + cg][r]);
             }
           }
         }
@@ -395,11 +404,11 @@ __global__ __launch_bounds__(64 * WVM * WVN, 1) void umx_gemm_pl16_kernel(const 
         float* c = p.Cp + row0 * p.ldc + p.offC + col;
         if (full) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) c[(long)r * p.ldc] = acc[i][j][r] + bv;
+          for (int r = 0; r < 4; ++r) c[(long)r * p.ldc] = ((r & 1) ? osg : 1.0f) * acc[i][j][r] + bv;
         } else if (col < p.N) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (row0 + r < p.M) c[(long)r * p.ldc] = acc[i][j][r] + bv;
+            if (row0 + r < p.M) c[(long)r * p.ldc] = ((r & 1) ? osg : 1.0f) * acc[i][j][r] + bv;
         }
       }
   }

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
   // ---- epilogue (C/D map of 32x32 tiles: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)); block-uniform fast path
   const bool full = ((long)mt * BMR + BMR <= p.M) && (nt * BNC + BNC <= p.N);
   const float cs = F16 ? p.cscale : 1.f;          // a power of two: exact (bf16 planes are unscaled, the multiply folds away)
+  const float cso = p.odd_sign < 0.f ? -cs : cs;  // odd rows: the producer stored them negated (sign-alternating rows, umx_kernels_pl.h); row parity = r & 1
   if (CPLX) {
 #pragma unroll
     for (int cg = 0; cg < TNW / 2; ++cg) {
@@ -196,8 +197,8 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float* cr = c + (long)((r & 3) + 8 * (r >> 2)) * p.ldc;
-          cr[p.offC] = cs * (acc[0][cg][r] - p.conj * acc[1][TNW / 2 + cg][r]);
-          cr[p.offCi] = cs * (acc[1][cg][r] + p.conj * acc[0][TNW / 2 + cg][r]);
+          cr[p.offC] = ((r & 1) ? cso : cs) * (acc[0][cg][r] - p.conj * acc[1][TNW / 2 + cg][r]);
+          cr[p.offCi] = ((r & 1) ? cso : cs) * (acc[1][cg][r] + p.conj * acc[0][TNW / 2 + cg][r]);
         }
       } else if (chan < p.N) {
 #pragma unroll
@@ -205,8 +206,8 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
           const int dr = (r & 3) + 8 * (r >> 2);
           if (e0 + dr < p.M) {
             float* cr = c + (long)dr * p.ldc;
-            cr[p.offC] = cs * (acc[0][cg][r] - p.conj * acc[1][TNW / 2 + cg][r]);
-            cr[p.offCi] = cs * (acc[1][cg][r] + p.conj * acc[0][TNW / 2 + cg][r]);
+            cr[p.offC] = ((r & 1) ? cso : cs) * (acc[0][cg][r] - p.conj * acc[1][TNW / 2 + cg][r]);
+            cr[p.offCi] = ((r & 1) ? cso : cs) * (acc[1][cg][r] + p.conj * acc[0][TNW / 2 + cg][r]);
           }
         }
       }
@@ -222,12 +223,12 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
         float* c = p.Cp + row0 * p.ldc + p.offC + col;
         if (full) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) c[(long)((r & 3) + 8 * (r >> 2)) * p.ldc] = cs * acc[i][j][r] + bv;
+          for (int r = 0; r < 16; ++r) c[(long)((r & 3) + 8 * (r >> 2)) * p.ldc] = ((r & 1) ? cso : cs) * acc[i][j][r] + bv;
         } else if (col < p.N) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int dr = (r & 3) + 8 * (r >> 2);
-            if (row0 + dr < p.M) c[(long)dr * p.ldc] = cs * acc[i][j][r] + bv;
+            if (row0 + dr < p.M) c[(long)dr * p.ldc] = ((r & 1) ? cso : cs) * acc[i][j][r] + bv;
           }
         }
       }

@@ -573,7 +573,7 @@ template <int NROWS, int PLP = 0>
 __global__ __launch_bounds__(256) void k_rotate_back_bwd(const float* __restrict__ gnode, const float* __restrict__ msg,
                                                          const float* __restrict__ frame, const int* __restrict__ edst,
                                                          float* __restrict__ gmsg, float* __restrict__ dedd,
-                                                         float* __restrict__ tau, long ne, float div) {
+                                                         float* __restrict__ tau, long ne, float div, float odd_sign = 1.0f) {
   UMX_WAVE_ITEM(e, ne)
   const int c0 = lane * 2;
   const float* f = frame + e * FRAME;
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256) void k_rotate_back_bwd(const float* __restrict
   torque_acc(ly, my, -1.0f, tx, ty, tz);
 #pragma unroll
   for (int r = 0; r < NROWS; ++r) {
-    if (PLP) pl_store2<(PLP ? PLP : 2)>(reinterpret_cast<unsigned short*>(gmsg) + e * (long)(NROWS * C * PLP), r * C + c0, lx[r], ly[r]);
+    if (PLP) pl_store2<(PLP ? PLP : 2)>(reinterpret_cast<unsigned short*>(gmsg) + e * (long)(NROWS * C * PLP), r * C + c0, row_sign(e, odd_sign) * lx[r], row_sign(e, odd_sign) * ly[r]);
     else *reinterpret_cast<float2*>(gmsg + e * (NROWS * C) + r * C + c0) = make_float2(lx[r], ly[r]);
   }
   s = wave_sum(s); tx = wave_sum(tx); ty = wave_sum(ty); tz = wave_sum(tz);

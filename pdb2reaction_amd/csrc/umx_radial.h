@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
                                                         const float* __restrict__ ln1w, const float* __restrict__ ln1b,
                                                         const float* __restrict__ w2, const float* __restrict__ b2,
                                                         const float* __restrict__ ln2w, const float* __restrict__ ln2b,
-                                                        float* __restrict__ h1pre, float* __restrict__ h2pre, void* __restrict__ out, long ne) {
+                                                        float* __restrict__ h1pre, float* __restrict__ h2pre, void* __restrict__ out, long ne,
+                                                        float odd_sign) {
   constexpr int RT = 32 * TR;
   __shared__ __attribute__((aligned(16))) float bufA[RT * R_LD];
   __shared__ __attribute__((aligned(16))) float bufB[RT * R_LD];
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
       const float2 o = (UMX_ABL & 2) ? v : ln_silu_row<FAST>(v, l2w, l2b);
       if (!(UMX_ABL & 16) && e < ne) {
         *reinterpret_cast<float2*>(h2pre + e * RH + 2 * lane) = v;
-        if (OUTQ3) q_store2<(OUTQ3 == 2)>(reinterpret_cast<unsigned short*>(out), e, RH, 2 * lane, o.x, o.y);
+        if (OUTQ3) q_store2<(OUTQ3 == 2)>(reinterpret_cast<unsigned short*>(out), e, RH, 2 * lane, row_sign(e, odd_sign) * o.x, row_sign(e, odd_sign) * o.y);
         else *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + e * RH + 2 * lane) = o;
       }
     }

@@ -14,8 +14,8 @@ from pdb2reaction_amd.engine import Engine  # noqa: E402
 
 GOLD = os.path.join("tests", "golden")
 VARIANTS = [
-    {"UMX_PRECISION": "bf16x3"}, {"UMX_PRECISION": "split"}, {"UMX_PRECISION": "fp32"},
-    {"UMX_PRECISION": "bf16x3", "UMX_NODE_F64": "0"},
+    {"UMX_PRECISION": "bf16x3"}, {"UMX_PRECISION": "bf16x3", "UMX_ALT_ROWS": "0"}, {"UMX_PRECISION": "split"}, {"UMX_PRECISION": "split", "UMX_ALT_ROWS": "0"},
+    {"UMX_PRECISION": "fp32"},
 ]
 which = sys.argv[1:] or ["c3", "c5"]
 w = W.make_synthetic_weights(0)
@@ -26,7 +26,7 @@ for name in which:
     e_ref = g["energy"] if name == "c5" else g["c3_energy"]
     f_ref = g["forces"][None] if name == "c5" else g["c3_forces"]
     for env in VARIANTS:
-        for k in ("UMX_PRECISION", "UMX_NODE_F64", "UMX_DEG_SPLIT"):
+        for k in ("UMX_PRECISION", "UMX_NODE_F64", "UMX_DEG_SPLIT", "UMX_ALT_ROWS"):
             os.environ.pop(k, None)
         os.environ.update(env)
         eng = Engine(0)

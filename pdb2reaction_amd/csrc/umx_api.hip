@@ -74,6 +74,8 @@ struct umx_engine {
   int q3_stages = 2;               // UMX_Q3S: LDS ring depth of the forward Q3 GEMMs (2 or 3)
   bool q3_wide = true;             // UMX_Q3WIDE=0 (dev): 256x128 tiles for every forward GEMM
   bool q3 = true;                  // UMX_Q3=0: forward operands in the 32-column PL layout + 256x128 tiles (set before umx_load_weights)
+  bool rev_q3 = true;              // UMX_REV_Q3=0: reverse operands of the bf16x3 mode in the PL layout (256x128 tiles) instead of the quad-row layout
+  std::map<const float*, bool> planes_q;                  // weight plane copies stored in the quad-row layout (else PL)
   float odd_sign = -1.0f;          // sign-alternating operand rows (umx_kernels_pl.h): -1 = on (default), +1 = off (UMX_ALT_ROWS=0, dev A/B)
   int rev_planes = 2;              // bf16 planes of the REVERSE-pass operands: 2 (3 products, 16-bit) or 3 (6 products, 24-bit: UMX_PRECISION=bf16x3)
   int fwd_fmt = 1;                 // forward operand format (QFmt, umx_kernels_pl.h): 1 = two fp16 planes (UMX_PRECISION=split), 0 = three bf16 planes (split-bf16)
@@ -303,7 +305,16 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
   // MFMA shape per GEMM (measured in the c3 pipeline): 16x16x32 wins 1-7 % on the complex SO(2) GEMMs and on K >= 512,
   // 32x32x16 wins 5-10 % on the short-K plain ones (radial fc3 and its transpose, conv-2 m=0)
   const bool use16 = eng->mfma16 >= 2 || (eng->mfma16 == 1 && (cplx || K >= 512));
-  if (fwd && eng->q3) {
+  const auto pq = eng->planes_q.find(Wkey);
+  const bool revq = !fwd && P == 3 && pq != eng->planes_q.end() && pq->second;      // reverse operands of the bf16x3 mode in the quad-row layout
+  if (revq) {
+    const bool wq = eng->q3_wide && N % (cplx ? 128 : 256) == 0 && fills;
+    const int bnq = wq ? (cplx ? 128 : 256) : (cplx ? 64 : 128);
+    const long nNq = (N + bnq - 1) / bnq;
+    dim3 gq((unsigned)(((nM + 7) / 8) * 8 * nNq));
+    if (cplx) { if (wq) hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<1, 0>), gq, block, 0, eng->stream, q); }
+    else      { if (wq) hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0>), gq, block, 0, eng->stream, q); }
+  } else if (fwd && eng->q3) {
     // forward operands in the quad-row layout: 256x256 tiles where N fills them, else 256x128 (umx_gemm_q.h)
     const bool wq = eng->q3_wide && N % (cplx ? 128 : 256) == 0 && fills;
     const int bnq = wq ? (cplx ? 128 : 256) : (cplx ? 64 : 128);
@@ -431,8 +442,8 @@ void carve_trans(Bump& b, long ne, WS& t, int pl) {
     const long ne4 = (ne + 3) / 4 * 4;          // the quad-row (Q3) layout stores rows in groups of four
     const long fp = pl & 15, rp = (pl & 16) ? 3 : 2;             // planes of the forward / reverse operands
     t.y1pl = b.take<unsigned short>(ne4 * XROT * fp); t.hidpl = b.take<unsigned short>(ne4 * ROW * fp);
-    t.a2pl = b.take<unsigned short>(ne4 * RH * fp); t.gmsgpl = b.take<unsigned short>(ne * ROW * rp);
-    t.ghgpl = b.take<unsigned short>(ne * HG * rp); t.gradpl = b.take<unsigned short>(ne * RAD * rp);
+    t.a2pl = b.take<unsigned short>(ne4 * RH * fp); t.gmsgpl = b.take<unsigned short>(ne4 * ROW * rp);      // (ne4: the quad-row form of the bf16x3 reverse operands)
+    t.ghgpl = b.take<unsigned short>(ne4 * HG * rp); t.gradpl = b.take<unsigned short>(ne * RAD * rp);
   } else {
     t.xrot = b.take<float>(ne * XROT); t.gmsg = b.take<float>(ne * ROW);
     t.ghg = b.take<float>(ne * HG); t.grad = b.take<float>(ne * RAD);
@@ -802,7 +813,8 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       DBG("g_xmid" + t, w.G2, nn * ROW);
       if (ne > 0 && eng->pl)
       {
-        if (eng->rev_planes == 3) hipLaunchKernelGGL(k_rotate_back_bwd_pl<3>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne, eng->odd_sign);
+        if (eng->rev_planes == 3 && eng->q3 && eng->rev_q3) hipLaunchKernelGGL(k_rotate_back_bwd_q3, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne, eng->odd_sign);
+        else if (eng->rev_planes == 3) hipLaunchKernelGGL(k_rotate_back_bwd_pl<3>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne, eng->odd_sign);
         else hipLaunchKernelGGL(k_rotate_back_bwd_pl<2>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne, eng->odd_sign);
       }
       HIPCHK(eng, hipGetLastError());
@@ -820,7 +832,8 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
         // the radial tail of the layer ABOVE (it feeds only dE/dd) beside this HBM-bound kernel -- not right behind its fc3^T GEMM, where
         // it would run next to the node-level and SO(2) GEMMs and slow those down by as much as it hides (measured)
         if (side && i + 1 < NL) CHK(side_launch(eng->ev_stail, [=, &w]() -> int { return radial_bwd_tail(eng, w, eng->lw[i + 1].rad, i + 1, ne); }));
-        if (eng->rev_planes == 3) hipLaunchKernelGGL(k_gate_edge_bwd_pl<3>, dim3(vgrid(eng, nblk(ne * (H / 4), 256))), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne, eng->odd_sign);
+        if (eng->rev_planes == 3 && eng->q3 && eng->rev_q3) hipLaunchKernelGGL(k_gate_edge_bwd_q3, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne, eng->odd_sign);
+        else if (eng->rev_planes == 3) hipLaunchKernelGGL(k_gate_edge_bwd_pl<3>, dim3(vgrid(eng, nblk(ne * (H / 4), 256))), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne, eng->odd_sign);
         else hipLaunchKernelGGL(k_gate_edge_bwd_pl<2>, dim3(vgrid(eng, nblk(ne * (H / 4), 256))), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne, eng->odd_sign);
         HIPCHK(eng, hipGetLastError());
         return UMX_OK;
@@ -1033,6 +1046,7 @@ int umx_create(umx_engine** out, int device_ordinal) {
   if (const char* ev = std::getenv("UMX_WS_EAGER")) e->ws_eager = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_WS_SOFT_EDGES")) e->ws_soft_edges = std::max(1L, std::atol(ev));
   if (const char* ev = std::getenv("UMX_NODE_F64")) e->node_f64_on = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("UMX_REV_Q3")) e->rev_q3 = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_ALT_ROWS")) e->odd_sign = std::atoi(ev) != 0 ? -1.0f : 1.0f;
   if (const char* ev = std::getenv("UMX_DEG_SPLIT")) e->deg_split = std::atoi(ev) != 0;
   e->stream_cap = 512;
@@ -1305,9 +1319,12 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
   };
   // P = 3: a forward weight (quad-row layout / fp16 planes as the mode says); P = 2: a transposed (reverse-pass) weight -- always the PL
   // layout, with the engine's reverse plane count
-  auto want_planes = [&](const float* host, const float* dev, int rows, int K, int P) {
+  eng->planes_q.clear();
+  auto want_planes = [&](const float* host, const float* dev, int rows, int K, int P, bool rev_quad = false) {
     const bool fwdw = (P == 3);
     if (!fwdw) P = eng->rev_planes;
+    const bool quad = (fwdw && eng->q3) || (!fwdw && rev_quad && P == 3 && eng->q3 && eng->rev_q3);
+    eng->planes_q[dev] = quad;
     if (fwdw && eng->q3 && eng->fwd_fmt == 1) { want_planes_f16(host, dev, rows, K); return; }
     PlaneReq r{dev, (bw.size() + 63) & ~size_t(63)};
     bw.resize(r.off + (size_t)rows * K * P);
@@ -1318,7 +1335,7 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
           uint32_t u; std::memcpy(&u, &x, 4);
           const uint32_t rnd = u + 0x7FFFu + ((u >> 16) & 1u);
           const unsigned short hb = (unsigned short)(rnd >> 16);
-          if (fwdw && eng->q3)       // quad-row layout (umx_gemm_q.h), index in bf16 units; rows are multiples of 4 here
+          if (quad)                  // quad-row layout (umx_gemm_q.h), index in bf16 units; rows are multiples of 4 here
             bw[r.off + (((size_t)(rr / 4) * (K / 16) + k / 16) * 384 + (size_t)(rr % 4) * 96 + (size_t)q * 32 + (size_t)(k % 16) * 2) / 2] = hb;
           else
             bw[r.off + (size_t)rr * K * P + (size_t)(k / 32) * 32 * P + (size_t)q * 32 + (k % 32)] = hb;
@@ -1336,9 +1353,11 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
     WH(c1 + ".fc_m0.weight", 640, 768); WH(c1 + ".so2_m_conv.0.fc.weight", 512, 512); WH(c1 + ".so2_m_conv.1.fc.weight", 256, 256);
     WH(c2 + ".fc_m0.weight", 384, 384); WH(c2 + ".so2_m_conv.0.fc.weight", 512, 256); WH(c2 + ".so2_m_conv.1.fc.weight", 256, 128);
     WH(c1 + ".rad_func.fc3.weight", RAD, RH);
-    want_planes(hd + loff[i].c1m0T, D(loff[i].c1m0T), 768, 640, 2); want_planes(hd + loff[i].c1m1T, D(loff[i].c1m1T), 2 * 512, 256, 2);
-    want_planes(hd + loff[i].c1m2T, D(loff[i].c1m2T), 2 * 256, 128, 2); want_planes(hd + loff[i].c2m0T, D(loff[i].c2m0T), 384, 384, 2);
-    want_planes(hd + loff[i].c2m1T, D(loff[i].c2m1T), 2 * 256, 256, 2); want_planes(hd + loff[i].c2m2T, D(loff[i].c2m2T), 2 * 128, 128, 2);
+    // the conv^T weights follow their A operands (g_msg / g_hg): quad-row layout in the bf16x3 mode; fc3^T stays PL (g_rad comes from the
+    // node-centric k_modrot_bwd_pl, whose rows are written edge by edge)
+    want_planes(hd + loff[i].c1m0T, D(loff[i].c1m0T), 768, 640, 2, true); want_planes(hd + loff[i].c1m1T, D(loff[i].c1m1T), 2 * 512, 256, 2, true);
+    want_planes(hd + loff[i].c1m2T, D(loff[i].c1m2T), 2 * 256, 128, 2, true); want_planes(hd + loff[i].c2m0T, D(loff[i].c2m0T), 384, 384, 2, true);
+    want_planes(hd + loff[i].c2m1T, D(loff[i].c2m1T), 2 * 256, 256, 2, true); want_planes(hd + loff[i].c2m2T, D(loff[i].c2m2T), 2 * 128, 128, 2, true);
     want_planes(hd + roff[c1 + ".rad_func"].w3T, D(roff[c1 + ".rad_func"].w3T), RH, RAD, 2);
   }
   if (eng->deg_split) {   // the edge-degree radial MLP's fc3 (128 -> 384) and its transpose run on the split path too

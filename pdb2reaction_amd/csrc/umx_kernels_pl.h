@@ -377,6 +377,73 @@ __global__ __launch_bounds__(256) void k_rotate_back_bwd_pl(const float* __restr
   }
 }
 
+// The same for the quad-row (Q3, three bf16 planes) operand layout of umx_gemm_q.h -- the reverse pass of the bf16x3 mode (round 4): the
+// conv-2^T GEMMs then run on the 256 x 256-tile kernel like the forward ones.  A workgroup = the four edges of one row group (one wave
+// each, XCD-contiguous row groups); per m-primary row the four waves stage their 128 columns x 3 planes in LDS in the byte order of the
+// 8 consecutive 384-B blocks and the workgroup writes them with coalesced 16-B stores (see k_gather_rotate_mod_q3).
+__global__ __launch_bounds__(256) void k_rotate_back_bwd_q3(const float* __restrict__ gnode, const float* __restrict__ msg,
+                                                            const float* __restrict__ frame, const int* __restrict__ edst,
+                                                            unsigned short* __restrict__ gmsg, float* __restrict__ dedd,
+                                                            float* __restrict__ tau, long ne, float odd_sign) {
+  constexpr int P = 3, BLK = 384;
+  __shared__ __attribute__((aligned(16))) unsigned int stage[2][8][4][8 * P];    // [buffer][16-column block][row in group][q*8 + pair]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long nvb = (((ne + 3) / 4 + 7) / 8) * 8;
+  const long per = nvb >> 3;
+  for (long vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+  const long grp = (vb & 7) * per + (vb >> 3);
+  const long e0 = grp * 4;
+  if (e0 >= ne) continue;                                                        // block-uniform
+  __syncthreads();
+  const long e = e0 + wave;
+  const bool valid = e < ne;
+  const long ee = valid ? e : e0;
+  const int c0 = lane * 2;
+  const float* f = frame + ee * FRAME;
+  const long jd = edst[ee];
+  float gx[9], gy[9], lx[9], ly[9], mx[9], my[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const float2 t = *reinterpret_cast<const float2*>(gnode + jd * ROW + r * C + c0);
+    gx[r] = t.x; gy[r] = t.y;
+    const float2 m = *reinterpret_cast<const float2*>(msg + ee * ROW + r * C + c0);
+    mx[r] = m.x; my[r] = m.y;
+  }
+  rot_fwd(f, gx, lx); rot_fwd(f, gy, ly);
+  const float sc = f[34];
+  float s = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    s += lx[r] * mx[r] + ly[r] * my[r];
+    lx[r] *= sc; ly[r] *= sc;
+  }
+  torque_acc(lx, mx, -1.0f, tx, ty, tz);
+  torque_acc(ly, my, -1.0f, tx, ty, tz);
+  s = wave_sum(s); tx = wave_sum(tx); ty = wave_sum(ty); tz = wave_sum(tz);
+  if (lane == 0 && valid) {
+    dedd[e] += f[35] * s;
+    tau[e * 4 + 0] += tx; tau[e * 4 + 1] += ty; tau[e * 4 + 2] += tz;
+  }
+  const float sg = row_sign(ee, odd_sign);
+  unsigned char* gbase = reinterpret_cast<unsigned char*>(gmsg) + grp * (long)(ROW / 16) * BLK;
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const int buf = r & 1;
+    unsigned int w[P];
+    q_split2<0>(sg * lx[r], sg * ly[r], w);
+    unsigned int* d = &stage[buf][c0 >> 4][wave][(c0 & 15) >> 1];
+#pragma unroll
+    for (int q = 0; q < P; ++q) d[q * 8] = w[q];
+    __syncthreads();
+    // 8 blocks x 384 B = 192 chunks of 16 B
+    if (threadIdx.x < 192) {
+      const uint4 val = reinterpret_cast<const uint4*>(&stage[buf][0][0][0])[threadIdx.x];
+      st_stream(reinterpret_cast<uint4*>(gbase + (long)r * 8 * BLK) + threadIdx.x, val);
+    }
+  }
+  }
+}
+
 // backward of the edge gate: ghid (9x128 fp32), hg (forward, fp32) -> g_hg = [ggate | ghpre] as PL planes (1408 columns)
 template <int P>
 __global__ void k_gate_edge_bwd_pl(const float* __restrict__ ghid, const float* __restrict__ hg, unsigned short* __restrict__ ghg, long ne, float odd_sign) {
@@ -409,6 +476,74 @@ __global__ void k_gate_edge_bwd_pl(const float* __restrict__ ghid, const float* 
   }
   pl_store4<P>(o, c, make_float4(sg * (a1[0] * s1[0] * (1.0f - s1[0])), sg * (a1[1] * s1[1] * (1.0f - s1[1])), sg * (a1[2] * s1[2] * (1.0f - s1[2])), sg * (a1[3] * s1[3] * (1.0f - s1[3]))));
   pl_store4<P>(o, H + c, make_float4(sg * (a2[0] * s2[0] * (1.0f - s2[0])), sg * (a2[1] * s2[1] * (1.0f - s2[1])), sg * (a2[2] * s2[2] * (1.0f - s2[2])), sg * (a2[3] * s2[3] * (1.0f - s2[3]))));
+  }
+}
+
+// The same for the quad-row (Q3) layout (bf16x3 reverse pass): a workgroup = 8 edges = two row groups; per 128-column row (the nine
+// m-primary rows of g_hpre, then the two gate rows) the values of the 8 edges are staged in LDS in block order and written with coalesced
+// 16-B stores (see k_gate_edge_fwd_q3).  Column layout of g_hg as everywhere: [ggate l1 (128) | ggate l2 (128) | ghpre 9 x 128].
+__global__ __launch_bounds__(256) void k_gate_edge_bwd_q3(const float* __restrict__ ghid, const float* __restrict__ hg, unsigned short* __restrict__ ghg,
+                                                          long ne, float odd_sign) {
+  constexpr int P = 3, BLK = 384;
+  __shared__ __attribute__((aligned(16))) unsigned int stage[2][2][8][4][8 * P]; // [buffer][row group][16-column block][row][q*8 + pair]
+  const long nvb = (ne + 7) / 8;
+  for (long vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+  const long e0 = vb * 8;
+  __syncthreads();
+  const int le = threadIdx.x >> 5;
+  const int c = (threadIdx.x & 31) * 4;
+  const long e = (e0 + le < ne) ? e0 + le : e0;
+  const float* p = hg + e * HG;
+  const float4 g1 = *reinterpret_cast<const float4*>(p + c), g2 = *reinterpret_cast<const float4*>(p + H + c);
+  const float s1[4] = {sigmoid_f(g1.x), sigmoid_f(g1.y), sigmoid_f(g1.z), sigmoid_f(g1.w)};
+  const float s2[4] = {sigmoid_f(g2.x), sigmoid_f(g2.y), sigmoid_f(g2.z), sigmoid_f(g2.w)};
+  const float rs = row_sign(le, odd_sign);                                       // e0 is a multiple of 8
+  unsigned char* gbase = reinterpret_cast<unsigned char*>(ghg) + (e0 >> 2) * (long)(HG / 16) * BLK;
+  float4 gv4[9], hv4[9];                                                         // all loads up front (the barriers below fence loads)
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    gv4[r] = *reinterpret_cast<const float4*>(ghid + e * ROW + r * H + c);
+    hv4[r] = *reinterpret_cast<const float4*>(p + 2 * H + r * H + c);
+  }
+  float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+  auto emit = [&](int it, int colblk, const float (&x)[4]) {                      // colblk: first 16-column block of this 128-column row
+    const int buf = it & 1;
+    unsigned int* d = &stage[buf][le >> 2][c >> 4][le & 3][(c & 15) >> 1];
+    unsigned int wa[P], wb[P];
+    q_split2<0>(rs * x[0], rs * x[1], wa); q_split2<0>(rs * x[2], rs * x[3], wb);
+#pragma unroll
+    for (int q = 0; q < P; ++q) *reinterpret_cast<uint2*>(d + q * 8) = make_uint2(wa[q], wb[q]);
+    __syncthreads();
+    constexpr int CPG = 64 * P;                                                  // 16-B chunks per row group: 8 blocks x 24
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+      const int ch = threadIdx.x + 256 * k2;
+      const int g = ch / CPG, o = ch % CPG;
+      if (ch < 2 * CPG && e0 + 4 * g < ne) {
+        const uint4 val = reinterpret_cast<const uint4*>(&stage[buf][g][0][0][0])[o];
+        st_stream(reinterpret_cast<uint4*>(gbase + (long)g * (HG / 16) * BLK + (long)colblk * BLK) + o, val);
+      }
+    }
+  };
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const float gv[4] = {gv4[r].x, gv4[r].y, gv4[r].z, gv4[r].w}, hv[4] = {hv4[r].x, hv4[r].y, hv4[r].z, hv4[r].w};
+    float w[4];
+    const bool l1 = (r == 1 || r == 3 || r == 5);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (r == 0) w[k] = gv[k] * silu_grad_f(hv[k]);
+      else {
+        w[k] = gv[k] * (l1 ? s1[k] : s2[k]);
+        if (l1) a1[k] += gv[k] * hv[k]; else a2[k] += gv[k] * hv[k];
+      }
+    }
+    emit(r, (2 * H + r * H) / 16, w);
+  }
+  const float q1[4] = {a1[0] * s1[0] * (1.0f - s1[0]), a1[1] * s1[1] * (1.0f - s1[1]), a1[2] * s1[2] * (1.0f - s1[2]), a1[3] * s1[3] * (1.0f - s1[3])};
+  const float q2[4] = {a2[0] * s2[0] * (1.0f - s2[0]), a2[1] * s2[1] * (1.0f - s2[1]), a2[2] * s2[2] * (1.0f - s2[2]), a2[3] * s2[3] * (1.0f - s2[3])};
+  emit(9, 0, q1);
+  emit(10, H / 16, q2);
   }
 }
 

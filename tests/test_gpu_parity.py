@@ -105,6 +105,8 @@ def switch_case(oracle):
     {"UMX_MFMA16": "0"}, {"UMX_MFMA16": "2"}, {"UMX_WIDE": "0", "UMX_PRECISION": "split"},
     {"UMX_MFMA16": "0", "UMX_PRECISION": "split"}, {"UMX_MFMA16": "2", "UMX_PRECISION": "split"},
     {"UMX_RADIAL_TR": "1"}, {"UMX_RADIAL_FAST": "2"}, {"UMX_FUSE_MODROT": "0"}, {"UMX_FUSE_MODROT": "0", "UMX_PRECISION": "split"},
+    {"UMX_REV_Q3": "0"},                                         # bf16x3 reverse operands in the PL layout (256x128 tiles)
+    {"UMX_ALT_ROWS": "0"}, {"UMX_ALT_ROWS": "0", "UMX_PRECISION": "split"},     # without the sign-alternating operand rows
 ], ids=lambda e: ",".join(f"{k[4:]}={v}" for k, v in e.items()))
 def test_documented_switches_hold_the_tolerances(weights, switch_case, env, monkeypatch):
     """Every run-time switch of README.md selects other kernels or tilings; each combination must stay inside the north-star tolerances."""

@@ -5,7 +5,7 @@ two engine calls.  numpy's OpenBLAS starts one worker per core of the MACHINE (6
 them spin after every matmul; inside a container with a CPU quota (16 cores on a one-GPU box) those spinning workers burn the cgroup's
 quota and the kernel throttles the whole process for the rest of the 100 ms scheduling period -- including the thread that feeds the
 GPU.  Measured on a 500-atom, 10-image string: 97 ms per batched E+F call instead of 57 ms, with the GPU idle for the difference
-(tools/gpu_batch_latency2.py).  The arrays are far too small to profit from BLAS threads, so the drivers run their host math on
+(tools/archive/gpu_batch_latency2.py).  The arrays are far too small to profit from BLAS threads, so the drivers run their host math on
 ``UMX_HOST_THREADS`` (default 1) threads via threadpoolctl; the limit is lifted again when the driver returns.
 """
 from __future__ import annotations
@@ -49,7 +49,7 @@ _CAPPED = None
 def cap_pools_to_usable_cores() -> int:
     """Once per process: BLAS / OpenMP pools that are larger than the cores this process may use are cut down to that number, for good.
     A pool sized for the whole machine inside a CPU-quota container is the mis-configuration described in the module docstring; a
-    limit <= the quota measured 56 ms per call where 32 and 64 threads gave 95 (``tools/gpu_batch_latency2.py``).  Called when a
+    limit <= the quota measured 56 ms per call where 32 and 64 threads gave 95 (``tools/archive/gpu_batch_latency2.py``).  Called when a
     calculator creates its engine, so that callers this package does not control (an external optimiser stepping through
     ``get_forces``) are covered too.  ``UMX_HOST_THREADS=0`` disables it.  Returns the cap applied (0: nothing done)."""
     global _CAPPED

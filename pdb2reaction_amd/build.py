@@ -17,7 +17,7 @@ ABI_HEADER = os.path.normpath(os.path.join(HERE, "..", "include", "umx.h"))
 # v_pk_fma_f32).  On gfx950 with this toolchain (ROCm 7.2) a kernel made of them is TIMING-SENSITIVE: alone on the chip it is bitwise
 # reproducible, but while other kernels share its SIMDs -- a second stream, another process -- single waves come out 0.1-1 % off (round 3:
 # k_norm_bwd, reproduced stand-alone in csrc/norm_bwd_repro.hip: 27-788 of 40 000 launches beside four busy processes, 0 of 80 000 without
-# the packed instructions).  The flags are part of the source digest.
+# the packed instructions; NOTES.md section 5 item 14).  The flags are part of the source digest.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize"]
 
 
@@ -83,7 +83,7 @@ def device_disassembly(lib_path: str = OUT) -> str:
 
 def check_no_packed_fp32(lib_path: str = OUT) -> int:
     """Fail when the shipped device code contains a packed-fp32 VALU instruction (timing-dependent results on gfx950 while other
-    kernels share the SIMDs; profiles/r04_k_norm_bwd_isa_diff.txt): the SLP vectoriser is off, but the
+    kernels share the SIMDs, NOTES.md section 5 item 14; profiles/r04_k_norm_bwd_isa_diff.txt): the SLP vectoriser is off, but the
     loop vectoriser, explicit float2 arithmetic or a compiler update could bring them back.  Returns the number of kernels checked."""
     import re
 
@@ -92,7 +92,7 @@ def check_no_packed_fp32(lib_path: str = OUT) -> int:
     kernels = len(re.findall(r"^[0-9a-f]+ <[^>]+>:", text, flags=re.M))
     if hits:
         raise RuntimeError(f"{lib_path}: {len(hits)} packed-fp32 instructions (v_pk_mul/add/fma_f32) in the gfx950 code object -- "
-                           "build.FLAGS must keep them out (-fno-slp-vectorize); see DESIGN.md section 5 item 14")
+                           "build.FLAGS must keep them out (-fno-slp-vectorize); see NOTES.md section 5 item 14")
     if kernels == 0:
         raise RuntimeError(f"{lib_path}: no kernel found in the gfx950 code object (disassembly failed?)")
     return kernels

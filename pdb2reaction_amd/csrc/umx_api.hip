@@ -589,7 +589,7 @@ int so3_linear(umx_engine* eng, const float* A, const float* Wl, const float* bi
 // issues the segments in order.  With two lanes (UMX_STREAMS=2) it issues the plans of two chunks alternately and hands a
 // TOKEN from matrix segment to matrix segment across the lanes (events), so that at any time at most one lane occupies the
 // matrix pipe while the other lane's stream segments run beside it on the same CUs -- the two bounds (MFMA and HBM)
-// overlap instead of adding up.
+// overlap instead of adding up (NOTES.md section 5).
 struct Seg { bool matrix; std::function<int()> fn; float* sync_buf = nullptr; size_t sync_count = 0; };
 struct Plan {
   std::vector<Seg> segs;
@@ -1656,7 +1656,7 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
     size_t fr = 0, tot = 0;
     HIPCHK(eng, hipMemGetInfo(&fr, &tot));
     budget = (size_t)((fr + eng->arena_bytes) * 0.85);
-    // default cap (UMX_WS_GB, 0 = none): chunks beyond a few images buy no speed, and an engine that takes
+    // default cap (UMX_WS_GB, 0 = none): chunks beyond a few images buy no speed (NOTES.md section 4), and an engine that takes
     // 85 % of the HBM starves every other engine of the process (a second calculator, the FD-Hessian helper, ...)
     if (eng->ws_cap_default && budget > eng->ws_cap_default) {
       long emax = 0;
@@ -1798,7 +1798,7 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
   };
   if (lanes == 2) {          // chunks in pairs, one per lane, matrix segments alternating between the lanes (run_plans_alternating)
     // UMX_LANES_ONE_STREAM=1 (tests): both lanes' segments in the same alternating order on ONE stream -- the two-lane plan without any
-    // concurrency (what results must be bitwise equal to; with real concurrency see DESIGN.md section 5, item 14)
+    // concurrency (what results must be bitwise equal to; with real concurrency see NOTES.md section 5, item 14)
     hipStream_t sts[2] = {s, std::getenv("UMX_LANES_ONE_STREAM") ? s : eng->stream2};
     hipEvent_t tok[2] = {eng->ev_tok[0], eng->ev_tok[1]};
     for (size_t ci = 0; ci < chunks.size() && st == UMX_OK; ci += 2) {

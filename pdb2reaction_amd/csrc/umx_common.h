@@ -41,7 +41,7 @@ __device__ __forceinline__ float rsqrt_f(float x) { return 1.0f / sqrtf(x); }
 // The factor cannot be folded into y -- y sits on the float grid and y (1 + c) rounds straight back to it (the same trap) -- so it
 // travels with y and is applied where the row is scaled, inside ONE fma: v y (1 + c) = fma(v, y, (v y) c), rounded once.  Two
 // extra instructions per element.  (A double sqrt + divide per row did the same but cost the fused radial kernels 2.7 ms per c3
-// iteration: every lane of the wave computes it.)  func_bias.hip: LayerNorm + SiLU gain -1.22e-8 -> see DESIGN.md section 5.
+// iteration: every lane of the wave computes it.)  func_bias.hip: LayerNorm + SiLU gain -1.22e-8 -> see NOTES.md section 5.
 struct Rstd { float y, c; };
 __device__ __forceinline__ Rstd rstd_eps(float x, float eps) {
   const float s = __fadd_rn(x, eps);                       // (explicitly rounded ops: must not be re-associated into dl = 0)
@@ -65,7 +65,7 @@ __device__ __forceinline__ float silu_grad_f(float x) {
 // Grid-stride forms ("virtual blocks"): the kernel body is the loop body, so ANY grid size does the same work in the same per-item
 // arithmetic order.  Launched with the full grid it is one iteration per wave (as UMX_WAVE_ITEM); launched with a capped grid
 // (engine "throttled" mode: a few resident workgroups per CU) the kernel leaves room on every CU for the other lane's GEMM
-// workgroups instead of flooding the chip (two-lane execution).   Usage:  UMX_WAVE_LOOP(idx, count) { body }
+// workgroups instead of flooding the chip (NOTES.md section 5, two-lane execution).   Usage:  UMX_WAVE_LOOP(idx, count) { body }
 #define UMX_WAVE_LOOP(idx, count)                                                     \
   const int lane = threadIdx.x & 63;                                                  \
   for (long _it = (long)blockIdx.x * 4 + (threadIdx.x >> 6); _it < (count); _it += (long)gridDim.x * 4) \

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void umx_gemm_kernel(const GemmP p) {
 // double and rounded to float32 ONCE (after bias and residual).  Node-level GEMMs are < 1 % of the work, so this costs nothing
 // measurable, while it removes their share of the one-signed energy drift that grows with the number of atoms (a float32 dot
 // product of 128 terms errs by ~3e-8 relative; rounded once the error is 3e-8 of the RESULT only and unbiased).  Used when the
-// engine runs large systems ("energy error vs N").  64 x 64 tile, 16 x 16 threads, 4 x 4 outputs per thread.
+// engine runs large systems (NOTES.md section 5, "energy error vs N").  64 x 64 tile, 16 x 16 threads, 4 x 4 outputs per thread.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 template <int AMODE>

@@ -13,7 +13,7 @@
 // global_load_lds wave-instruction then fetches whole 128-B lines.  (With separate planes and a 16-wide
 // k-step every line was requested four separate times and the fill, not the MFMA, set the pace.)
 //
-// Structure (cdna_hip_programming.md section 5; measured steps in DESIGN.md section 5):
+// Structure (cdna_hip_programming.md section 5; measured steps in NOTES.md section 5):
 //  * 256 x (64*WNT) block tile, BK = 32, 4 waves (2x2), ONE block per CU, each wave owns a
 //    128 x (32*WNT) C tile = 4 x WNT v_mfma_f32_32x32x16_bf16 tiles (up to 256 accumulator registers;
 //    the wave has the whole 512-entry register file).

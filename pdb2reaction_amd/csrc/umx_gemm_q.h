@@ -12,7 +12,7 @@
 // (rows padded to a multiple of 4).  A 16-column k-tile of a 256-row operand tile is 64 contiguous-by-block pieces = 8 P KB, so
 // BOTH operands of a 256 x 256 tile times two ring stages take 80 KB (fp16 form) / 96 KB (Q3) -- with the 32-column plane-interleaved
 // rows of the PL layout (umx_gemm_pl.h) one 3-plane stage of that tile is already 98 KB and the forward GEMMs were stuck at 256 x 128.
-// A wider tile needs a third less L2->LDS fill per FLOP, which co-limits these kernels: measured -8...10 %
+// A wider tile needs a third less L2->LDS fill per FLOP, which co-limits these kernels (NOTES.md section 5): measured -8...10 %
 // against the PL kernels.  Every DMA instruction still fetches whole lines (8 P consecutive lanes cover one block).
 // Fragment reads: lane = row, 16 B (8 k-values of one plane) per ds_read_b128, which is served in the lane groups
 // {0-3,12-15,20-27} / {4-11,16-19,28-31} (+32).  In the plain P = 3 image the bank base of a row group is 32*(group & 1) dwords,
@@ -54,7 +54,7 @@ __device__ __forceinline__ void q3_issue(const unsigned char* A, const unsigned 
 // which plane products A_qa . B_qb a kernel accumulates:
 //   bf16, 3 x 3 planes, 6 products: qa + qb < 3 (everything down to 2^-16 of the leading term; dropped terms are 2^-24)
 //   fp16, 2 x 3 planes, 4 products: hh, hl, lh and A_hi . B_lo2 -- the weights (B, 33 bits in three half planes) are EXACT, so their
-//         rounding cannot bias every atom the same way (two-plane weights shift the c3 energy by +2.5e-8 eV/atom);
+//         rounding cannot bias every atom the same way (two-plane weights shift the c3 energy by +2.5e-8 eV/atom, NOTES.md section 5);
 //         the activations keep 22 bits with unbiased per-element rounding; dropped: A_lo . B_mid (2^-22, random sign) and below
 //   fp16, 2 x 2 planes, 3 or 4 products: hh, hl, lh (+ ll)
 __host__ __device__ constexpr bool q_use_product(int PA, int PB, int NPROD, int qa, int qb) {

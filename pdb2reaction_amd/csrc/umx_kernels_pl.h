@@ -23,7 +23,7 @@ __device__ __forceinline__ float row_sign(long e, float odd_sign) { return (e & 
 template <int P> __device__ __forceinline__ long pl_index(int k) { return (long)(k >> 5) * (32 * P) + (k & 31); }
 
 // split 2 adjacent values into P planes and store them (k even): 4-byte store per plane
-// dev switch (-DUMX_NT=1): non-temporal stores for the write-once operand planes (A/B measurement in DESIGN.md section 9)
+// dev switch (-DUMX_NT=1): non-temporal stores for the write-once operand planes (A/B measurement in NOTES.md section 9)
 #ifndef UMX_NT
 #define UMX_NT 0
 #endif

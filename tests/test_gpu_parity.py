@@ -635,7 +635,7 @@ def test_two_lane_execution_is_bitwise_identical(weights, monkeypatch):
     Round 3: this test failed about once in ten suite runs (forces of one image 1e-6...1e-4 eV/A off).  Cause: the packed-fp32
     instructions hipcc's SLP vectoriser emits (v_pk_mul/add/fma_f32) are timing-sensitive on gfx950 -- beside other kernels on the same
     SIMDs single waves come out 0.1-1 % off (csrc/norm_bwd_repro.hip); the library is built with -fno-slp-vectorize since
-    (build.py).  test_library_has_no_packed_fp32 keeps it that way."""
+    (build.py, NOTES.md section 5 item 14).  test_library_has_no_packed_fp32 keeps it that way."""
     from pdb2reaction_amd.engine import Engine
 
     z, imgs, _ = synth.make_images(260, 5, seed=21)

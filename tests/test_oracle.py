@@ -163,7 +163,7 @@ def test_oracle_c1_golden_first_image(oracle):
 
 
 def test_float32_torch_arithmetic_deviates_per_atom(weights, oracle):
-    """Context for the energy tolerance: the same restatement run in torch float32 -- the reference's dtype and
+    """Context for the energy tolerance (NOTES.md section 3): the same restatement run in torch float32 -- the reference's dtype and
     op style -- deviates from float64 arithmetic by ~1e-7 eV PER ATOM (one-signed: shared quantities are rounded the same way for every
     atom), i.e. 1e-4 eV is already exceeded near 1000 atoms by float32 arithmetic itself.  The engine is held to <= 2.5e-8 eV per atom."""
     from oracle.escn_md_oracle import Oracle

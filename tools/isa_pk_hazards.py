@@ -1,4 +1,4 @@
-"""ISA evidence for DESIGN.md section 5 item 14: compile csrc/norm_bwd_repro.hip with and without hipcc's SLP
+"""ISA evidence for NOTES.md section 5 item 14: compile csrc/norm_bwd_repro.hip with and without hipcc's SLP
 vectoriser, cut k_norm_bwd out of both listings and tabulate, for every packed-fp32 instruction (v_pk_mul/add/fma_f32),
   * who produced each of its sources and how many instructions earlier (VMEM load behind s_waitcnt, DPP op, v_readlane -> SGPR pair, VALU),
   * who consumes its result first and how many instructions later (DPP op, v_readlane, store, VALU, another v_pk),

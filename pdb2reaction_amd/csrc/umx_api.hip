@@ -1746,8 +1746,10 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
   if (eng->hint_images > 0 && !eng->gp && lanes == 1) {
     long emax = 0;
     for (long k = 0; k < K; ++k) emax = std::max(emax, (long)img_edges[k]);
-    hint_nodes = (long)eng->hint_images * N;
-    hint_edges = (long)eng->hint_images * (emax + emax / 20 + 64);
+    long hint_img = eng->hint_images;                                       // (a chunk never holds more than UMX_MAX_CHUNK_IMAGES images)
+    if (const char* ev = std::getenv("UMX_MAX_CHUNK_IMAGES")) { const long v = std::atol(ev); if (v > 0) hint_img = std::min(hint_img, v); }
+    hint_nodes = hint_img * N;
+    hint_edges = hint_img * (emax + emax / 20 + 64);
     if ((hint_nodes <= eng->cap_nodes && hint_edges <= eng->cap_edges) || carve(nullptr, hint_nodes, hint_edges, nullptr, ws_mode(eng)) > budget) hint_nodes = hint_edges = 0;
   }
   // (the hint alone triggers ONE allocation; after that it only enlarges a growth the batches themselves ask for -- otherwise every batch

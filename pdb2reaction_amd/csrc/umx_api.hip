@@ -608,6 +608,7 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
   const dim3 B256(256);
   const bool pl = eng->pl;
   const bool gp = eng->gp;                                       // graph-parallel: partial sums over this rank's edges + exchange points
+  const bool fused_rev = eng->fuse_modrot && (eng->pl || !eng->dbg_on);     // k_modrot_bwd_pl produces g_xn itself (fp32 mode: unless debug captures are on)
   const long g_lo = gp ? eng->gp_lo : 0, g_hi = gp ? eng->gp_hi : nn;
   // side-stream issue of the fused radial kernels (see umx_engine::side); the plan is the same, only WHERE two of its kernels run changes
   const bool side = eng->side && eng->n_lanes == 1 && !eng->dbg_on && !gp && pl && ne > 0 && eng->fused_radial && eng->q3;
@@ -882,9 +883,18 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
         CHK(gemm_cplx(eng, w.ghg, HG, 640, 896, nullptr, 0, 0, L.c1m1T, 256, 512, w.gy1, XROT, 768, 1280, ne, 512, 256, -1.0f));
         CHK(gemm_cplx(eng, w.ghg, HG, 1152, 1280, nullptr, 0, 0, L.c1m2T, 128, 256, w.gy1, XROT, 1792, 2048, ne, 256, 128, -1.0f));
         DBG("g_hg" + t, w.ghg, ne * HG);
-        hipLaunchKernelGGL(k_gather_rotate, dim3(nblk(ne, 4)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.xrot, ne);
-        hipLaunchKernelGGL(k_modulate_bwd, dim3(nblk(ne, 4)), B256, 0, s, w.gy1, w.xrot, w.rad[i], w.grad, w.tau, ne);
-        DBG("g_xrot" + t, w.gy1, ne * XROT); DBG("g_rad" + t, w.grad, ne * RAD);
+        if (eng->fuse_modrot && !eng->dbg_on) {
+          // round 4: the fp32 mode takes the node-centric fused kernel of the split path too (P = 0: g_rad as float32 rows) instead of
+          // k_gather_rotate + k_modulate_bwd + k_gather_rotate_bwd -- the rotated message and g_xrot never touch HBM (-27 KB per edge and
+          // layer).  With debug captures on the unfused kernels run: they expose xrot / g_xrot to the stage-by-stage test.
+          hipLaunchKernelGGL(k_modrot_bwd_pl<0>, dim3((unsigned)nn), B256, 0, s, w.gy1, w.xn[i], w.frame, w.rad[i], w.row_ptr, w.out_ptr, w.out_edge,
+                             reinterpret_cast<unsigned short*>(w.grad), w.tau, w.tau2, w.G1, nn, 1.0f);
+          HIPCHK(eng, hipGetLastError());
+        } else {
+          hipLaunchKernelGGL(k_gather_rotate, dim3(nblk(ne, 4)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.xrot, ne);
+          hipLaunchKernelGGL(k_modulate_bwd, dim3(nblk(ne, 4)), B256, 0, s, w.gy1, w.xrot, w.rad[i], w.grad, w.tau, ne);
+          DBG("g_xrot" + t, w.gy1, ne * XROT); DBG("g_rad" + t, w.grad, ne * RAD);
+        }
         return radial_bwd(eng, w, L.rad, i, ne, w.grad);
       });
     }
@@ -892,7 +902,7 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       // g_xn: every rank holds the contributions of its own edges only.  A rank WITHOUT edges (fewer atoms than ranks, or only isolated
       // targets) has run no edge kernel: G1 still holds g_xn2 of the atom-wise backward and must not enter the sum
       if (ne == 0) P.stream([=, &w]() -> int { HIPCHK(eng, hipMemsetAsync(w.G1, 0, (size_t)nn * ROW * sizeof(float), eng->stream)); return UMX_OK; });
-      else if (!(pl && eng->fuse_modrot))      // fp32 mode / unfused reverse: the partial g_xn of this rank's edges has to exist BEFORE the exchange
+      else if (!fused_rev)                     // unfused reverse: the partial g_xn of this rank's edges has to exist BEFORE the exchange
         P.stream([=, &w]() -> int {
           hipLaunchKernelGGL(k_gather_rotate_bwd, dim3(nblk(nn, 4)), B256, 0, eng->stream, w.gy1, w.frame, w.row_ptr, w.out_ptr, w.out_edge, w.G1, nn);
           HIPCHK(eng, hipGetLastError());
@@ -903,7 +913,7 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
     P.stream([=, &w]() -> int {
       hipStream_t s = eng->stream;
       const std::string t = "." + std::to_string(i);
-      if (!(ne > 0 && eng->pl && eng->fuse_modrot) && !gp)
+      if (!(ne > 0 && fused_rev) && !gp)
         hipLaunchKernelGGL(k_gather_rotate_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.gy1, w.frame, w.row_ptr, w.out_ptr, w.out_edge, w.G1, nn);   // G1 = g_xn
       hipLaunchKernelGGL(k_norm_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.G1, xin, Lp->n1w, w.G2, w.G0, nn);                      // G0 = g_xin
       HIPCHK(eng, hipGetLastError());
@@ -924,7 +934,7 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
                               DEG_RESCALE);
       if (side) HIPCHK(eng, hipStreamWaitEvent(s, eng->ev_stail, 0));        // join: layer 1's tail, the last one issued on the side stream (e128a, dedd_rad)
       CHK(radial_bwd(eng, w, eng->rdeg, NL, ne, w.gmsg, dpl ? w.gmsgpl : nullptr));
-      if (eng->pl && eng->fuse_modrot) hipLaunchKernelGGL(k_add4, dim3(nblk(ne, 256)), B256, 0, s, w.tau, w.tau2, ne);
+      if (fused_rev) hipLaunchKernelGGL(k_add4, dim3(nblk(ne, 256)), B256, 0, s, w.tau, w.tau2, ne);
       hipLaunchKernelGGL(k_force_edge, dim3(nblk(ne, 256)), B256, 0, s, w.dedd, w.dedd_rad, w.tau, w.frame, w.evec, w.gvec, ne);
     }
     hipLaunchKernelGGL(k_force_node, dim3(nblk(nn, 4)), B256, 0, s, w.gvec, w.row_ptr, w.out_ptr, w.out_edge, (float)eng->rmsd, d_forces, nn);

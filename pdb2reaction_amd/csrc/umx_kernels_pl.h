@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256) void k_modulate_bwd_pl(float* __restrict__ gy1
 // walks its incoming edges (n is the target: columns C..2C of the 256-wide [src | dst] rows) and its outgoing edges (n is the
 // source: columns 0..C).  In both walks the un-rotated feature is the node's OWN xn[n], so the rotated message is re-derived
 // in registers, and
-//   g_rad[e][k]  = sum_{rows r of block k} gy1[e][r] * xrot[r]        -> PL planes (A operand of the w3^T GEMM)
+//   g_rad[e][k]  = sum_{rows r of block k} gy1[e][r] * xrot[r]        -> PL planes (A operand of the w3^T GEMM; P = 0: float32 rows, fp32 mode)
 //   g_xrot[e][r] = gy1[e][r] * rad[e][k(r)]                            (never leaves the registers: -18 KB/edge of HBM traffic)
 //   tau[e]      += <g_xrot, L xrot>                                    (target half -> tau, source half -> tau2: two writers)
 //   g_xn[n]      = sum_e W_e^T g_xrot[e][half]                         (deterministic segmented sum, fixed edge order)
@@ -659,10 +659,16 @@ __global__ __launch_bounds__(256) void k_modrot_bwd_pl(const float* __restrict__
       gax[k] += gv[r].x * px[r]; gay[k] += gv[r].y * py[r];
       hx[r] = gv[r].x * rv[k].x; hy[r] = gv[r].y * rv[k].y;
     }
-    unsigned short* gr = grad + e * (long)(RAD * P);
-    const float sg = row_sign(e, odd_sign);
+    if constexpr (P == 0) {      // fp32 precision mode: g_rad as plain float32 rows (the A operand of the fp32-MFMA fc3^T GEMM), no row signs
+      float* gr = reinterpret_cast<float*>(grad) + e * (long)RAD;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) pl_store2<P>(gr, k * 2 * C + half + c0, sg * gax[k], sg * gay[k]);
+      for (int k = 0; k < 6; ++k) *reinterpret_cast<float2*>(gr + k * 2 * C + half + c0) = make_float2(gax[k], gay[k]);
+    } else {
+      unsigned short* gr = grad + e * (long)(RAD * P);
+      const float sg = row_sign(e, odd_sign);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pl_store2<(P ? P : 2)>(gr, k * 2 * C + half + c0, sg * gax[k], sg * gay[k]);
+    }
     float tx = 0.f, ty = 0.f, tz = 0.f;
     torque_acc(hx, px, 1.0f, tx, ty, tz); torque_acc(hy, py, 1.0f, tx, ty, tz);
     tx = wave_sum(tx); ty = wave_sum(ty); tz = wave_sum(tz);

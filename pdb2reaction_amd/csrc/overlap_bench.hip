@@ -35,7 +35,7 @@ static double now_ms() { return std::chrono::duration<double, std::milli>(std::c
 
 // "pmc" mode: one launch of every large split-bf16 GEMM of a c3 layer at the real shapes (8-image chunk = 1.14 M edges), for
 // rocprofv3 --pmc passes (SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES, LDS and wait counters); operands are random finite planes (bit patterns 0x3c00-0x3fff with random sign: 1-2 as fp16, 0.0078-0.031 as bf16).
-static int pmc_mode(int reps) {
+static int pmc_mode(int reps, bool x3 = false) {
   const long M = 1139068;
   const long M4 = (M + 3) / 4 * 4;
   unsigned char *y1, *w; float* C;
@@ -56,6 +56,28 @@ static int pmc_mode(int reps) {
     const long nM = (M + bmr - 1) / bmr, nN = (N + bnc - 1) / bnc;
     return dim3((unsigned)(((nM + 7) / 8) * 8 * nN));
   };
+  if (x3) {
+    // the DEFAULT mode since round 4 (bf16x3): three bf16 planes, 6 products in both passes; forward and conv^T operands in the quad-row layout, fc3^T PL
+    for (int r = 0; r < reps; ++r) {
+      hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0>), grid(0, 0, 640), dim3(512), 0, 0, mk(3, 2304, 0, 0, 0, 1408, 0, 0, 640, 768));
+      hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1>), grid(1, 1, 256), dim3(512), 0, 0, mk(3, 2304, 768, 1280, 256, 1408, 640, 896, 256, 512));
+      hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1>), grid(1, 1, 128), dim3(512), 0, 0, mk(3, 2304, 1792, 2048, 128, 1408, 1152, 1280, 128, 256));
+      hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0>), grid(0, 0, 384), dim3(512), 0, 0, mk(3, 1152, 0, 0, 0, 1152, 0, 0, 384, 384));
+      hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1>), grid(1, 1, 256), dim3(512), 0, 0, mk(3, 1152, 384, 640, 256, 1152, 384, 640, 256, 256));
+      hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1>), grid(1, 1, 128), dim3(512), 0, 0, mk(3, 1152, 896, 1024, 128, 1152, 896, 1024, 128, 128));
+      hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1>), grid(0, 1, 1536), dim3(512), 0, 0, mk(3, 128, 0, 0, 0, 1536, 0, 0, 1536, 128));
+      hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0>), grid(0, 0, 384), dim3(512), 0, 0, mk(3, 1152, 0, 0, 0, 1152, 0, 0, 384, 384));
+      hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1>), grid(1, 1, 256), dim3(512), 0, 0, mk(3, 1152, 384, 640, 256, 1152, 384, 640, 256, 256));
+      hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1>), grid(1, 1, 128), dim3(512), 0, 0, mk(3, 1152, 896, 1024, 128, 1152, 896, 1024, 128, 128));
+      hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1>), grid(0, 1, 768), dim3(512), 0, 0, mk(3, 1408, 0, 0, 0, 2304, 0, 0, 768, 640));
+      hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1>), grid(1, 1, 512), dim3(512), 0, 0, mk(3, 1408, 640, 896, 512, 2304, 768, 1280, 512, 256));
+      hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1>), grid(1, 1, 256), dim3(512), 0, 0, mk(3, 1408, 1152, 1280, 256, 2304, 1792, 2048, 256, 128));
+      hipLaunchKernelGGL((umx_gemm_pl16_kernel<0, 3, 2, 4, 2, 2, 2>), grid(0, 0, 128), dim3(512), 0, 0, mk(3, 1536, 0, 0, 0, 128, 0, 0, 128, 1536));
+    }
+    CK(hipDeviceSynchronize());
+    printf("pmc3 mode: %d x 14 GEMM launches done\n", reps);
+    return 0;
+  }
   for (int r = 0; r < reps; ++r) {
     // forward (quad-row layout, fp16: 2 activation planes x 3 weight planes, 4 products): conv-1 m0 / m1 / m2, conv-2 m0 / m1 / m2, radial fc3
     hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0, 2, 2, 1, 4, 3>), grid(0, 0, 640), dim3(512), 0, 0, mk(2, 2304, 0, 0, 0, 1408, 0, 0, 640, 768));
@@ -144,6 +166,7 @@ static int verify_mode(long M, int iters) {
 
 int main(int argc, char** argv) {
   if (argc > 1 && !strcmp(argv[1], "pmc")) return pmc_mode(argc > 2 ? atoi(argv[2]) : 2);
+  if (argc > 1 && !strcmp(argv[1], "pmc3")) return pmc_mode(argc > 2 ? atoi(argv[2]) : 2, true);
   if (argc > 1 && !strcmp(argv[1], "verify")) return verify_mode(argc > 2 ? atol(argv[2]) : 100000, argc > 3 ? atoi(argv[3]) : 40);
   const long M = argc > 1 ? atol(argv[1]) : 569632; const int N = argc > 2 ? atoi(argv[2]) : 512, K = argc > 3 ? atoi(argv[3]) : 512;
   const double copy_gb = argc > 4 ? atof(argv[4]) : 8.0;

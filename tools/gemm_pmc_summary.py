@@ -36,6 +36,8 @@ def load(d):
     return out
 
 
+if len(sys.argv) > 4 and sys.argv[4] == "bf16x3":      # the default mode since round 4: three bf16 planes, 6 products in both passes
+    SHAPES = [(n, c, nn, kk, 3) for (n, c, nn, kk, _) in SHAPES]
 p1, p2 = load(sys.argv[1]), load(sys.argv[2])
 rows = []
 for (_, a), (_, b), (name, cplx, n, k, p) in zip(p1.items(), p2.items(), SHAPES):
@@ -52,8 +54,11 @@ for (_, a), (_, b), (name, cplx, n, k, p) in zip(p1.items(), p2.items(), SHAPES)
         "wait_inst_lds_frac": a["SQ_WAIT_INST_LDS"] / wc,
         "lds_idx_active_per_cu_cycle": b["SQ_LDS_IDX_ACTIVE"] / (256.0 * cyc), "lds_bank_conflict_frac": b["SQ_LDS_BANK_CONFLICT"] / max(b["SQ_LDS_IDX_ACTIVE"], 1.0),
     })
-out = {"command": "rocprofv3 --pmc <pass counters> -- build/overlap_bench pmc 1   (two passes; csrc/overlap_bench.hip)",
-       "workload": "every large split-bf16 GEMM of one c3 layer, forward (quad-row layout, fp16: 2 activation x 3 weight planes, 4 products) and reverse (PL layout, bf16 2 x 2 planes, 3 products), M = 1 139 068 edges (8-image chunk), random finite planes",
+x3 = len(sys.argv) > 4 and sys.argv[4] == "bf16x3"
+out = {"command": f"rocprofv3 --pmc <pass counters> -- build/overlap_bench {'pmc3' if x3 else 'pmc'} 1   (two passes; csrc/overlap_bench.hip)",
+       "workload": ("every large GEMM of one c3 layer in the bf16x3 mode: 3 x 3 bf16 planes, 6 products, forward and conv^T reverse on the quad-row layout, fc3^T PL" if x3 else
+                    "every large split-bf16 GEMM of one c3 layer, forward (quad-row layout, fp16: 2 activation x 3 weight planes, 4 products) and reverse (PL layout, bf16 2 x 2 planes, 3 products)")
+                   + ", M = 1 139 068 edges (8-image chunk), random finite planes",
        "csrc_sha256": source_digest(), "gemms": rows}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(f"{'gemm':14s} {'us':>7s} {'exec TF/s':>9s} {'util':>5s} {'GHz':>5s} {'wait':>5s} {'w_inst':>6s} {'w_lds':>5s} {'lds/cyc':>7s} {'conf':>5s}")

@@ -1,7 +1,7 @@
 """Summarise two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs of the same bench command) into
 profiles/rNN_pmc_hbm_traffic.json: HBM bytes per kernel launch and per iteration.
 
-    python tools/pmc_summary.py <fetch_dir> <write_dir> <iterations_in_each_run> <out.json>
+    python tools/pmc_summary.py <fetch_dir> <write_dir> <iterations_in_each_run> <out.json> [mode label]
 
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half of wide coalesced reads, WRITE_SIZE is
 exact; both are in KiB:  hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
@@ -49,7 +49,7 @@ kernels.sort(key=lambda k: -k["hbm_bytes_per_launch"] * k["launches_per_iteratio
 out = {
     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline (two separate passes)",
     "correction": "gfx950: FETCH_SIZE reports half of wide coalesced reads -> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
-    "workload": "c3: 2000 atoms x 16 images, 1 GPU, default precision mode (auto -> fp16 forward planes at this size)",
+    "workload": "c3: 2000 atoms x 16 images, 1 GPU, precision mode " + (sys.argv[5] if len(sys.argv) > 5 else "auto (= bf16x3)"),
     "csrc_sha256": source_digest(),
     "hbm_bytes_per_iteration": total / iters,
     "dominant_family": {"kernel": "umx_gemm_q_kernel<*> + umx_gemm_pl16_kernel<*> + umx_gemm_pl_kernel<*>", "launches_per_iteration": fam_n / iters,

@@ -362,6 +362,24 @@ class GrowingStringDriver:
         self.t_eval = 0.0
         self.redo_steps = 0                                  # how often the optimistic step had to be recomputed
 
+    @classmethod
+    def from_calculator(cls, atoms: Sequence[str], reactant: np.ndarray, product: np.ndarray, calc: Any, *, group=None, **kw) -> "GrowingStringDriver":
+        """The driver for a ``pdb2reaction_amd.uma_pysis`` calculator, DEVICE RESIDENT when the calculator runs on the HIP engine: the string
+        lives on the engine's GPU and is evaluated through ``parallel.EngineStringEvaluator`` (device-pointer entry, frozen rows zeroed,
+        images sharded over the ranks of `group` when torch.distributed is initialised) -- per image exactly what ``calc.get_forces``
+        returns.  Any other calculator (a stand-in, a core without an engine, the graph-parallel mode) gets the numpy evaluator."""
+        core = calc._ensure_core(atoms) if hasattr(calc, "_ensure_core") else None
+        engine = getattr(core, "engine", None)
+        if engine is None or getattr(core, "_gp", None) is not None or not hasattr(engine, "energy_forces_dev"):
+            return cls(atoms, reactant, product, calc, **kw)
+        from .parallel import EngineStringEvaluator
+
+        max_images = int({**GS_KW, **(kw.get("gs_kw") or {})}["max_nodes"]) + 2
+        ev = EngineStringEvaluator(engine, len(list(atoms)), core.device, frozen=getattr(calc, "freeze_atoms", ()), group=group, max_images=max_images)
+        drv = cls(atoms, reactant, product, calc=None, evaluate_device=ev, device=core.device, **kw)
+        drv.calc = calc
+        return drv
+
     # ---- helpers -------------------------------------------------------------------------------------
     @property
     def coords(self) -> np.ndarray:

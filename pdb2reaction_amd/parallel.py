@@ -41,8 +41,11 @@ class ShardedImageEvaluator:
     """
 
     def __init__(self, evaluate_local: Callable, n_images: int, n_atoms: int, device: torch.device,
-                 group: Optional["dist.ProcessGroup"] = None, engine=None, check: str = "sync"):
-        """engine: the ``Engine`` behind ``evaluate_local`` when that goes through the asynchronous device-pointer entry
+                 group: Optional["dist.ProcessGroup"] = None, engine=None, check: str = "sync", force_collective: bool = False):
+        """force_collective: issue the all-gather even in a one-rank group (it is the identity there) -- exercises the RCCL call on
+        the evaluator's own buffers where only one GPU is available (tests).
+
+        engine: the ``Engine`` behind ``evaluate_local`` when that goes through the asynchronous device-pointer entry
         (``umx_energy_forces_dev`` cannot refuse a non-finite energy itself).  With it, the gathered energies are checked:
         they are the same on every rank, so every rank takes the same decision without a further collective.
 
@@ -59,7 +62,8 @@ class ShardedImageEvaluator:
         self.engine = engine
         self.check = check
         self.n_images, self.n_atoms, self.device, self.group = n_images, n_atoms, device, group
-        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        initialised = dist.is_available() and dist.is_initialized()
+        self.distributed = initialised and (dist.get_world_size(group) > 1 or bool(force_collective))
         self.world = dist.get_world_size(group) if self.distributed else 1
         self.rank = dist.get_rank(group) if self.distributed else 0
         self.lo, self.hi = shard_bounds(n_images, self.world, self.rank)
@@ -242,11 +246,12 @@ class EngineStringEvaluator:
     size, since a growing string changes k)."""
 
     def __init__(self, engine, n_atoms: int, device: torch.device, frozen: Sequence[int] = (), group: Optional["dist.ProcessGroup"] = None,
-                 check: str = "sync", max_images: int = 0):
+                 check: str = "sync", max_images: int = 0, force_collective: bool = False):
         from ._calculator_base import BOHR2ANG
         from .hessian import EV_PER_ANG_TO_AU, EV_TO_HARTREE
 
         self.engine, self.n_atoms, self.device, self.group, self.check = engine, int(n_atoms), device, group, check
+        self.force_collective = bool(force_collective)
         self._b2a, self._e2h, self._f2au = float(BOHR2ANG), float(EV_TO_HARTREE), float(EV_PER_ANG_TO_AU)
         self._frozen = torch.as_tensor(sorted(set(int(i) for i in frozen)), dtype=torch.long, device=device)
         self._cap = 0
@@ -280,7 +285,8 @@ class EngineStringEvaluator:
         k = x_bohr.shape[0]
         ev = self._ev.get(k)
         if ev is None:
-            ev = self._ev[k] = ShardedImageEvaluator(self._local, k, self.n_atoms, self.device, group=self.group, engine=self.engine, check=self.check)
+            ev = self._ev[k] = ShardedImageEvaluator(self._local, k, self.n_atoms, self.device, group=self.group, engine=self.engine, check=self.check,
+                                                        force_collective=self.force_collective)
         e, f = ev(x_bohr.reshape(k, self.n_atoms, 3))
         return e, f.reshape(k, -1)
 

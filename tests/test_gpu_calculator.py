@@ -182,6 +182,39 @@ def test_gsm_driver_on_the_engine(tmp_path, setup):
     assert xyz.shape == (6, 14, 3)
 
 
+def test_device_resident_gsm_driver_equals_the_host_path(setup):
+    """Round 4: ``GrowingStringDriver.from_calculator`` keeps the string on the engine's GPU and evaluates it through
+    the device-pointer entry (``parallel.EngineStringEvaluator``) -- per image the same numbers as ``get_forces_batch`` (same float32
+    positions into the engine, same frozen rows, same unit factors), so the run follows the host-path run: same growth, same cycle
+    count, coordinates to round-off (the float64 reductions of the string update run in another order on the GPU)."""
+    import torch
+    from pdb2reaction_amd.gsm import GrowingStringDriver
+    from pdb2reaction_amd.parallel import EngineStringEvaluator
+
+    z, elem, imgs = setup
+    r, p = (imgs[0] * U.ANG2BOHR).reshape(-1), (imgs[3] * U.ANG2BOHR).reshape(-1)
+    kw = dict(gs_kw={"max_nodes": 4, "perp_thresh": 1e3, "climb": False}, stopt_kw={"max_cycles": 12, "max_step": 0.05})
+    calc = U.uma_pysis(model="synthetic", freeze_atoms=[0, 7])
+    host = GrowingStringDriver(elem, r, p, calc, **kw).run()
+    drv = GrowingStringDriver.from_calculator(elem, r, p, calc, **kw)
+    assert drv.device.type == "cuda" and isinstance(drv._evaluate_device, EngineStringEvaluator)
+    dev = drv.run()
+    assert dev.cycles == host.cycles and dev.fully_grown and [h["images"] for h in dev.history] == [h["images"] for h in host.history]
+    assert np.abs(dev.coords - host.coords).max() <= 1e-9 and np.abs(dev.energies - host.energies).max() <= 1e-9
+    # the evaluator IS get_forces_batch on the device: bitwise per image
+    x = torch.as_tensor(host.coords, dtype=torch.float64, device=drv.device)
+    e_d, f_d = drv._evaluate_device(x)
+    chk = calc.get_forces_batch(elem, host.coords)
+    assert np.array_equal(e_d.cpu().numpy(), chk["energy"]) and np.array_equal(f_d.cpu().numpy(), chk["forces"])
+    assert np.all(f_d.cpu().numpy().reshape(6, -1, 3)[:, [0, 7]] == 0.0)
+    assert dev.timing["total_s"] > 0 and dev.timing["redo_steps"] >= 0
+    # a stand-in calculator without an engine keeps the numpy path
+    class Plain:
+        def get_forces_batch(self, atoms, c):
+            return calc.get_forces_batch(atoms, c)
+    assert GrowingStringDriver.from_calculator(elem, r, p, Plain(), **kw).device.type == "cpu"
+
+
 def test_staged_scan_with_batched_lbfgs_on_the_engine(setup):
     """Row f3 end to end: two mobile images are rigidly fitted onto a reference and their anchors dragged onto it while
     the rest relaxes -- every L-BFGS cycle is ONE batched engine call for both images."""

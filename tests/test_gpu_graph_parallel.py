@@ -140,6 +140,47 @@ def _nccl_one_rank(rank, port, out):
         dist.destroy_process_group()
 
 
+def _nccl_one_rank_gather(rank, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from pdb2reaction_amd.engine import Engine
+        from pdb2reaction_amd.parallel import EngineStringEvaluator
+        from pdb2reaction_amd._calculator_base import ANG2BOHR
+
+        z, imgs, _ = synth.make_images(60, 3, seed=6)
+        eng = Engine(0)
+        eng.load_weights(W.make_synthetic_weights(0))
+        eng.set_system(z)
+        x = torch.as_tensor(imgs * ANG2BOHR, dtype=torch.float64, device=dev).reshape(3, -1)
+        plain = EngineStringEvaluator(eng, len(z), dev, frozen=[2])
+        e0, f0 = plain(x)
+        for check in ("sync", "deferred"):
+            ev = EngineStringEvaluator(eng, len(z), dev, frozen=[2], check=check, force_collective=True)
+            e, f = ev(x)
+            e2, f2 = ev(x)
+            ev.flush()
+            torch.cuda.synchronize()
+            inner = ev._ev[3]
+            out[check] = bool(inner.distributed and not inner._stage_cpu and torch.equal(e, e0) and torch.equal(f, f0) and torch.equal(e2, e0) and torch.equal(f2, f0))
+        out["backend"] = dist.get_backend()
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_all_gather_of_the_image_shards():
+    """The collective of the image-sharded path: ONE ``all_gather_into_tensor`` of float64 [E | status | F] rows per
+    evaluation, here issued by RCCL in a one-rank nccl group (``force_collective``) on the evaluator's device buffers, on torch's current
+    stream right behind the engine's kernels -- sync and deferred check; the gathered result must be bitwise the ungathered one."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_nccl_one_rank_gather, args=(_port(), out), nprocs=1, join=True)
+    assert out["backend"] == "nccl" and out["sync"] is True and out["deferred"] is True
+
+
 def test_rccl_all_reduce_in_place_on_engine_memory():
     """The RCCL leg of the graph-parallel mode: with a one-rank nccl group and ``force_collective`` all ten all-reduces are issued by
     RCCL on the caller's stream directly on the engine's workspace buffers (the ``__cuda_array_interface__`` view, no copy).  A

@@ -21,18 +21,20 @@ calc = U.uma_pysis(model="synthetic", freeze_atoms=list(frozen))
 r, p = (imgs[0] * U.ANG2BOHR).reshape(-1), (imgs[1] * U.ANG2BOHR).reshape(-1)
 free0 = torch.cuda.mem_get_info()[0]
 t0 = time.perf_counter()
-drv = GrowingStringDriver(elem, r, p, calc, gs_kw={"max_nodes": nodes, "climb": True}, stopt_kw={"max_cycles": cycles})
+drv = GrowingStringDriver.from_calculator(elem, r, p, calc, gs_kw={"max_nodes": nodes, "climb": True}, stopt_kw={"max_cycles": cycles})
+print("driver device:", drv.device)
 res = drv.run()
 dt = time.perf_counter() - t0
 free1 = torch.cuda.mem_get_info()[0]
 print(f"atoms {n} images {len(res.coords)} cycles {res.cycles} force evaluations {res.force_evaluations} "
       f"fully_grown {res.fully_grown} converged {res.converged}")
 print(f"wall {dt:.2f} s = {dt / max(res.cycles, 1) * 1e3:.1f} ms/cycle; image E+F per s {res.force_evaluations / dt:.1f}")
+print(f"timing: total {res.timing['total_s']:.2f} s, optimistic steps recomputed {int(res.timing['redo_steps'])}, Lanczos evaluations {drv.lanczos_evals}")
 print(f"device memory in use by the run: {(free0 - free1) / 2**30:.2f} GiB (workspace is allocated once and kept)")
 print("energies (Hartree, rel. to first):", np.round(res.energies - res.energies[0], 5))
 assert np.isfinite(res.energies).all() and np.isfinite(res.coords).all()
 # second run on the same calculator must not grow the footprint
-drv2 = GrowingStringDriver(elem, r, p, calc, gs_kw={"max_nodes": nodes, "climb": False}, stopt_kw={"max_cycles": 5})
+drv2 = GrowingStringDriver.from_calculator(elem, r, p, calc, gs_kw={"max_nodes": nodes, "climb": False}, stopt_kw={"max_cycles": 5})
 drv2.run()
 free2 = torch.cuda.mem_get_info()[0]
 print(f"after a second run: {(free1 - free2) / 2**20:.1f} MiB more")

@@ -215,6 +215,28 @@ def test_device_resident_gsm_driver_equals_the_host_path(setup):
     assert GrowingStringDriver.from_calculator(elem, r, p, Plain(), **kw).device.type == "cpu"
 
 
+def test_rfo_single_structure_optimisation_on_the_engine(setup):
+    """The RFO branch of ``_optimize_single`` (path_opt.py:464-518) on the engine: the initial Hessian is ``get_hessian`` (finite
+    differences of BATCHED engine forces), every cycle one E+F; frozen atoms stay put, the energy falls, the forces shrink."""
+    from pdb2reaction_amd.rfo import optimize_single
+
+    z, elem, imgs = setup
+    calc = U.uma_pysis(model="synthetic", freeze_atoms=[0, 3], out_hess_torch=True)
+    x0 = imgs[0] * U.ANG2BOHR
+    f0 = calc.get_forces(elem, x0.reshape(-1))
+    res = optimize_single(calc, elem, x0, "rfo", {"thresh": "gau_loose", "max_cycles": 12, "gdiis": False, "line_search": False, "adapt_step_func": False},
+                          freeze=[0, 3])
+    assert res["n_hessian_calls"] == 1 and res["n_force_calls"] == res["cycles"] + 1
+    assert np.array_equal(res["coords"][[0, 3]], x0[[0, 3]])
+    assert res["energy"] < f0["energy"] - 1e-4
+    act = np.ones(len(z), bool); act[[0, 3]] = False
+    assert np.abs(res["forces"].reshape(-1, 3)[act]).max() < 0.7 * np.abs(f0["forces"].reshape(-1, 3)[act]).max()
+    es = [h["energy"] for h in res["history"]]
+    assert all(b <= a + 5e-6 for a, b in zip(es, es[1:]))           # restricted steps on a model Hessian: no energy rise beyond float32 noise
+    lb = optimize_single(calc, elem, x0, "lbfgs", {"thresh": "gau_loose", "max_cycles": 12}, freeze=[0, 3])
+    assert lb["energy"] < f0["energy"] - 1e-4 and np.array_equal(lb["coords"][[0, 3]], x0[[0, 3]])
+
+
 def test_staged_scan_with_batched_lbfgs_on_the_engine(setup):
     """Row f3 end to end: two mobile images are rigidly fitted onto a reference and their anchors dragged onto it while
     the rest relaxes -- every L-BFGS cycle is ONE batched engine call for both images."""

@@ -178,6 +178,16 @@ def test_c2_c3_gsm_driver_at_baseline_sizes(n_atoms, n_img, gold):
     res = drv.run()
     assert res.fully_grown and res.coords.shape == (n_img, 3 * n_atoms) and np.isfinite(res.energies).all()
     assert len(calls) <= res.cycles + 1 and max(calls) == n_img and res.force_evaluations == sum(calls)
+    # the DEVICE-RESIDENT form of the same run (round 4: the string never leaves the GPU, one read of 2K+8 doubles per cycle) follows it:
+    # same growth sequence, same number of evaluations, coordinates and energies to round-off
+    n_host = len(calls)
+    dev = GrowingStringDriver.from_calculator(elem, r, p, calc, gs_kw={"max_nodes": n_img - 2, "perp_thresh": 1e3, "climb": False},
+                                              stopt_kw={"max_cycles": n_img // 2 + 2, "max_step": 0.05})
+    assert dev.device.type == "cuda"
+    rd = dev.run()
+    assert len(calls) == n_host                                  # (the device path does not go through get_forces_batch)
+    assert rd.cycles == res.cycles and rd.force_evaluations == res.force_evaluations and [h["images"] for h in rd.history] == [h["images"] for h in res.history]
+    assert np.abs(rd.coords - res.coords).max() <= 1e-8 and np.abs(rd.energies - res.energies).max() <= 1e-8
     # endpoint energy of the driver == golden energy of c2 image 0 (Hartree vs eV), forces of the frozen atoms are zero
     assert abs(res.energies[0] / U.EV2AU - g["energy"][0]) <= TOL_E
     f0 = inner(elem, res.coords[:1])["forces"].reshape(n_atoms, 3)

@@ -127,8 +127,9 @@ class Engine:
     """One UMA-S engine on one GPU (one per process/rank)."""
 
     def __init__(self, device: int = 0, precision: Optional[str] = None):
-        """precision: None = the UMX_PRECISION environment variable (default "auto": split-f16 up to 4096 atoms per image,
-        split-bf16 above), else "auto" | "split" | "split-bf16" | "fp32"."""
+        """precision: None = the UMX_PRECISION environment variable (default "auto" = "bf16x3": 3 x 3 bf16 planes / 6 products in both
+        passes, the like-for-like arithmetic to float32 -- include/umx.h), else "auto" | "bf16x3" | "split" (the opt-in fast mode:
+        fp16 forward planes, 16-bit reverse) | "split-bf16" | "fp32"."""
         self.lib = load_library()
         self._h = C.c_void_p()
         st = self.lib.umx_create(C.byref(self._h), int(device))
@@ -206,7 +207,7 @@ class Engine:
         return e, f
 
     def precision_mode(self) -> str:
-        """The arithmetic the engine is in now ("split-f16" | "split-bf16" | "fp32"): what "auto" resolved to for the bound system."""
+        """The arithmetic the engine is in now ("bf16x3" | "split-f16" | "split-bf16" | "fp32"): what "auto" resolved to."""
         return self.lib.umx_precision_mode(self._h).decode()
 
     def take_range_error(self) -> bool:

@@ -236,7 +236,32 @@ class GraphParallelEvaluator:
         return self._e.clone(), self._f.clone()
 
 
-class EngineStringEvaluator:
+class ShardedStringEvaluator:
+    """``evaluator(x[k, 3N]) -> (E[k], F[k, 3N])`` for ANY batch size k (a growing string changes it): the k images are sharded contiguously
+    over the ranks of `group` through a :class:`ShardedImageEvaluator` cached per k; ``local_fn(x_local[kl, N, 3]) -> (E[kl], F[kl, N, 3])``
+    evaluates this rank's block on `device`.  The device contract of ``gsm.GrowingStringDriver(evaluate_device=...)``."""
+
+    def __init__(self, local_fn: Callable, n_atoms: int, device: torch.device, group: Optional["dist.ProcessGroup"] = None, engine=None,
+                 check: str = "sync", force_collective: bool = False):
+        self.local_fn, self.n_atoms, self.device, self.group, self.engine, self.check = local_fn, int(n_atoms), device, group, engine, check
+        self.force_collective = bool(force_collective)
+        self._ev: dict = {}
+
+    def __call__(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        k = x.shape[0]
+        ev = self._ev.get(k)
+        if ev is None:
+            ev = self._ev[k] = ShardedImageEvaluator(self.local_fn, k, self.n_atoms, self.device, group=self.group, engine=self.engine, check=self.check,
+                                                     force_collective=self.force_collective)
+        e, f = ev(x.reshape(k, self.n_atoms, 3))
+        return e, f.reshape(k, -1)
+
+    def flush(self):
+        for ev in self._ev.values():
+            ev.flush()
+
+
+class EngineStringEvaluator(ShardedStringEvaluator):
     """Device evaluator of string images for a device-resident driver (``gsm.GrowingStringDriver(evaluate_device=...)``, bench.py):
     ``evaluator(x[k, 3N] Bohr float64 on the engine's GPU) -> (E[k] Hartree float64, F[k, 3N] Hartree/Bohr float64)`` on the same
     device, exactly what ``uma_pysis.get_forces_batch`` returns per image (``uma_pysis.py:695-706``: float32 Angstrom positions into
@@ -250,13 +275,11 @@ class EngineStringEvaluator:
         from ._calculator_base import BOHR2ANG
         from .hessian import EV_PER_ANG_TO_AU, EV_TO_HARTREE
 
-        self.engine, self.n_atoms, self.device, self.group, self.check = engine, int(n_atoms), device, group, check
-        self.force_collective = bool(force_collective)
+        super().__init__(self._local, n_atoms, device, group=group, engine=engine, check=check, force_collective=force_collective)
         self._b2a, self._e2h, self._f2au = float(BOHR2ANG), float(EV_TO_HARTREE), float(EV_PER_ANG_TO_AU)
         self._frozen = torch.as_tensor(sorted(set(int(i) for i in frozen)), dtype=torch.long, device=device)
         self._cap = 0
         self._pos32 = self._e = self._f = None
-        self._ev: dict = {}
         if max_images:
             self._reserve(int(max_images))
             engine.reserve_images(int(max_images))
@@ -280,16 +303,3 @@ class EngineStringEvaluator:
         if self._frozen.numel():
             f[:, self._frozen, :] = 0.0                                              # uma_pysis.py:561-567
         return self._e[:kl] * self._e2h, f
-
-    def __call__(self, x_bohr: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        k = x_bohr.shape[0]
-        ev = self._ev.get(k)
-        if ev is None:
-            ev = self._ev[k] = ShardedImageEvaluator(self._local, k, self.n_atoms, self.device, group=self.group, engine=self.engine, check=self.check,
-                                                        force_collective=self.force_collective)
-        e, f = ev(x_bohr.reshape(k, self.n_atoms, 3))
-        return e, f.reshape(k, -1)
-
-    def flush(self):
-        for ev in self._ev.values():
-            ev.flush()

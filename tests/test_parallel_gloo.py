@@ -372,3 +372,70 @@ def test_single_rank_fd_hessian_never_mixes_two_arithmetics():
     h_wide = fd_hessian(lambda c: (-(c.reshape(len(c), -1) @ a)).reshape(c.shape).astype(np.float32), x0, [], device=torch.device("cpu"),
                         double=True, partial=False, batch=4, engine=wide)
     assert torch.equal(h, h_wide) and len(calls) == 12 and calls[6:] == [True] * 6
+
+
+# ---- round 4: the REAL driver (gsm.GrowingStringDriver) through the sharded evaluator, two ranks ---------------------------------
+def _mb_energy_forces(q):
+    """Mueller-Brown surface in x, y (+ z^2 / 2), scaled to a Hartree-like range: q (k, 1, 3) -> (E (k,), F (k, 1, 3)), torch float64."""
+    A = torch.tensor([-200.0, -100.0, -170.0, 15.0], dtype=torch.float64)
+    a = torch.tensor([-1.0, -1.0, -6.5, 0.7], dtype=torch.float64)
+    b = torch.tensor([0.0, 0.0, 11.0, 0.6], dtype=torch.float64)
+    c = torch.tensor([-10.0, -10.0, -6.5, 0.7], dtype=torch.float64)
+    x0 = torch.tensor([1.0, 0.0, -0.5, -1.0], dtype=torch.float64)
+    y0 = torch.tensor([0.0, 0.5, 1.5, 1.0], dtype=torch.float64)
+    p = q.reshape(-1, 3)
+    dx, dy = p[:, 0:1] - x0, p[:, 1:2] - y0
+    t = A * torch.exp(a * dx ** 2 + b * dx * dy + c * dy ** 2)
+    e = 1e-3 * t.sum(1) + 0.5 * p[:, 2] ** 2
+    fx = -1e-3 * (t * (2 * a * dx + b * dy)).sum(1)
+    fy = -1e-3 * (t * (b * dx + 2 * c * dy)).sum(1)
+    return e, torch.stack([fx, fy, -p[:, 2]], dim=1).reshape(q.shape)
+
+
+def _gsm_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pdb2reaction_amd.gsm import GrowingStringDriver
+        from pdb2reaction_amd.parallel import ShardedStringEvaluator
+
+        calls = []
+
+        def local(c):
+            calls.append(int(c.shape[0]))
+            return _mb_energy_forces(c)
+
+        ev = ShardedStringEvaluator(local, 1, torch.device("cpu"))
+        drv = GrowingStringDriver(["X"], np.array([-0.558224, 1.441726, 0.0]), np.array([0.623499, 0.028038, 0.0]), evaluate_device=ev, device=torch.device("cpu"),
+                                  gs_kw={"max_nodes": 9, "perp_thresh": 2e-2, "climb_rms": 5e-3}, stopt_kw={"thresh": "gau", "max_step": 0.05, "max_cycles": 400})
+        res = drv.run()
+        out[rank] = (res.coords, res.energies, res.converged, res.cycles, res.force_evaluations, calls, drv.lanczos_evals)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_growing_string_driver_runs_spmd_over_two_ranks():
+    """SURVEY.md 8e with the real driver: both ranks run ``gsm.GrowingStringDriver`` (device-resident form, CPU tensors here) on the same
+    string; every batched evaluation is sharded over the ranks (each evaluates its block only) and gathered; the replicated update keeps
+    the ranks bit-identical, and the run equals the single-process run."""
+    from pdb2reaction_amd.gsm import GrowingStringDriver
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gsm_worker, args=(2, port, out), nprocs=2, join=True)
+    single = GrowingStringDriver(["X"], np.array([-0.558224, 1.441726, 0.0]), np.array([0.623499, 0.028038, 0.0]),
+                                 evaluate_device=lambda x: tuple(t.reshape(x.shape[0], -1) if t.dim() > 1 else t for t in _mb_energy_forces(x.reshape(-1, 1, 3))),
+                                 device=torch.device("cpu"), gs_kw={"max_nodes": 9, "perp_thresh": 2e-2, "climb_rms": 5e-3},
+                                 stopt_kw={"thresh": "gau", "max_step": 0.05, "max_cycles": 400}).run()
+    c0, e0, conv0, cyc0, nev0, calls0, lz0 = out[0]
+    c1, e1, conv1, cyc1, nev1, calls1, lz1 = out[1]
+    assert conv0 and conv1 and cyc0 == cyc1 == single.cycles and nev0 == nev1 == single.force_evaluations
+    assert np.array_equal(c0, c1) and np.array_equal(e0, e1)                         # the ranks never diverge
+    assert np.array_equal(c0, single.coords) and np.array_equal(e0, single.energies)  # sharding changes nothing
+    assert lz0 == lz1 and lz0 > 0
+    # each rank evaluated only its share: together the ranks did the batched evaluations once (+ every Lanczos single on rank 0's block)
+    assert sum(calls0) + sum(calls1) == nev0 and sum(calls0) < nev0 and sum(calls1) < nev0

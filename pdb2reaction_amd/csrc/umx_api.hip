@@ -78,7 +78,9 @@ struct umx_engine {
   std::map<const float*, bool> planes_q;                  // weight plane copies stored in the quad-row layout (else PL)
   float odd_sign = -1.0f;          // sign-alternating operand rows (umx_kernels_pl.h): -1 = on (default), +1 = off (UMX_ALT_ROWS=0, dev A/B)
   int rev_planes = 2;              // bf16 planes of the REVERSE-pass operands: 2 (3 products, 16-bit) or 3 (6 products, 24-bit: UMX_PRECISION=bf16x3)
-  int fwd_fmt = 1;                 // forward operand format (QFmt, umx_kernels_pl.h): 1 = two fp16 planes (UMX_PRECISION=split), 0 = three bf16 planes (split-bf16)
+  int fwd_fmt = 1;                 // forward operand format (QFmt, umx_kernels_pl.h): 1 = two fp16 planes (UMX_PRECISION=split), 0 = three bf16 planes (split-bf16),
+                                   // 2 = two fp16 planes + two 8-bit planes (UMX_PRECISION=f16x2b8: 24-bit products, the third-plane terms on the bf8 matrix instruction)
+  std::map<const float*, const unsigned char*> planes8;   // fwd_fmt 2: the 8-bit planes ("O8" layout, umx_gemm_q.h) of a weight
   std::string precision;           // umx_set_precision: overrides UMX_PRECISION when non-empty
   bool node_ctx = false;           // set around the node-level launches (NodeCtx): only those take the float64-accumulating kernel
   bool node_f64_on = true;         // UMX_NODE_F64=0: node-level linears (atom-wise SO(3) linears, scalar MLP, readout and their transposes) on the
@@ -299,7 +301,7 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
     pr = &eng->prof[eng->prof_used++];
     pr->flops = cplx ? 8.0 * M * (double)N * K : 2.0 * M * (double)N * K;
     pr->M = (int)M; pr->N = N; pr->K = K; pr->amode = 9; pr->cplx = cplx; pr->gz = 1;
-    pr->prec = (fwd && eng->q3 && eng->fwd_fmt == 1) ? 20 + eng->f16_prod : P;      // 23 / 24: two fp16 planes, 3 / 4 products; 3 / 2: bf16 planes, 6 / 3 products
+    pr->prec = (fwd && eng->q3 && eng->fwd_fmt == 2) ? 28 : (fwd && eng->q3 && eng->fwd_fmt == 1) ? 20 + eng->f16_prod : P;      // 28: fp16 x 2 + bf8 (4 + 2 half-cost products); 23 / 24: two fp16 planes, 3 / 4 products; 3 / 2: bf16 planes, 6 / 3 products
     HIPCHK(eng, hipEventRecord(pr->a, eng->stream));
   }
   // MFMA shape per GEMM (measured in the c3 pipeline): 16x16x32 wins 1-7 % on the complex SO(2) GEMMs and on K >= 512,
@@ -321,7 +323,19 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
     const long nNq = (N + bnq - 1) / bnq;
     dim3 gq((unsigned)(((nM + 7) / 8) * 8 * nNq));
     const int S = eng->q3_stages;             // ring depth: 2 (default) or 3 (UMX_Q3S=3: 144 KB wide / 108 KB narrow)
-    if (eng->fwd_fmt == 1) {
+    if (eng->fwd_fmt == 2) {
+      // two fp16 planes + two 8-bit planes of the activations, three fp16 planes (exact) + two 8-bit planes of the weights (umx_gemm_q.h, X8);
+      // the 8-bit planes of A follow its half planes in the same buffer
+      if (K % 64 != 0 || offA0 % 64 != 0 || offA1 % 64 != 0) return fail(eng, UMX_ERR_ARG, "gemm_pl: the f16x2b8 form needs K and the column offsets in multiples of 64");
+      const auto sc = eng->plane_scale.find(Wkey);
+      const auto p8 = eng->planes8.find(Wkey);
+      if (sc == eng->plane_scale.end() || p8 == eng->planes8.end()) return fail(eng, UMX_ERR_ARG, "gemm_pl: weight has no f16x2b8 plane copy");
+      q.lda = (long)a_cols * 2; q.ldb = (long)K * 3;
+      q.cscale = 1.0f / (QF16_SCALE * sc->second);
+      q.A8 = reinterpret_cast<const unsigned char*>(Apl) + (size_t)((M + 3) / 4 * 4) * a_cols * 4; q.lda8 = (long)a_cols * 2; q.B8 = p8->second;
+      if (cplx) { if (wq) hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1, 2, 2, 1, 4, 3, 1>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<1, 0, 2, 2, 1, 4, 3, 1>), gq, block, 0, eng->stream, q); }
+      else      { if (wq) hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 2, 2, 1, 4, 3, 1>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0, 2, 2, 1, 4, 3, 1>), gq, block, 0, eng->stream, q); }
+    } else if (eng->fwd_fmt == 1) {
       // two fp16 planes of 16 x (activations), three (exact) or two planes of s_w x (weights): C = (A' . B'^T) / (16 s_w)
       q.lda = (long)a_cols * 2; q.ldb = (long)K * (eng->f16_prod == 3 ? 2 : 3);
       const auto sc = eng->plane_scale.find(Wkey);
@@ -403,7 +417,7 @@ struct Bump {
 };
 
 // workspace mode: 0 = fp32 path, else (planes of the forward operands) + 16 when the reverse operands have three planes
-inline int ws_mode(const umx_engine* eng) { return !eng->pl ? 0 : ((eng->q3 && eng->fwd_fmt == 1) ? 2 : 3) + (eng->rev_planes == 3 ? 16 : 0); }
+inline int ws_mode(const umx_engine* eng) { return !eng->pl ? 0 : ((eng->q3 && eng->fwd_fmt == 1) ? 2 : 3) + (eng->rev_planes == 3 ? 16 : 0); }   // (fwd_fmt 2: two half planes + two byte planes = 3 x 2 bytes)
 
 // Workspace layout.  PERSISTENT buffers live from the forward to the reverse pass of an evaluation (node-level state, the graph, and the
 // per-edge activations of all four layers: ~72 KB per directed edge); TRANSIENT buffers are the operands between a producer and a GEMM
@@ -485,20 +499,32 @@ int radial_fwd_head(umx_engine* eng, const WS& w, const RadialW& r, int slot, lo
     do {                                                                                                              \
       const int fm = eng->radial_fast;                                                                                \
       if (TR == 1) {                                                                                                  \
-        if (fm == 2) hipLaunchKernelGGL((k_radial_head<Q, 2, 1>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign);                      \
-        else if (fm == 1) hipLaunchKernelGGL((k_radial_head<Q, 1, 1>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign);                 \
-        else hipLaunchKernelGGL((k_radial_head<Q, 0, 1>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign);                              \
+        if (fm == 2) hipLaunchKernelGGL((k_radial_head<Q, 2, 1>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign, (unsigned char*)nullptr);                      \
+        else if (fm == 1) hipLaunchKernelGGL((k_radial_head<Q, 1, 1>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign, (unsigned char*)nullptr);                 \
+        else hipLaunchKernelGGL((k_radial_head<Q, 0, 1>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign, (unsigned char*)nullptr);                              \
       } else {                                                                                                        \
-        if (fm == 2) hipLaunchKernelGGL((k_radial_head<Q, 2, 2>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign);                      \
-        else if (fm == 1) hipLaunchKernelGGL((k_radial_head<Q, 1, 2>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign);                 \
-        else if (Q == 2 && eng->radial_f16 == 3) hipLaunchKernelGGL((k_radial_head<Q, 0, 2, (Q == 2 ? 3 : 0)>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign); \
-        else if (Q == 2 && eng->radial_f16 == 2) hipLaunchKernelGGL((k_radial_head<Q, 0, 2, (Q == 2 ? 2 : 0)>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign); \
-        else if (Q == 2 && eng->radial_f16 == 1) hipLaunchKernelGGL((k_radial_head<Q, 0, 2, (Q == 2 ? 1 : 0)>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign); \
-        else hipLaunchKernelGGL((k_radial_head<Q, 0, 2>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign);                              \
+        if (fm == 2) hipLaunchKernelGGL((k_radial_head<Q, 2, 2>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign, (unsigned char*)nullptr);                      \
+        else if (fm == 1) hipLaunchKernelGGL((k_radial_head<Q, 1, 2>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign, (unsigned char*)nullptr);                 \
+        else if (Q == 2 && eng->radial_f16 == 3) hipLaunchKernelGGL((k_radial_head<Q, 0, 2, (Q == 2 ? 3 : 0)>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign, (unsigned char*)nullptr); \
+        else if (Q == 2 && eng->radial_f16 == 2) hipLaunchKernelGGL((k_radial_head<Q, 0, 2, (Q == 2 ? 2 : 0)>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign, (unsigned char*)nullptr); \
+        else if (Q == 2 && eng->radial_f16 == 1) hipLaunchKernelGGL((k_radial_head<Q, 0, 2, (Q == 2 ? 1 : 0)>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign, (unsigned char*)nullptr); \
+        else hipLaunchKernelGGL((k_radial_head<Q, 0, 2>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign, (unsigned char*)nullptr);                              \
       }                                                                                                               \
     } while (0)
     ProfRec* pr = prof_open(eng, 2.0 * ne * ((double)NG * RH + (double)RH * RH), -1, ne, RH, NG + RH);
-    if (planes && eng->fwd_fmt == 1) UMX_RH_LAUNCH(2, w.a2pl); else if (planes) UMX_RH_LAUNCH(1, w.a2pl); else UMX_RH_LAUNCH(0, w.ra);
+    if (planes && eng->fwd_fmt == 2) {
+      unsigned char* a2o8 = reinterpret_cast<unsigned char*>(w.a2pl) + (size_t)((ne + 3) / 4 * 4) * RH * 4;
+      const int fm = eng->radial_fast;
+      if (TR == 1) {
+        if (fm == 2) hipLaunchKernelGGL((k_radial_head<3, 2, 1>), UMX_RH_ARGS, (void*)w.a2pl, ne, eng->odd_sign, a2o8);
+        else if (fm == 1) hipLaunchKernelGGL((k_radial_head<3, 1, 1>), UMX_RH_ARGS, (void*)w.a2pl, ne, eng->odd_sign, a2o8);
+        else hipLaunchKernelGGL((k_radial_head<3, 0, 1>), UMX_RH_ARGS, (void*)w.a2pl, ne, eng->odd_sign, a2o8);
+      } else {
+        if (fm == 2) hipLaunchKernelGGL((k_radial_head<3, 2, 2>), UMX_RH_ARGS, (void*)w.a2pl, ne, eng->odd_sign, a2o8);
+        else if (fm == 1) hipLaunchKernelGGL((k_radial_head<3, 1, 2>), UMX_RH_ARGS, (void*)w.a2pl, ne, eng->odd_sign, a2o8);
+        else hipLaunchKernelGGL((k_radial_head<3, 0, 2>), UMX_RH_ARGS, (void*)w.a2pl, ne, eng->odd_sign, a2o8);
+      }
+    } else if (planes && eng->fwd_fmt == 1) UMX_RH_LAUNCH(2, w.a2pl); else if (planes) UMX_RH_LAUNCH(1, w.a2pl); else UMX_RH_LAUNCH(0, w.ra);
 #undef UMX_RH_LAUNCH
 #undef UMX_RH_ARGS
     prof_close(eng, pr);
@@ -513,9 +539,11 @@ int radial_fwd_head(umx_engine* eng, const WS& w, const RadialW& r, int slot, lo
   hipLaunchKernelGGL(k_ln_silu_fwd, dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h1pre[slot], r.ln1w, r.ln1b, w.ra, ne);
   CHK(gemm_plain(eng, w.ra, RH, 0, r.w2, RH, r.b2, w.h2pre[slot], RH, 0, ne, RH, RH));
   if (eng->pl && eng->planes.count(r.w3)) {
-    if (eng->q3 && eng->fwd_fmt == 1) hipLaunchKernelGGL((k_ln_silu_fwd_pl<2, true>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne, eng->odd_sign);
-    else if (eng->q3) hipLaunchKernelGGL((k_ln_silu_fwd_pl<3, true>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne, eng->odd_sign);
-    else hipLaunchKernelGGL((k_ln_silu_fwd_pl<3, false>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne, eng->odd_sign);
+    if (eng->q3 && eng->fwd_fmt == 2) hipLaunchKernelGGL((k_ln_silu_fwd_pl<2, true>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne, eng->odd_sign,
+                                                         reinterpret_cast<unsigned char*>(w.a2pl) + (size_t)((ne + 3) / 4 * 4) * RH * 4);
+    else if (eng->q3 && eng->fwd_fmt == 1) hipLaunchKernelGGL((k_ln_silu_fwd_pl<2, true>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne, eng->odd_sign, (unsigned char*)nullptr);
+    else if (eng->q3) hipLaunchKernelGGL((k_ln_silu_fwd_pl<3, true>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne, eng->odd_sign, (unsigned char*)nullptr);
+    else hipLaunchKernelGGL((k_ln_silu_fwd_pl<3, false>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne, eng->odd_sign, (unsigned char*)nullptr);
   } else {
     hipLaunchKernelGGL(k_ln_silu_fwd, dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.ra, ne);
   }
@@ -682,8 +710,10 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
         hipStream_t s = eng->stream;
         // the NEXT layer's radial head (geometry only; a2pl is free: this layer's fc3 has consumed it) beside this HBM-bound kernel
         if (side && i + 1 < NL) CHK(side_launch(eng->ev_shead, [=, &w]() -> int { return radial_fwd_head(eng, w, eng->lw[i + 1].rad, i + 1, ne); }));
-        if (eng->q3 && eng->fwd_fmt == 1) hipLaunchKernelGGL(k_gather_rotate_mod_q3<1>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne, eng->odd_sign);
-        else if (eng->q3) hipLaunchKernelGGL(k_gather_rotate_mod_q3<0>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne, eng->odd_sign);
+        if (eng->q3 && eng->fwd_fmt == 2) hipLaunchKernelGGL(k_gather_rotate_mod_q3<2>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne, eng->odd_sign,
+                                                             reinterpret_cast<unsigned char*>(w.y1pl) + (size_t)((ne + 3) / 4 * 4) * XROT * 4);
+        else if (eng->q3 && eng->fwd_fmt == 1) hipLaunchKernelGGL(k_gather_rotate_mod_q3<1>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne, eng->odd_sign, (unsigned char*)nullptr);
+        else if (eng->q3) hipLaunchKernelGGL(k_gather_rotate_mod_q3<0>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne, eng->odd_sign, (unsigned char*)nullptr);
         else hipLaunchKernelGGL((k_gather_rotate_mod_pl<3, false>), dim3((nblk(ne, 4) + 7) / 8 * 8), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne, eng->odd_sign);
         HIPCHK(eng, hipGetLastError());
         return UMX_OK;
@@ -696,8 +726,10 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       });
       P.stream([=, &w]() -> int {
         hipStream_t s = eng->stream;
-        if (eng->q3 && eng->fwd_fmt == 1) hipLaunchKernelGGL(k_gate_edge_fwd_q3<1>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hg[i], w.hidpl, ne, eng->odd_sign);
-        else if (eng->q3) hipLaunchKernelGGL(k_gate_edge_fwd_q3<0>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hg[i], w.hidpl, ne, eng->odd_sign);
+        if (eng->q3 && eng->fwd_fmt == 2) hipLaunchKernelGGL(k_gate_edge_fwd_q3<2>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hg[i], w.hidpl, ne, eng->odd_sign,
+                                                             reinterpret_cast<unsigned char*>(w.hidpl) + (size_t)((ne + 3) / 4 * 4) * ROW * 4);
+        else if (eng->q3 && eng->fwd_fmt == 1) hipLaunchKernelGGL(k_gate_edge_fwd_q3<1>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hg[i], w.hidpl, ne, eng->odd_sign, (unsigned char*)nullptr);
+        else if (eng->q3) hipLaunchKernelGGL(k_gate_edge_fwd_q3<0>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hg[i], w.hidpl, ne, eng->odd_sign, (unsigned char*)nullptr);
         else hipLaunchKernelGGL((k_gate_edge_fwd_pl<3, false>), dim3(nblk(ne * (H / 4), 256)), B256, 0, s, w.hg[i], w.hidpl, ne, eng->odd_sign);
         HIPCHK(eng, hipGetLastError());
         return UMX_OK;
@@ -1275,14 +1307,31 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
     else if (mode == "split" || mode == "split-f16") { eng->pl = true; eng->fwd_fmt = eng->q3 ? 1 : 0; }   // (the dev layout UMX_Q3=0 has bf16 planes only)
     else if (mode == "split-bf16") { eng->pl = true; eng->fwd_fmt = 0; }
     else if (mode == "bf16x3" || mode == "split-exact") { eng->pl = true; eng->fwd_fmt = 0; rev3 = true; }   // 24-bit products in BOTH passes
-    else return fail(eng, UMX_ERR_ARG, "UMX_PRECISION must be auto, split (= split-f16), split-bf16, bf16x3 (= split-exact) or fp32");
+    else if (mode == "f16x2b8") { eng->pl = true; eng->fwd_fmt = 2; rev3 = true; }   // forward: two fp16 planes + bf8 third planes (25-bit operands), reverse as bf16x3
+    else return fail(eng, UMX_ERR_ARG, "UMX_PRECISION must be auto, split (= split-f16), split-bf16, bf16x3 (= split-exact), f16x2b8 or fp32");
     eng->rev_planes = (eng->pl && rev3) ? 3 : 2;
-    if (mode == "split-f16" && !eng->q3) return fail(eng, UMX_ERR_ARG, "UMX_PRECISION=split-f16 needs the quad-row operand layout (UMX_Q3=1)");
+    if ((mode == "split-f16" || mode == "f16x2b8") && !eng->q3) return fail(eng, UMX_ERR_ARG, "UMX_PRECISION=split-f16 / f16x2b8 need the quad-row operand layout (UMX_Q3=1)");
     // a precision change alters the workspace carve-up: force a re-carve on the next call
     eng->cap_nodes = 0; eng->cap_edges = 0;
   }
   if (const char* ev = std::getenv("UMX_F16_PRODUCTS")) eng->f16_prod = std::atoi(ev) == 3 ? 3 : 4;
   eng->plane_scale.clear();
+  std::vector<std::pair<const float*, size_t>> preq8;   // fwd_fmt 2: (weight, offset of its 8-bit planes in `bw`, in shorts)
+  // bf8 (e5m2) <- binary32, round to nearest even, saturating at the largest finite value 57344, subnormals kept (v_cvt_pk_bf8_f32's result for in-range input)
+  auto to_bf8 = [](float f) -> unsigned char {
+    uint32_t x; std::memcpy(&x, &f, 4);
+    const unsigned char sign = (unsigned char)((x >> 24) & 0x80u);
+    x &= 0x7FFFFFFFu;
+    float a; std::memcpy(&a, &x, 4);
+    if (!(a == a)) return (unsigned char)(sign | 0x7Fu);
+    if (a >= 57344.0f) return (unsigned char)(sign | 0x7Bu);
+    if (a < 6.103515625e-05f) return (unsigned char)(sign | (unsigned char)std::lrintf(a * 65536.0f));     // below 2^-14: multiples of 2^-16 (lrintf: to nearest even)
+    uint32_t h = (((x >> 23) - 112u) << 2) | ((x & 0x7FFFFFu) >> 21);
+    const uint32_t rem = x & 0x1FFFFFu;
+    if (rem > 0x100000u || (rem == 0x100000u && (h & 1u))) ++h;
+    if (h > 0x7Bu) h = 0x7Bu;
+    return (unsigned char)(sign | h);
+  };
   // IEEE binary16 <- binary32, round to nearest even, subnormals kept (what v_cvt_f16_f32 does for the activations)
   auto to_half = [](float f) -> unsigned short {
     uint32_t x; std::memcpy(&x, &f, 4);
@@ -1310,9 +1359,12 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
   // fp16 quad-row copy of a forward weight: PB half planes of s * w, s = the power of two that puts max|w| into [2^14, 2^15).
   // PB = 3: 33 significand bits -- exact for every weight above max|w| * 2^-16, an absolute 2^-39 max|w| below; PB = 2: 22 bits.
   auto want_planes_f16 = [&](const float* host, const float* dev, int rows, int K) {
-    const int PB = eng->f16_prod == 3 ? 2 : 3;
+    const bool x8 = eng->fwd_fmt == 2;        // three half planes + the two 8-bit planes (O8 layout, umx_gemm_q.h) behind them
+    const int PB = (!x8 && eng->f16_prod == 3) ? 2 : 3;
     PlaneReq r{dev, (bw.size() + 63) & ~size_t(63)};
-    bw.resize(r.off + (size_t)rows * K * PB);
+    const size_t off8 = r.off + (size_t)rows * K * PB;
+    bw.resize(off8 + (x8 ? (size_t)rows * K : 0));
+    if (x8) preq8.push_back({dev, off8});
     float mx = 0.f;
     for (size_t i = 0; i < (size_t)rows * K; ++i) mx = std::max(mx, std::fabs(host[i]));
     int ex = 0;
@@ -1323,7 +1375,13 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
       for (int k = 0; k < K; ++k) {
         float x = host[(size_t)rr * K + k] * sc;
         const size_t o = r.off + (((size_t)(rr / 4) * (K / 16) + k / 16) * (128 * PB) + (size_t)(rr % 4) * (32 * PB) + (size_t)(k % 16) * 2) / 2;
-        for (int q = 0; q < PB; ++q) { const unsigned short hq = to_half(x); bw[o + 16 * q] = hq; x -= from_half(hq); }
+        const float xs = x;
+        float w1 = 0.f;
+        for (int q = 0; q < PB; ++q) { const unsigned short hq = to_half(x); bw[o + 16 * q] = hq; if (q == 1) w1 = from_half(hq); x -= from_half(hq); }
+        if (x8) {           // 3-bit copies of the first two planes: w0' = bf8(s w), w1' = bf8(2^10 w1)
+          unsigned char* b8 = reinterpret_cast<unsigned char*>(bw.data() + off8) + ((size_t)rr * (K / 64) + k / 64) * 128 + (size_t)(k % 64);
+          b8[0] = to_bf8(xs); b8[64] = to_bf8(w1 * (float)(1 << Q8_SHIFT1));
+        }
       }
     preq.push_back(r);
   };
@@ -1335,7 +1393,7 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
     if (!fwdw) P = eng->rev_planes;
     const bool quad = (fwdw && eng->q3) || (!fwdw && rev_quad && P == 3 && eng->q3 && eng->rev_q3);
     eng->planes_q[dev] = quad;
-    if (fwdw && eng->q3 && eng->fwd_fmt == 1) { want_planes_f16(host, dev, rows, K); return; }
+    if (fwdw && eng->q3 && eng->fwd_fmt >= 1) { want_planes_f16(host, dev, rows, K); return; }
     PlaneReq r{dev, (bw.size() + 63) & ~size_t(63)};
     bw.resize(r.off + (size_t)rows * K * P);
     for (int rr = 0; rr < rows; ++rr)
@@ -1381,6 +1439,8 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
   HIPCHK(eng, hipMemcpy(eng->d_bw, bw.data(), bw.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
   eng->planes.clear();
   for (const auto& r : preq) eng->planes[r.dev] = eng->d_bw + r.off;
+  eng->planes8.clear();
+  for (const auto& r : preq8) eng->planes8[r.first] = reinterpret_cast<const unsigned char*>(eng->d_bw + r.second);
   auto fill_rad = [&](RadialW& r, const std::string& pre, int out) {
     const RadOff& o = roff[pre];
     r.w1g = D(o.w1g); r.w1gT = D(o.w1gT); r.ts = D(o.ts); r.tt = D(o.tt); r.w2T = D(o.w2T); r.w3T = D(o.w3T);
@@ -1427,7 +1487,7 @@ int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes) {
 
 const char* umx_precision_mode(const umx_engine* eng) {
   if (!eng || !eng->have_weights) return "";
-  return !eng->pl ? "fp32" : (eng->q3 && eng->fwd_fmt == 1) ? "split-f16" : eng->rev_planes == 3 ? "bf16x3" : "split-bf16";
+  return !eng->pl ? "fp32" : (eng->q3 && eng->fwd_fmt == 2) ? "f16x2b8" : (eng->q3 && eng->fwd_fmt == 1) ? "split-f16" : eng->rev_planes == 3 ? "bf16x3" : "split-bf16";
 }
 
 int umx_set_system(umx_engine* eng, int n_atoms, const int32_t* z, int charge, int spin, int task_index, float radius, int max_neigh) {
@@ -1495,7 +1555,7 @@ int umx_synchronize(umx_engine* eng) {
   if (flag) {
     HIPCHK(eng, hipMemset(eng->d_flags, 0, sizeof(int)));
     return fail(eng, UMX_ERR_RANGE, std::string("a device-pointer evaluation produced a non-finite energy") +
-                (eng->pl && eng->fwd_fmt == 1 ? " (an activation beyond the fp16 operand range of the split-f16 forward planes: re-load with UMX_PRECISION=split-bf16 or fp32)"
+                (eng->pl && eng->fwd_fmt >= 1 ? " (an activation beyond the fp16 operand range of the split-f16 / f16x2b8 forward planes: re-load with UMX_PRECISION=bf16x3 or fp32)"
                                               : " (non-finite input or an overflow in float32)"));
   }
   return UMX_OK;
@@ -1654,7 +1714,7 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
     // bit 0: set by an EARLIER evaluation through a device-pointer entry (this one has not computed an energy yet; on this stream that
     // evaluation is complete): its caller got NaN energies / forces and, most likely, derived these positions from them
     return fail(eng, UMX_ERR_RANGE, std::string("the previous device-pointer evaluation produced a non-finite energy") +
-                (eng->pl && eng->fwd_fmt == 1 ? " (an activation beyond the fp16 operand range of the split-f16 forward planes: re-load with UMX_PRECISION=split-bf16 or fp32)"
+                (eng->pl && eng->fwd_fmt >= 1 ? " (an activation beyond the fp16 operand range of the split-f16 / f16x2b8 forward planes: re-load with UMX_PRECISION=bf16x3 or fp32)"
                                               : " (non-finite input or an overflow in float32)"));
   }
   eng->last_maxdeg = img_edges[K];
@@ -1935,7 +1995,7 @@ int umx_energy_forces(umx_engine* eng, int n_images, const float* pos, double* e
     if (!std::isfinite(energy[k])) {
       (void)hipMemset(eng->d_flags, 0, sizeof(int));         // reported right here: do not fail the NEXT call for it as well
       return fail(eng, UMX_ERR_RANGE, "image " + std::to_string(k) + ": non-finite energy" +
-                  (eng->pl && eng->fwd_fmt == 1 ? " (an activation beyond the fp16 operand range of UMX_PRECISION=split: try split-bf16 or fp32)"
+                  (eng->pl && eng->fwd_fmt >= 1 ? " (an activation beyond the fp16 operand range of UMX_PRECISION=split / f16x2b8: try bf16x3 or fp32)"
                                                 : " (an overflow in float32)"));
     }
   return UMX_OK;
@@ -1997,7 +2057,7 @@ int umx_profile_read(umx_engine* eng, umx_profile_stats* out, int reset) {
     if (out) {
       const int fam = r.prec > 0 ? 0 : (r.prec < 0 ? 2 : 1);
       out->ms[fam] += t; out->launches[fam] += 1; out->alg_flops[fam] += r.flops;
-      out->mfma_flops[fam] += r.flops * (r.prec == 3 ? 6.0 : r.prec == 2 ? 3.0 : r.prec == 24 ? 4.0 : r.prec == 23 ? 3.0 : 1.0);
+      out->mfma_flops[fam] += r.flops * (r.prec == 3 ? 6.0 : r.prec == 2 ? 3.0 : r.prec == 24 ? 4.0 : r.prec == 23 ? 3.0 : r.prec == 28 ? 6.0 : 1.0);   // (28: four fp16 + two bf8 products executed -- the bf8 ones at twice the rate)
     }
     if (dump) std::fprintf(dump, "%d,%d,%d,%d,%d,%d,%d,%.6f,%.6e\n", r.M, r.N, r.K, r.amode, r.cplx, r.prec, r.gz, t, r.flops);
   }

@@ -22,6 +22,8 @@ constexpr float NORM_EPS = 1e-5f;
 constexpr float LN_EPS = 1e-5f;
 constexpr float DEG_RESCALE = 5.0f;
 constexpr float SQRT3 = 1.7320508075688772f;
+constexpr int Q8_SHIFT = 20;      // 8-bit operand planes (umx_gemm_q.h, X8): x2' = bf8(2^Q8_SHIFT x (residual of the two half planes)),
+constexpr int Q8_SHIFT1 = 10;     //                                           x1' = bf8(2^Q8_SHIFT1 x (the low half plane))
 
 // Accurate (<= 1 ulp, unbiased) transcendentals on purpose: every atom shares the same weights, so the
 // deterministic error of the fast v_exp/v_rsq approximations does not average out over atoms -- it showed up

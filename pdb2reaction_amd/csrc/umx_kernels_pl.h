@@ -67,9 +67,32 @@ template <int P> __device__ __forceinline__ void pl_store4(unsigned short* row, 
 //                  2^-14 / QF16_SCALE a fixed absolute resolution of 2^-25 / QF16_SCALE -- half subnormals are kept by the
 //                  conversion and by the MFMA), 256-B blocks.  |x| >= 65520 / QF16_SCALE converts to inf, the low plane to -inf
 //                  and the GEMM output to NaN: a range violation cannot pass silently (the energy comes out non-finite).
+//   FMT 2 ("Q2H+O8"): FMT 1 plus, in a second buffer, the two 8-bit planes of the 2^-22-order products (umx_gemm_q.h, X8 = 1):
+//                  x1' = bf8(2^Q8_SHIFT1 lo) and x2' = bf8(2^Q8_SHIFT (s x - hi - lo)), one 128-B line per (row, 64-column chunk):
+//                  byte (row * (cols/64) + k/64) * 128 + plane * 64 + k%64.  25 significant bits in all.
 // element (row, k, plane q) of a matrix with `cols` columns -> byte ((row/4) * (cols/16) + k/16) * 128 P + (row%4) * 32 P + q * 32 + (k%16) * 2.
 constexpr float QF16_SCALE = 16.f;
-template <int FMT> struct QFmt { static constexpr int P = FMT ? 2 : 3; static constexpr int BLK = 128 * P; static constexpr int ROWB = 32 * P; };
+template <int FMT> struct QFmt { static constexpr int P = FMT ? 2 : 3; static constexpr int BLK = 128 * P; static constexpr int ROWB = 32 * P; static constexpr bool X8 = (FMT == 2); };
+// the 8-bit planes of two adjacent values: bits 0-15 = the two bytes of plane 0 (x1'), bits 16-31 = those of plane 1 (x2').
+// (bf8 = e5m2, largest finite value 57344: |lo| <= 2^-11 * 65504 and |residual| <= 2^-22 * 65504 stay far inside after the shifts)
+__device__ __forceinline__ unsigned int o8_split2(float x0, float x1) {
+  x0 *= QF16_SCALE; x1 *= QF16_SCALE;
+  const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+  const float d0 = x0 - (float)h0, d1 = x1 - (float)h1;
+  const _Float16 l0 = (_Float16)d0, l1 = (_Float16)d1;
+  const float r0 = (d0 - (float)l0) * (float)(1 << Q8_SHIFT), r1 = (d1 - (float)l1) * (float)(1 << Q8_SHIFT);
+  int v = __builtin_amdgcn_cvt_pk_bf8_f32((float)l0 * (float)(1 << Q8_SHIFT1), (float)l1 * (float)(1 << Q8_SHIFT1), 0, false);
+  v = __builtin_amdgcn_cvt_pk_bf8_f32(r0, r1, v, true);
+  return (unsigned int)v;
+}
+__device__ __forceinline__ unsigned char* o8_ptr(unsigned char* base, long row, int cols, int k) { return base + (row * (cols >> 6) + (k >> 6)) * 128 + (k & 63); }
+// direct (2-byte) stores of the 8-bit planes of two adjacent values -- only where a row is short (the 128-column radial operand)
+__device__ __forceinline__ void o8_store2(unsigned char* base, long row, int cols, int k, float x0, float x1) {
+  const unsigned int w = o8_split2(x0, x1);
+  unsigned char* d = o8_ptr(base, row, cols, k);
+  *reinterpret_cast<unsigned short*>(d) = (unsigned short)(w & 0xffffu);
+  *reinterpret_cast<unsigned short*>(d + 64) = (unsigned short)(w >> 16);
+}
 // two adjacent values -> one packed dword per plane
 template <int FMT> __device__ __forceinline__ void q_split2(float x0, float x1, unsigned int (&out)[QFmt<FMT>::P]) {
   if constexpr (FMT == 0) {
@@ -134,7 +157,8 @@ template <int FMT> __device__ __forceinline__ void q_store4(unsigned short* base
 // LayerNorm(128)+SiLU of the radial MLP, output as PL planes (A operand of the fc3 GEMM)
 template <int P, bool Q = false>
 __global__ __launch_bounds__(256) void k_ln_silu_fwd_pl(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ b, unsigned short* __restrict__ y, long rows, float odd_sign) {
+                                                        const float* __restrict__ b, unsigned short* __restrict__ y, long rows, float odd_sign,
+                                                        unsigned char* __restrict__ y8) {
   UMX_WAVE_LOOP(row, rows) {
   const int c0 = lane * 2;
   float2 v = *reinterpret_cast<const float2*>(x + row * RH + c0);
@@ -147,6 +171,7 @@ __global__ __launch_bounds__(256) void k_ln_silu_fwd_pl(const float* __restrict_
   const float o0 = sg * silu_f(scale_rstd(v.x, rstd) * ww.x + bb.x), o1 = sg * silu_f(scale_rstd(v.y, rstd) * ww.y + bb.y);
   if (Q) q_store2<(P == 2)>(y, row, RH, c0, o0, o1);            // Q with P = 2: the fp16 two-plane format
   else pl_store2<P>(y + row * (RH * P), c0, o0, o1);
+  if (Q && P == 2 && y8) o8_store2(y8, row, RH, c0, o0, o1);    // (+ the 8-bit planes, FMT 2)
   }
 }
 
@@ -196,9 +221,12 @@ __global__ __launch_bounds__(256) void k_gather_rotate_mod_pl(const float* __res
 template <int FMT>
 __global__ __launch_bounds__(256) void k_gather_rotate_mod_q3(const float* __restrict__ xn, const int* __restrict__ esrc,
                                                               const int* __restrict__ edst, const float* __restrict__ frame,
-                                                              const float* __restrict__ rad, unsigned short* __restrict__ y1, long ne, float odd_sign) {
+                                                              const float* __restrict__ rad, unsigned short* __restrict__ y1, long ne, float odd_sign,
+                                                              unsigned char* __restrict__ y1o8) {
   constexpr int P = QFmt<FMT>::P, BLK = QFmt<FMT>::BLK;
+  constexpr bool X8 = QFmt<FMT>::X8;
   __shared__ __attribute__((aligned(16))) unsigned int stage[2][16][4][8 * P];   // [buffer][16-column block][row in group][q*8 + pair]
+  __shared__ __attribute__((aligned(16))) unsigned char stage8[X8 ? 2 : 1][4][X8 ? 512 : 16];   // FMT 2: [buffer][edge][the 4 O8 lines of 256 columns]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long nvb = (((ne + 3) / 4 + 7) / 8) * 8;                                 // virtual blocks = row groups, padded to the 8 XCDs
   const long per = nvb >> 3;                                                     // XCD-contiguous groups (see UMX_WAVE_LOOP_PL_XCD)
@@ -234,6 +262,12 @@ __global__ __launch_bounds__(256) void k_gather_rotate_mod_q3(const float* __res
     q_split2<FMT>(x0, x1, w);
 #pragma unroll
     for (int q = 0; q < P; ++q) d[q * 8] = w[q];
+    if constexpr (X8) {
+      const unsigned int w8 = o8_split2(x0, x1);
+      unsigned char* d8 = &stage8[buf][wave][(col >> 6) * 128 + (col & 63)];
+      *reinterpret_cast<unsigned short*>(d8) = (unsigned short)(w8 & 0xffffu);
+      *reinterpret_cast<unsigned short*>(d8 + 64) = (unsigned short)(w8 >> 16);
+    }
   };
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
@@ -248,6 +282,10 @@ __global__ __launch_bounds__(256) void k_gather_rotate_mod_q3(const float* __res
     uint4* dst = reinterpret_cast<uint4*>(gbase + (long)r * 16 * BLK);
     dst[threadIdx.x] = src[threadIdx.x];
     if (P == 3 && threadIdx.x < 128) dst[256 + threadIdx.x] = src[256 + threadIdx.x];
+    if constexpr (X8)
+      if (threadIdx.x < 128 && e0 + (threadIdx.x >> 5) < ne)                 // 4 edges x 512 B: one 16-B chunk per thread, 512 contiguous bytes per edge
+        st_stream(reinterpret_cast<uint4*>(y1o8 + (e0 + (threadIdx.x >> 5)) * (long)(XROT * 2) + r * 512) + (threadIdx.x & 31),
+                  reinterpret_cast<const uint4*>(&stage8[buf][threadIdx.x >> 5][0])[threadIdx.x & 31]);
   }
   }
 }
@@ -285,9 +323,12 @@ __global__ void k_gate_edge_fwd_pl(const float* __restrict__ hg, unsigned short*
 // planes of the 8 edges are staged in LDS in the byte order of their 2 x 8 consecutive blocks and written with coalesced
 // 16-B stores (same reason as k_gather_rotate_mod_q3).
 template <int FMT>
-__global__ __launch_bounds__(256) void k_gate_edge_fwd_q3(const float* __restrict__ hg, unsigned short* __restrict__ hid, long ne, float odd_sign) {
+__global__ __launch_bounds__(256) void k_gate_edge_fwd_q3(const float* __restrict__ hg, unsigned short* __restrict__ hid, long ne, float odd_sign,
+                                                          unsigned char* __restrict__ hido8) {
   constexpr int P = QFmt<FMT>::P, BLK = QFmt<FMT>::BLK;
+  constexpr bool X8 = QFmt<FMT>::X8;
   __shared__ __attribute__((aligned(16))) unsigned int stage[2][2][8][4][8 * P]; // [buffer][row group][16-column block][row][q*8 + pair]
+  __shared__ __attribute__((aligned(16))) unsigned char stage8[X8 ? 2 : 1][8][X8 ? 256 : 16];     // FMT 2: [buffer][edge][the 2 O8 lines of 128 columns]
   const long nvb = (ne + 7) / 8;
   for (long vb = blockIdx.x; vb < nvb; vb += gridDim.x) {                        // grid-stride over groups of 8 edges: any grid size works
   const long e0 = vb * 8;
@@ -321,7 +362,17 @@ __global__ __launch_bounds__(256) void k_gate_edge_fwd_q3(const float* __restric
     q_split2<FMT>(x[0], x[1], wa); q_split2<FMT>(x[2], x[3], wb);
 #pragma unroll
     for (int q = 0; q < P; ++q) *reinterpret_cast<uint2*>(d + q * 8) = make_uint2(wa[q], wb[q]);
+    if constexpr (X8) {
+      const unsigned int a8 = o8_split2(x[0], x[1]), b8 = o8_split2(x[2], x[3]);
+      unsigned char* d8 = &stage8[buf][le][(c >> 6) * 128 + (c & 63)];
+      *reinterpret_cast<unsigned int*>(d8) = (a8 & 0xffffu) | (b8 << 16);
+      *reinterpret_cast<unsigned int*>(d8 + 64) = (a8 >> 16) | (b8 & 0xffff0000u);
+    }
     __syncthreads();
+    if constexpr (X8)
+      if (threadIdx.x < 128 && e0 + (threadIdx.x >> 4) < ne)                 // 8 edges x 256 B: one 16-B chunk per thread
+        st_stream(reinterpret_cast<uint4*>(hido8 + (e0 + (threadIdx.x >> 4)) * (long)(ROW * 2) + r * 256) + (threadIdx.x & 15),
+                  reinterpret_cast<const uint4*>(&stage8[buf][threadIdx.x >> 4][0])[threadIdx.x & 15]);
     // per row group: 8 blocks x 128 P bytes = 64 P chunks of 16 B; 128 P chunks in all
     constexpr int CPG = 64 * P;
 #pragma unroll

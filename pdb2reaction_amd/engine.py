@@ -207,7 +207,7 @@ class Engine:
         return e, f
 
     def precision_mode(self) -> str:
-        """The arithmetic the engine is in now ("bf16x3" | "split-f16" | "split-bf16" | "fp32"): what "auto" resolved to."""
+        """The arithmetic the engine is in now ("bf16x3" | "split-f16" | "split-bf16" | "f16x2b8" | "fp32"): what "auto" resolved to."""
         return self.lib.umx_precision_mode(self._h).decode()
 
     def take_range_error(self) -> bool:

@@ -32,7 +32,7 @@ def gold():
     return load_golden("c3c4_n2000")
 
 
-@pytest.mark.parametrize("mode", ["split", "split-bf16", "bf16x3", "fp32"])
+@pytest.mark.parametrize("mode", ["split", "split-bf16", "bf16x3", "f16x2b8", "fp32"])
 def test_c3_energy_and_forces_against_f64_oracle(weights, gold, mode, monkeypatch):
     """The headline configuration: E and F of 2000-atom images vs the float64 oracle, every precision mode (split = fp16 forward
     planes, the default; split-bf16 = three bf16 forward planes; fp32 = fp32 MFMA everywhere)."""
@@ -199,7 +199,7 @@ def test_c2_c3_gsm_driver_at_baseline_sizes(n_atoms, n_img, gold):
     calc.close()
 
 
-@pytest.mark.parametrize("mode", ["auto", "split", "fp32"])
+@pytest.mark.parametrize("mode", ["auto", "split", "f16x2b8", "fp32"])
 def test_c5_energy_and_forces_against_f64_oracle(weights, mode, monkeypatch):
     """BASELINE configs[4]: a 20 000-atom image (1.6 M directed edges; one image needs more workspace than the default cap -- the
     engine then takes the full budget).  E and F against the float64 oracle (tools/make_golden_c5.py).
@@ -222,7 +222,7 @@ def test_c5_energy_and_forces_against_f64_oracle(weights, mode, monkeypatch):
     try:
         eng.load_weights(weights)
         eng.set_system(g["z"])
-        assert eng.precision_mode() == {"auto": "bf16x3", "split": "split-f16", "fp32": "fp32"}[mode]
+        assert eng.precision_mode() == {"auto": "bf16x3", "split": "split-f16", "f16x2b8": "f16x2b8", "fp32": "fp32"}[mode]
         e, f = eng.energy_forces(g["pos"][None])
         ne, maxdeg = eng.graph_stats()
         assert ne > 1_500_000 and maxdeg <= 300

@@ -66,7 +66,7 @@ def test_c3_energy_golden(engine):
     assert np.abs(e - g["c3_energy"]).max() <= TOL_E
 
 
-@pytest.mark.parametrize("mode", ["fp32", "split", "split-bf16", "bf16x3"])
+@pytest.mark.parametrize("mode", ["fp32", "split", "split-bf16", "bf16x3", "f16x2b8"])
 def test_precision_modes(weights, oracle, mode, monkeypatch):
     """UMX_PRECISION: fp32-MFMA everywhere, or split planes on the large SO(2)/radial GEMMs (LDS-DMA GEMM; forward: two fp16 activation
     planes x three exact fp16 weight planes, 4 products -- or three bf16 planes, 6 products; reverse: two bf16 planes, 3 products --
@@ -96,6 +96,8 @@ def switch_case(oracle):
     {"UMX_FUSED_RADIAL": "0"},                                   # separate radial launches; fc3 operand written by k_ln_silu_fwd_pl<3, true>
     {"UMX_FUSED_RADIAL": "0", "UMX_PRECISION": "split"},         # ... by k_ln_silu_fwd_pl<2, true>
     {"UMX_FUSED_RADIAL": "0", "UMX_PRECISION": "split-bf16"},
+    {"UMX_FUSED_RADIAL": "0", "UMX_PRECISION": "f16x2b8"},       # ... plus the 8-bit planes by direct stores
+    {"UMX_Q3WIDE": "0", "UMX_PRECISION": "f16x2b8"},             # 256x128 tiles of the fp16 x 2 + bf8 GEMM
     {"UMX_Q3": "0"},                                             # dev layout: bf16 PL planes + 256x128 tiles in both passes
     {"UMX_Q3": "0", "UMX_PRECISION": "split"},                   # ("split" falls back to bf16 forward planes there)
     {"UMX_Q3WIDE": "0"}, {"UMX_Q3WIDE": "0", "UMX_PRECISION": "split"},
@@ -493,7 +495,7 @@ def test_device_pointer_entry_is_stream_ordered(engine):
         assert np.array_equal(out[2], e_ref2) and np.array_equal(out[3], f_ref2.astype(np.float64))
 
 
-@pytest.mark.parametrize("mode", ["fp32", "split", "split-bf16", "bf16x3"])
+@pytest.mark.parametrize("mode", ["fp32", "split", "split-bf16", "bf16x3", "f16x2b8"])
 def test_stage_by_stage_against_staged_oracle(weights, mode, monkeypatch):
     """Every intermediate of the forward AND of the analytic reverse pass vs oracle/staged.py, in both precision modes
     (the split-bf16 path keeps its GEMM operands as bf16 planes, so fewer fp32 intermediates exist there)."""
@@ -529,7 +531,7 @@ def test_stage_by_stage_against_staged_oracle(weights, mode, monkeypatch):
             names += [f"{s}.{i}" for s in per_layer]
         # reverse pass: 16-bit products (2 x 2 bf16 planes) ~1e-5 relative per GEMM; bf16x3 (3 x 3 planes, 24-bit products) is held to
         # the fp32 mode's bound
-        tol = 2e-5 if mode in ("fp32", "bf16x3") else 1e-4
+        tol = 2e-5 if mode in ("fp32", "bf16x3", "f16x2b8") else 1e-4
         for nm in names:
             a = engine.debug_fetch(nm)
             r = t[nm].reshape(-1)

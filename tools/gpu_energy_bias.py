@@ -15,8 +15,11 @@ from pdb2reaction_amd.engine import Engine  # noqa: E402
 GOLD = os.path.join("tests", "golden")
 VARIANTS = [
     {"UMX_PRECISION": "bf16x3"}, {"UMX_PRECISION": "bf16x3", "UMX_ALT_ROWS": "0"}, {"UMX_PRECISION": "split"}, {"UMX_PRECISION": "split", "UMX_ALT_ROWS": "0"},
-    {"UMX_PRECISION": "fp32"},
+    {"UMX_PRECISION": "fp32"}, {"UMX_PRECISION": "f16x2b8"}, {"UMX_PRECISION": "f16x2b8", "UMX_ALT_ROWS": "0"},
 ]
+VARIANTS += [{"UMX_PRECISION": "split", "UMX_F16_PRODUCTS": "3"}]       # two-plane fp16 weights: what a rounding of the WEIGHTS does to the energy
+if os.environ.get("BIAS_ONLY"):          # e.g. BIAS_ONLY=f16x2b8: only that mode's variants
+    VARIANTS = [v for v in VARIANTS if v["UMX_PRECISION"] in os.environ["BIAS_ONLY"].split(",")]
 which = sys.argv[1:] or ["c3", "c5"]
 w = W.make_synthetic_weights(0)
 for name in which:
@@ -26,7 +29,7 @@ for name in which:
     e_ref = g["energy"] if name == "c5" else g["c3_energy"]
     f_ref = g["forces"][None] if name == "c5" else g["c3_forces"]
     for env in VARIANTS:
-        for k in ("UMX_PRECISION", "UMX_NODE_F64", "UMX_DEG_SPLIT", "UMX_ALT_ROWS"):
+        for k in ("UMX_PRECISION", "UMX_NODE_F64", "UMX_DEG_SPLIT", "UMX_ALT_ROWS", "UMX_F16_PRODUCTS"):
             os.environ.pop(k, None)
         os.environ.update(env)
         eng = Engine(0)

@@ -21,6 +21,7 @@ Rank 0 prints ONE JSON line (contract in the task statement) carrying
   both passes) are emulation overhead, reported separately as `mfma_pipe_util` (executed FLOPs / peak).
   `traffic` (HBM bytes per launch from rocprofv3 PMC passes) is only emitted when the committed summary under profiles/
   was measured on EXACTLY this build (source digest compiled into libumx.so), else null + `traffic_source` says why;
+* `f16x2b8_mode`: the same workload in the other >= 24-bit mode (opt-in `UMX_PRECISION=f16x2b8`, NOTES.md section 10);
 * `fast_mode`: the same workload in the opt-in fast mode (`UMX_PRECISION=split`: 22-23-bit forward activations, 16-bit reverse
   products -- narrower than float32, hence not the headline) and `fp32_mode`: on the fp32 MFMA (`UMX_PRECISION=fp32`), a few
   steps each, timed the same way (N=1 only);
@@ -380,6 +381,11 @@ def main():
             # reference's float32, so it is NOT the headline; tolerances are met with margin (tests/test_gpu_baseline_sizes.py)
             out["fast_mode"] = side_mode("split", args.fp32_steps, args.fp32_warmup, "split_bf16", PEAK_BF16_MFMA_TFLOPS,
                                          "f16-split (fwd 2 x 3 fp16 planes / 4 products, reverse 2 x 2 bf16 planes / 3 products): narrower than float32")
+        if world == 1 and not args.no_fast_mode and mode == "bf16x3":
+            # a second >= 24-bit mode (opt-in): the forward GEMMs' two 2^-22-order plane products on the block-scaled bf8 matrix instruction
+            out["f16x2b8_mode"] = side_mode("f16x2b8", args.fp32_steps, args.fp32_warmup, "split_bf16", PEAK_BF16_MFMA_TFLOPS,
+                                            "forward: 2 fp16 + 2 bf8 activation planes x 3 exact fp16 + 2 bf8 weight planes, 4 fp16 products + 2 bf8 products "
+                                            "(>= 24-bit products in 5 instruction slots); reverse as bf16x3")
         if world == 1 and split and not args.no_fp32_mode:
             # every GEMM on v_mfma_f32_32x32x2_f32: the same float32 products as the headline mode's, on the fp32 matrix pipe
             out["fp32_mode"] = side_mode("fp32", args.fp32_steps, args.fp32_warmup, "fp32", PEAK_FP32_MFMA_TFLOPS, "f32 (all GEMMs on v_mfma_f32_32x32x2_f32)")

@@ -40,6 +40,8 @@ def test_bench_json_line_contract():
     assert f["value"] > 0 and f["dtype"].startswith("f32") and 0.0 < f["gemm_frac"] < 1.0 and f["steps"] >= 5 and f["warmup"] >= 2
     fm = d["fast_mode"]                                                              # the opt-in narrower mode, reported beside, never as `value`
     assert fm["value"] > 0 and fm["precision_mode"] == "split-f16" and "narrower" in fm["dtype"]
+    x8 = d["f16x2b8_mode"]                                                           # the other >= 24-bit mode (opt-in), beside
+    assert x8["value"] > 0 and x8["precision_mode"] == "f16x2b8" and "bf8" in x8["dtype"]
     g = d["gsm"]                                                                     # the real driver on the fully grown string
     assert "error" not in g, g
     for leg in ("climb_off", "climb_on"):

@@ -138,7 +138,7 @@ class Engine:
         self.device = int(device)
         self.natoms = 0
         self.precision = precision
-        self.widened = False            # True once an fp16 range violation moved this engine to split-bf16
+        self.widened = False            # True once an fp16 range violation moved this engine to bf16 forward planes (split-bf16 / bf16x3)
         self._blob = None
         self._system = None
         if precision is not None:
@@ -223,16 +223,19 @@ class Engine:
         """Public form of the fp16 -> bf16 forward-plane switch, for callers that decide it collectively (parallel.py, hessian.py)."""
         return self._widen(why)
 
+    _WIDER = {"split-f16": "split-bf16", "f16x2b8": "bf16x3"}       # the mode with the same reverse pass and bf16 (float32-range) forward planes
+
     def _widen(self, why: str) -> bool:
-        """Move an engine whose forward operands are fp16 planes to UMX_PRECISION=split-bf16 (once); False when that is not the
-        arithmetic in use (or UMX_NO_WIDEN=1)."""
-        if self.widened or self._blob is None or self._system is None or self.precision_mode() != "split-f16":
+        """Move an engine whose forward operands are fp16 planes (split-f16, f16x2b8) to the mode with bf16 forward planes (split-bf16,
+        bf16x3) -- once; False when the engine is not in such a mode (or UMX_NO_WIDEN=1)."""
+        wider = self._WIDER.get(self.precision_mode())
+        if self.widened or self._blob is None or self._system is None or wider is None:
             return False
         if os.environ.get("UMX_NO_WIDEN", "0") == "1":
             return False
-        warnings.warn(f"pdb2reaction_amd: {why} -- re-loading the engine with bf16 forward planes (UMX_PRECISION=split-bf16)", RuntimeWarning)
-        self._chk(self.lib.umx_set_precision(self._h, b"split-bf16"), "umx_set_precision")
-        self.precision, self.widened = "split-bf16", True
+        warnings.warn(f"pdb2reaction_amd: {why} -- re-loading the engine with bf16 forward planes (UMX_PRECISION={wider})", RuntimeWarning)
+        self._chk(self.lib.umx_set_precision(self._h, wider.encode()), "umx_set_precision")
+        self.precision, self.widened = wider, True
         self.load_weights(self._blob)
         z, charge, spin, task, radius, max_neigh = self._system
         self.set_system(z, charge, spin, task, radius, max_neigh)

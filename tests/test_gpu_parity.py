@@ -127,8 +127,9 @@ def test_documented_switches_hold_the_tolerances(weights, switch_case, env, monk
         eng.close()
 
 
-def test_fp16_operand_range_is_guarded(weights, monkeypatch):
-    """The default mode keeps the forward GEMM operands as fp16 planes of 16 x (activation): an activation beyond +-4094 converts to
+@pytest.mark.parametrize("mode,wider", [("split", "split-bf16"), ("f16x2b8", "bf16x3")])
+def test_fp16_operand_range_is_guarded(weights, mode, wider, monkeypatch):
+    """The modes with fp16 forward planes (split, f16x2b8) keep the forward GEMM operands as fp16 planes of 16 x (activation): an activation beyond +-4094 converts to
     inf, the GEMM output to NaN and the host-buffer entry refuses the result (UMX_ERR_RANGE) instead of returning it.  The binding
     then re-loads the SAME engine with bf16 forward planes (float32's range; still the HIP path) and evaluates again -- the answer
     is bitwise what an engine created in split-bf16 gives for the same (absurd) weights."""
@@ -138,7 +139,7 @@ def test_fp16_operand_range_is_guarded(weights, monkeypatch):
     key = "blocks.0.edge_wise.so2_conv_1.rad_func.fc3"
     big[key + ".weight"] = (np.asarray(weights[key + ".weight"]) * 3e4).astype(np.float32)
     z, imgs, _ = synth.make_images(40, 1, seed=2)
-    monkeypatch.setenv("UMX_PRECISION", "split")
+    monkeypatch.setenv("UMX_PRECISION", mode)
     monkeypatch.setenv("UMX_NO_WIDEN", "1")
     eng = Engine(0)
     try:
@@ -150,7 +151,7 @@ def test_fp16_operand_range_is_guarded(weights, monkeypatch):
     finally:
         eng.close()
     monkeypatch.delenv("UMX_NO_WIDEN")
-    ref = Engine(0, precision="split-bf16")
+    ref = Engine(0, precision=wider)
     eng = Engine(0)
     try:
         ref.load_weights(big)
@@ -159,7 +160,7 @@ def test_fp16_operand_range_is_guarded(weights, monkeypatch):
         assert np.isfinite(e0).all() and np.isfinite(f0).all()
         eng.load_weights(big)
         eng.set_system(z)
-        with pytest.warns(RuntimeWarning, match="split-bf16"):
+        with pytest.warns(RuntimeWarning, match=wider):
             e, f = eng.energy_forces(imgs)
         assert eng.widened and np.array_equal(e, e0) and np.array_equal(f, f0)
         e2, f2 = eng.energy_forces(imgs)                       # stays widened, no second warning path

@@ -67,6 +67,158 @@ __global__ void k_split_o8(const float* __restrict__ src, long rows, long ld, in
   d[0] = (unsigned char)(pk & 0xff); d[64] = (unsigned char)((pk >> 8) & 0xff);
 }
 
+
+// ---- experiment (round 4, NOTES.md section 10): the A operand as plain fp32 (4 B per element instead of the 6 B of three bf16 planes), split into
+// its three bf16 planes IN REGISTERS by the GEMM (truncating split: x = p0 + p1 + p2 exactly, 8 + 8 + 8 bits) -- 11 VALU ops per two values.
+// "QF" layout of A: blocks of 4 rows x 16 columns fp32 = 256 B; element (r, k) -> ((r/4) * (cols/16) + k/16) * 256 + (r%4) * 64 + (k%16) * 4.
+// LDS image: the DMA's flat chunk order, the 16-B piece index of a row XOR-ed with (row group & 3) (conflict-free ds_read_b128).
+__global__ void k_copy_qf(const float* __restrict__ src, long rows, long ld, int K, unsigned char* __restrict__ dst) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * K) return;
+  const long r = i / K; const int k = (int)(i % K);
+  *reinterpret_cast<float*>(dst + ((r / 4) * (K / 16) + k / 16) * 256 + (r % 4) * 64 + (k % 16) * 4) = src[r * ld + k];
+}
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+#ifndef QF_TRUNC
+#define QF_TRUNC 0
+#endif
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned int& p0, unsigned int& p1, unsigned int& p2) {
+#if QF_TRUNC
+  const unsigned int u0 = __builtin_bit_cast(unsigned int, x0), u1 = __builtin_bit_cast(unsigned int, x1);
+  p0 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+  const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = x1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
+  const unsigned int v0 = __builtin_bit_cast(unsigned int, r0), v1 = __builtin_bit_cast(unsigned int, r1);
+  p1 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+  const float s0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u), s1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
+  p2 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned int, s1), __builtin_bit_cast(unsigned int, s0), 0x07060302u);
+#else
+  // round-to-nearest planes: exactly what the producers' q_split2<0> writes today (bitwise the same GEMM inputs), with ONE v_cvt_pk_bf16_f32
+  // per pair and plane: 11 VALU ops per two values
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  p0 = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{x0, x1}, bf16x2_t));
+  const float r0 = x0 - __builtin_bit_cast(float, p0 << 16), r1 = x1 - __builtin_bit_cast(float, p0 & 0xffff0000u);
+  p1 = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{r0, r1}, bf16x2_t));
+  const float s0 = r0 - __builtin_bit_cast(float, p1 << 16), s1 = r1 - __builtin_bit_cast(float, p1 & 0xffff0000u);
+  p2 = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{s0, s1}, bf16x2_t));
+#endif
+}
+template <int WIDE, int S>
+__global__ __launch_bounds__(512, 1) void gemm_qf_kernel(const GemmPL p) {
+  constexpr int PB = 3, BM = 256, BN = WIDE ? 256 : 128;
+  constexpr int BLKB = 128 * PB, CPBB = 8 * PB;
+  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 32 * PB, STAGE = A_BYTES + B_BYTES;
+  constexpr int TNW = WIDE ? 4 : 2;
+  constexpr int JA = A_BYTES / 8192, JBF = B_BYTES / 8192, BHR = (B_BYTES % 8192) ? 1 : 0;
+  static_assert(S * STAGE <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[S * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int nN = (p.N + BN - 1) / BN, nM = (p.M + BM - 1) / BM;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int mt = (slot / nN) * 8 + xcd, nt = slot % nN;
+  if (mt >= nM) return;
+  const unsigned char* Ab = reinterpret_cast<const unsigned char*>(p.Apl);
+  const unsigned char* Bb = reinterpret_cast<const unsigned char*>(p.Bpl);
+  const long a_blocks = p.lda / 16, b_blocks = p.K / 16;
+  const long gA = ((long)p.M + 3) / 4;
+  const int gN = p.N / 4;
+  long a_off[JA], b_off[JBF + BHR];
+#pragma unroll
+  for (int j = 0; j < JA; ++j) {
+    const int c = tid + 512 * j, g = c >> 4, s = c & 15;
+    long grp = (long)mt * (BM / 4) + g;
+    if (grp >= gA) grp = gA - 1;
+    a_off[j] = grp * a_blocks * 256 + (s >> 2) * 64 + (((s & 3) ^ (g & 3)) * 16);
+  }
+#pragma unroll
+  for (int j = 0; j < JBF + BHR; ++j) {
+    const int c = tid + 512 * j, g = (c / CPBB) % (BN / 4), s = c % CPBB;
+    int cg = nt * (BN / 4) + g; if (cg >= gN) cg = gN - 1;
+    b_off[j] = (long)cg * b_blocks * BLKB + (s ^ q_swz<PB>(g)) * 16;
+  }
+  const int piece = __builtin_amdgcn_readfirstlane(wave * 1024);
+  const bool b_tail = __builtin_amdgcn_readfirstlane(wave < 4 ? 1 : 0) != 0;
+  f32x16 acc[2][TNW];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TNW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int a_ad[2][2], b_ad[TNW][PB];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int row = wm * 64 + t * 32 + l31, g = row >> 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a_ad[t][i] = g * 256 + (row & 3) * 64 + (((h * 2 + i) ^ (g & 3)) * 16);
+  }
+#pragma unroll
+  for (int t = 0; t < TNW; ++t) {
+    const int row = wn * (32 * TNW) + t * 32 + l31;
+#pragma unroll
+    for (int q = 0; q < PB; ++q) b_ad[t][q] = A_BYTES + q_row_off<PB>(row) + ((q * 2 + h) ^ q_swz<PB>(row >> 2)) * 16;
+  }
+  const int nk = p.K / 16;
+  constexpr int TAG = 77000 + S * 10 + WIDE;
+  constexpr int GI = JA + JBF;
+#pragma unroll
+  for (int t = 0; t < S - 1; ++t)
+    if (t < nk) q3_issue<JA, JBF, BHR, A_BYTES, TAG>(Ab, Bb, ring + t * STAGE, a_off, b_off, (long)t * 256, (long)t * BLKB, piece, b_tail);
+  int st_cur = 0, st_nxt = S - 1;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (S == 2 || kt + S - 2 >= nk) wait_vmcnt<0>();
+    else if (BHR != 0 && b_tail) wait_vmcnt<(S - 2) * (GI + 1)>();
+    else wait_vmcnt<(S - 2) * GI>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + S - 1 < nk) q3_issue<JA, JBF, BHR, A_BYTES, TAG>(Ab, Bb, ring + st_nxt * STAGE, a_off, b_off, (long)(kt + S - 1) * 256, (long)(kt + S - 1) * BLKB, piece, b_tail);
+    const unsigned char* sb = ring + st_cur * STAGE;
+    st_cur = st_cur + 1 == S ? 0 : st_cur + 1;
+    st_nxt = st_nxt + 1 == S ? 0 : st_nxt + 1;
+    bf16x8_t a[2][3], b[TNW][PB];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(sb + a_ad[t][0]), hi = *reinterpret_cast<const f32x4_t*>(sb + a_ad[t][1]);
+      unsigned int w[3][4];
+      split3_pair(lo[0], lo[1], w[0][0], w[1][0], w[2][0]); split3_pair(lo[2], lo[3], w[0][1], w[1][1], w[2][1]);
+      split3_pair(hi[0], hi[1], w[0][2], w[1][2], w[2][2]); split3_pair(hi[2], hi[3], w[0][3], w[1][3], w[2][3]);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { const u32x4_t v{w[q][0], w[q][1], w[q][2], w[q][3]}; a[t][q] = __builtin_bit_cast(bf16x8_t, v); }
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q)
+#pragma unroll
+      for (int t = 0; t < TNW; ++t) b[t][q] = *reinterpret_cast<const bf16x8_t*>(sb + b_ad[t][q]);
+#pragma unroll
+    for (int ord = 4; ord >= 0; --ord)
+#pragma unroll
+      for (int qa = 0; qa < 3; ++qa) {
+        const int qb = ord - qa;
+        if (qb < 0 || qb >= PB || qa + qb >= 3) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][qa], b[j][qb], acc[i][j], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) {
+      const int col = nt * BN + wn * (32 * TNW) + j * 32 + l31;
+      const long row0 = (long)mt * BM + wm * 64 + i * 32 + 4 * h;
+      float* c = p.Cp + row0 * p.ldc + col;
+      if (col < p.N)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          if (row0 + dr < p.M) c[(long)dr * p.ldc] = acc[i][j][r];
+        }
+    }
+}
+
 // accuracy + speed of the fp16 two-plane forms against the bf16 three-plane form, with a float64 host reference on the first rows.
 // Row r of A is scaled by 2^-(r % 28) when `ragged` to put the low planes into the half subnormal range.
 static int f16_mode(long M, int N, int K) {
@@ -124,6 +276,34 @@ static int f16_mode(long M, int N, int K) {
     report("fp32 MFMA", timeit([&] { hipLaunchKernelGGL((umx_gemm_kernel<A_PLAIN, 0, E_BIAS>), gf, dim3(256), 0, 0, pf); }));
     CK(hipMemset(C, 0, M * (long)N * 4));
     report("Q3 bf16 x3 planes, 6 products", timeit([&] { hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1>), gw, dim3(512), 0, 0, g3); }));
+    {
+      unsigned char* Aqf; CK(hipMalloc(&Aqf, (size_t)Mp * K * 4)); CK(hipMemset(Aqf, 0, (size_t)Mp * K * 4));
+      hipLaunchKernelGGL(k_copy_qf, dim3((unsigned)((M * K + 255) / 256)), dim3(256), 0, 0, A, M, (long)K, K, Aqf);
+      CK(hipDeviceSynchronize());
+      GemmPL gf = g3; gf.Apl = reinterpret_cast<const unsigned short*>(Aqf); gf.lda = K;
+      CK(hipMemset(C, 0, M * (long)N * 4));
+      report("A fp32 split in registers, 6 products", timeit([&] { hipLaunchKernelGGL((gemm_qf_kernel<1, 2>), gw, dim3(512), 0, 0, gf); }));
+      {   // bit for bit the plane form?  (library kernels: umx_gemm_q_kernel with AF = 1 against AF = 0, wide and narrow)
+        std::vector<float> c0((size_t)4096 * N), c1((size_t)4096 * N);
+        auto cmp = [&](const char* nm) { CK(hipMemcpy(c1.data(), C, c1.size() * 4, hipMemcpyDeviceToHost)); size_t nd = 0; for (size_t i = 0; i < c0.size(); ++i) nd += std::memcmp(&c0[i], &c1[i], 4) != 0; printf("         %-44s differing from the plane form in %zu of %zu values\n", nm, nd, c0.size()); };
+        CK(hipMemset(C, 0, M * (long)N * 4)); hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1>), gw, dim3(512), 0, 0, g3); CK(hipDeviceSynchronize());
+        CK(hipMemcpy(c0.data(), C, c0.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemset(C, 0, M * (long)N * 4)); hipLaunchKernelGGL((gemm_qf_kernel<1, 2>), gw, dim3(512), 0, 0, gf); CK(hipDeviceSynchronize()); cmp("bench kernel gemm_qf_kernel<1, 2>");
+        CK(hipMemset(C, 0, M * (long)N * 4)); GemmPL gl = gf; gl.lda = 3L * K;      // (the library kernels keep lda = 3 x columns for every six-product form)
+        hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 3, 2, 0, 6, 3, 0, 1>), gw, dim3(512), 0, 0, gl); CK(hipDeviceSynchronize()); cmp("library kernel AF = 1, 256x256");
+        const dim3 gn2((unsigned)(((nm + 7) / 8) * 8 * ((N + 127) / 128)));
+        CK(hipMemset(C, 0, M * (long)N * 4)); hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0, 3, 2, 0, 6, 3, 0, 1>), gn2, dim3(512), 0, 0, gl); CK(hipDeviceSynchronize()); cmp("library kernel AF = 1, 256x128");
+        CK(hipMemset(C, 0, M * (long)N * 4)); hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0>), gn2, dim3(512), 0, 0, g3); CK(hipDeviceSynchronize()); cmp("library kernel planes, 256x128");
+      }
+      CK(hipMemset(C, 0, M * (long)N * 4));
+      report("... ring 3", timeit([&] { hipLaunchKernelGGL((gemm_qf_kernel<1, 3>), gw, dim3(512), 0, 0, gf); }));
+      const dim3 gn((unsigned)(((nm + 7) / 8) * 8 * ((N + 127) / 128)));
+      CK(hipMemset(C, 0, M * (long)N * 4));
+      report("... 256x128 tiles", timeit([&] { hipLaunchKernelGGL((gemm_qf_kernel<0, 2>), gn, dim3(512), 0, 0, gf); }));
+      CK(hipMemset(C, 0, M * (long)N * 4));
+      report("Q3 bf16 x3, 256x128 tiles", timeit([&] { hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0>), gn, dim3(512), 0, 0, g3); }));
+      CK(hipFree(Aqf));
+    }
     CK(hipMemset(C, 0, M * (long)N * 4));
     report("Q2 f16 x2 planes, 4 products", timeit([&] { hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 2, 2, 1, 4, 2>), gw, dim3(512), 0, 0, g2); }));
     if (K % 64 == 0) {

@@ -80,7 +80,10 @@ struct umx_engine {
   int rev_planes = 2;              // bf16 planes of the REVERSE-pass operands: 2 (3 products, 16-bit) or 3 (6 products, 24-bit: UMX_PRECISION=bf16x3)
   int fwd_fmt = 1;                 // forward operand format (QFmt, umx_kernels_pl.h): 1 = two fp16 planes (UMX_PRECISION=split), 0 = three bf16 planes (split-bf16),
                                    // 2 = two fp16 planes + two 8-bit planes (UMX_PRECISION=f16x2b8: 24-bit products, the third-plane terms on the bf8 matrix instruction)
+                                   // 3 = plain float32 quad-row blocks, split into three bf16 planes by the GEMM in registers (the bf16 forward planes since round 4)
   std::map<const float*, const unsigned char*> planes8;   // fwd_fmt 2: the 8-bit planes ("O8" layout, umx_gemm_q.h) of a weight
+  bool a_f32 = true;               // UMX_A_F32=0: the A operands of the bf16-plane GEMMs as three pre-split bf16 planes (6 B per element; rounds 2-3) instead of float32
+  bool rev_qf = false;             // derived at load: reverse quad-row operands (g_msg, g_hg) as float32 blocks (bf16x3, quad-row reverse layout, a_f32)
   std::string precision;           // umx_set_precision: overrides UMX_PRECISION when non-empty
   bool node_ctx = false;           // set around the node-level launches (NodeCtx): only those take the float64-accumulating kernel
   bool node_f64_on = true;         // UMX_NODE_F64=0: node-level linears (atom-wise SO(3) linears, scalar MLP, readout and their transposes) on the
@@ -314,7 +317,10 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
     const int bnq = wq ? (cplx ? 128 : 256) : (cplx ? 64 : 128);
     const long nNq = (N + bnq - 1) / bnq;
     dim3 gq((unsigned)(((nM + 7) / 8) * 8 * nNq));
-    if (cplx) { if (wq) hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<1, 0>), gq, block, 0, eng->stream, q); }
+    if (eng->rev_qf) {         // A = float32 blocks, split in registers (umx_gemm_q.h, AF)
+      if (cplx) { if (wq) hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1, 3, 2, 0, 6, 3, 0, 1>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<1, 0, 3, 2, 0, 6, 3, 0, 1>), gq, block, 0, eng->stream, q); }
+      else      { if (wq) hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 3, 2, 0, 6, 3, 0, 1>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0, 3, 2, 0, 6, 3, 0, 1>), gq, block, 0, eng->stream, q); }
+    } else if (cplx) { if (wq) hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<1, 0>), gq, block, 0, eng->stream, q); }
     else      { if (wq) hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0>), gq, block, 0, eng->stream, q); }
   } else if (fwd && eng->q3) {
     // forward operands in the quad-row layout: 256x256 tiles where N fills them, else 256x128 (umx_gemm_q.h)
@@ -351,6 +357,13 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
       if (cplx) { if (wq) UMX_QH(1, 1); else UMX_QH(1, 0); }
       else      { if (wq) UMX_QH(0, 1); else UMX_QH(0, 0); }
 #undef UMX_QH
+    } else if (eng->fwd_fmt == 3) {
+      // A = float32 quad-row blocks, split into the three bf16 planes in registers; weights as three bf16 planes (umx_gemm_q.h, AF = 1)
+#define UMX_QF(CP, WD) do { if (S == 3) hipLaunchKernelGGL((umx_gemm_q_kernel<CP, WD, 3, 3, 0, 6, 3, 0, 1>), gq, block, 0, eng->stream, q);   \
+                            else hipLaunchKernelGGL((umx_gemm_q_kernel<CP, WD, 3, 2, 0, 6, 3, 0, 1>), gq, block, 0, eng->stream, q); } while (0)
+      if (cplx) { if (wq) UMX_QF(1, 1); else UMX_QF(1, 0); }
+      else      { if (wq) UMX_QF(0, 1); else UMX_QF(0, 0); }
+#undef UMX_QF
     } else if (cplx) {
       if (wq) { if (S == 3) hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1, 3, 3>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1>), gq, block, 0, eng->stream, q); }
       else    { if (S == 3) hipLaunchKernelGGL((umx_gemm_q_kernel<1, 0, 3, 3>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<1, 0>), gq, block, 0, eng->stream, q); }
@@ -417,7 +430,7 @@ struct Bump {
 };
 
 // workspace mode: 0 = fp32 path, else (planes of the forward operands) + 16 when the reverse operands have three planes
-inline int ws_mode(const umx_engine* eng) { return !eng->pl ? 0 : ((eng->q3 && eng->fwd_fmt == 1) ? 2 : 3) + (eng->rev_planes == 3 ? 16 : 0); }   // (fwd_fmt 2: two half planes + two byte planes = 3 x 2 bytes)
+inline int ws_mode(const umx_engine* eng) { return !eng->pl ? 0 : ((eng->q3 && (eng->fwd_fmt == 1 || eng->fwd_fmt == 3)) ? 2 : 3) + (eng->rev_planes == 3 ? 16 : 0) + (eng->rev_qf ? 32 : 0); }   // (fwd_fmt 2: two half planes + two byte planes = 3 x 2 bytes)
 
 // Workspace layout.  PERSISTENT buffers live from the forward to the reverse pass of an evaluation (node-level state, the graph, and the
 // per-edge activations of all four layers: ~72 KB per directed edge); TRANSIENT buffers are the operands between a producer and a GEMM
@@ -454,10 +467,11 @@ void carve_trans(Bump& b, long ne, WS& t, int pl) {
   if (pl) {
     t.gmsg = b.take<float>(ne * 3 * C);                      // only the edge-degree backward uses fp32 g_msg (E x 384)
     const long ne4 = (ne + 3) / 4 * 4;          // the quad-row (Q3) layout stores rows in groups of four
-    const long fp = pl & 15, rp = (pl & 16) ? 3 : 2;             // planes of the forward / reverse operands
+    const long fp = pl & 15, rp = (pl & 16) ? 3 : 2;             // 2-byte units per element of the forward / reverse operands
+    const long rq = (pl & 32) ? 2 : rp;                          // ... of the quad-row reverse operands (float32 blocks: 2)
     t.y1pl = b.take<unsigned short>(ne4 * XROT * fp); t.hidpl = b.take<unsigned short>(ne4 * ROW * fp);
-    t.a2pl = b.take<unsigned short>(ne4 * RH * fp); t.gmsgpl = b.take<unsigned short>(ne4 * ROW * rp);      // (ne4: the quad-row form of the bf16x3 reverse operands)
-    t.ghgpl = b.take<unsigned short>(ne4 * HG * rp); t.gradpl = b.take<unsigned short>(ne * RAD * rp);
+    t.a2pl = b.take<unsigned short>(ne4 * RH * fp); t.gmsgpl = b.take<unsigned short>(ne4 * ROW * rq);      // (ne4: the quad-row form of the bf16x3 reverse operands)
+    t.ghgpl = b.take<unsigned short>(ne4 * HG * rq); t.gradpl = b.take<unsigned short>(ne * RAD * rp);
   } else {
     t.xrot = b.take<float>(ne * XROT); t.gmsg = b.take<float>(ne * ROW);
     t.ghg = b.take<float>(ne * HG); t.grad = b.take<float>(ne * RAD);
@@ -524,7 +538,7 @@ int radial_fwd_head(umx_engine* eng, const WS& w, const RadialW& r, int slot, lo
         else if (fm == 1) hipLaunchKernelGGL((k_radial_head<3, 1, 2>), UMX_RH_ARGS, (void*)w.a2pl, ne, eng->odd_sign, a2o8);
         else hipLaunchKernelGGL((k_radial_head<3, 0, 2>), UMX_RH_ARGS, (void*)w.a2pl, ne, eng->odd_sign, a2o8);
       }
-    } else if (planes && eng->fwd_fmt == 1) UMX_RH_LAUNCH(2, w.a2pl); else if (planes) UMX_RH_LAUNCH(1, w.a2pl); else UMX_RH_LAUNCH(0, w.ra);
+    } else if (planes && eng->fwd_fmt == 1) UMX_RH_LAUNCH(2, w.a2pl); else if (planes && eng->fwd_fmt == 3) UMX_RH_LAUNCH(4, w.a2pl); else if (planes) UMX_RH_LAUNCH(1, w.a2pl); else UMX_RH_LAUNCH(0, w.ra);
 #undef UMX_RH_LAUNCH
 #undef UMX_RH_ARGS
     prof_close(eng, pr);
@@ -542,6 +556,7 @@ int radial_fwd_head(umx_engine* eng, const WS& w, const RadialW& r, int slot, lo
     if (eng->q3 && eng->fwd_fmt == 2) hipLaunchKernelGGL((k_ln_silu_fwd_pl<2, true>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne, eng->odd_sign,
                                                          reinterpret_cast<unsigned char*>(w.a2pl) + (size_t)((ne + 3) / 4 * 4) * RH * 4);
     else if (eng->q3 && eng->fwd_fmt == 1) hipLaunchKernelGGL((k_ln_silu_fwd_pl<2, true>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne, eng->odd_sign, (unsigned char*)nullptr);
+    else if (eng->q3 && eng->fwd_fmt == 3) hipLaunchKernelGGL((k_ln_silu_fwd_pl<2, true, 3>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne, eng->odd_sign, (unsigned char*)nullptr);
     else if (eng->q3) hipLaunchKernelGGL((k_ln_silu_fwd_pl<3, true>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne, eng->odd_sign, (unsigned char*)nullptr);
     else hipLaunchKernelGGL((k_ln_silu_fwd_pl<3, false>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne, eng->odd_sign, (unsigned char*)nullptr);
   } else {
@@ -713,6 +728,7 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
         if (eng->q3 && eng->fwd_fmt == 2) hipLaunchKernelGGL(k_gather_rotate_mod_q3<2>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne, eng->odd_sign,
                                                              reinterpret_cast<unsigned char*>(w.y1pl) + (size_t)((ne + 3) / 4 * 4) * XROT * 4);
         else if (eng->q3 && eng->fwd_fmt == 1) hipLaunchKernelGGL(k_gather_rotate_mod_q3<1>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne, eng->odd_sign, (unsigned char*)nullptr);
+        else if (eng->q3 && eng->fwd_fmt == 3) hipLaunchKernelGGL(k_gather_rotate_mod_q3<3>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne, eng->odd_sign, (unsigned char*)nullptr);
         else if (eng->q3) hipLaunchKernelGGL(k_gather_rotate_mod_q3<0>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne, eng->odd_sign, (unsigned char*)nullptr);
         else hipLaunchKernelGGL((k_gather_rotate_mod_pl<3, false>), dim3((nblk(ne, 4) + 7) / 8 * 8), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne, eng->odd_sign);
         HIPCHK(eng, hipGetLastError());
@@ -729,6 +745,7 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
         if (eng->q3 && eng->fwd_fmt == 2) hipLaunchKernelGGL(k_gate_edge_fwd_q3<2>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hg[i], w.hidpl, ne, eng->odd_sign,
                                                              reinterpret_cast<unsigned char*>(w.hidpl) + (size_t)((ne + 3) / 4 * 4) * ROW * 4);
         else if (eng->q3 && eng->fwd_fmt == 1) hipLaunchKernelGGL(k_gate_edge_fwd_q3<1>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hg[i], w.hidpl, ne, eng->odd_sign, (unsigned char*)nullptr);
+        else if (eng->q3 && eng->fwd_fmt == 3) hipLaunchKernelGGL(k_gate_edge_fwd_q3<3>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hg[i], w.hidpl, ne, eng->odd_sign, (unsigned char*)nullptr);
         else if (eng->q3) hipLaunchKernelGGL(k_gate_edge_fwd_q3<0>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hg[i], w.hidpl, ne, eng->odd_sign, (unsigned char*)nullptr);
         else hipLaunchKernelGGL((k_gate_edge_fwd_pl<3, false>), dim3(nblk(ne * (H / 4), 256)), B256, 0, s, w.hg[i], w.hidpl, ne, eng->odd_sign);
         HIPCHK(eng, hipGetLastError());
@@ -846,7 +863,8 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       DBG("g_xmid" + t, w.G2, nn * ROW);
       if (ne > 0 && eng->pl)
       {
-        if (eng->rev_planes == 3 && eng->q3 && eng->rev_q3) hipLaunchKernelGGL(k_rotate_back_bwd_q3, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne, eng->odd_sign);
+        if (eng->rev_qf) hipLaunchKernelGGL(k_rotate_back_bwd_q3<3>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne, eng->odd_sign);
+        else if (eng->rev_planes == 3 && eng->q3 && eng->rev_q3) hipLaunchKernelGGL(k_rotate_back_bwd_q3<0>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne, eng->odd_sign);
         else if (eng->rev_planes == 3) hipLaunchKernelGGL(k_rotate_back_bwd_pl<3>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne, eng->odd_sign);
         else hipLaunchKernelGGL(k_rotate_back_bwd_pl<2>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne, eng->odd_sign);
       }
@@ -865,7 +883,8 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
         // the radial tail of the layer ABOVE (it feeds only dE/dd) beside this HBM-bound kernel -- not right behind its fc3^T GEMM, where
         // it would run next to the node-level and SO(2) GEMMs and slow those down by as much as it hides (measured)
         if (side && i + 1 < NL) CHK(side_launch(eng->ev_stail, [=, &w]() -> int { return radial_bwd_tail(eng, w, eng->lw[i + 1].rad, i + 1, ne); }));
-        if (eng->rev_planes == 3 && eng->q3 && eng->rev_q3) hipLaunchKernelGGL(k_gate_edge_bwd_q3, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne, eng->odd_sign);
+        if (eng->rev_qf) hipLaunchKernelGGL(k_gate_edge_bwd_q3<3>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne, eng->odd_sign);
+        else if (eng->rev_planes == 3 && eng->q3 && eng->rev_q3) hipLaunchKernelGGL(k_gate_edge_bwd_q3<0>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne, eng->odd_sign);
         else if (eng->rev_planes == 3) hipLaunchKernelGGL(k_gate_edge_bwd_pl<3>, dim3(vgrid(eng, nblk(ne * (H / 4), 256))), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne, eng->odd_sign);
         else hipLaunchKernelGGL(k_gate_edge_bwd_pl<2>, dim3(vgrid(eng, nblk(ne * (H / 4), 256))), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne, eng->odd_sign);
         HIPCHK(eng, hipGetLastError());
@@ -1089,6 +1108,7 @@ int umx_create(umx_engine** out, int device_ordinal) {
   if (const char* ev = std::getenv("UMX_WS_SOFT_EDGES")) e->ws_soft_edges = std::max(1L, std::atol(ev));
   if (const char* ev = std::getenv("UMX_NODE_F64")) e->node_f64_on = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_REV_Q3")) e->rev_q3 = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("UMX_A_F32")) e->a_f32 = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_ALT_ROWS")) e->odd_sign = std::atoi(ev) != 0 ? -1.0f : 1.0f;
   if (const char* ev = std::getenv("UMX_DEG_SPLIT")) e->deg_split = std::atoi(ev) != 0;
   e->stream_cap = 512;
@@ -1302,14 +1322,16 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
     // mode whose every product, forward and reverse, carries >= 24 significant bits -- the like-for-like arithmetic.  The faster split-f16
     // (22-bit forward activations, 16-bit reverse products) meets the tolerances with margin but is narrower: an explicit choice.
     bool rev3 = false;
+    const int bf = (eng->q3 && eng->a_f32) ? 3 : 0;              // bf16-plane forward operands: float32 blocks split by the GEMM (round 4), or pre-split planes
     if (mode == "fp32") eng->pl = false;
-    else if (mode == "auto") { eng->pl = true; eng->fwd_fmt = 0; rev3 = true; }
+    else if (mode == "auto") { eng->pl = true; eng->fwd_fmt = bf; rev3 = true; }
     else if (mode == "split" || mode == "split-f16") { eng->pl = true; eng->fwd_fmt = eng->q3 ? 1 : 0; }   // (the dev layout UMX_Q3=0 has bf16 planes only)
-    else if (mode == "split-bf16") { eng->pl = true; eng->fwd_fmt = 0; }
-    else if (mode == "bf16x3" || mode == "split-exact") { eng->pl = true; eng->fwd_fmt = 0; rev3 = true; }   // 24-bit products in BOTH passes
+    else if (mode == "split-bf16") { eng->pl = true; eng->fwd_fmt = bf; }
+    else if (mode == "bf16x3" || mode == "split-exact") { eng->pl = true; eng->fwd_fmt = bf; rev3 = true; }   // 24-bit products in BOTH passes
     else if (mode == "f16x2b8") { eng->pl = true; eng->fwd_fmt = 2; rev3 = true; }   // forward: two fp16 planes + bf8 third planes (25-bit operands), reverse as bf16x3
     else return fail(eng, UMX_ERR_ARG, "UMX_PRECISION must be auto, split (= split-f16), split-bf16, bf16x3 (= split-exact), f16x2b8 or fp32");
     eng->rev_planes = (eng->pl && rev3) ? 3 : 2;
+    eng->rev_qf = eng->pl && eng->rev_planes == 3 && eng->q3 && eng->rev_q3 && eng->a_f32;
     if ((mode == "split-f16" || mode == "f16x2b8") && !eng->q3) return fail(eng, UMX_ERR_ARG, "UMX_PRECISION=split-f16 / f16x2b8 need the quad-row operand layout (UMX_Q3=1)");
     // a precision change alters the workspace carve-up: force a re-carve on the next call
     eng->cap_nodes = 0; eng->cap_edges = 0;
@@ -1393,7 +1415,7 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
     if (!fwdw) P = eng->rev_planes;
     const bool quad = (fwdw && eng->q3) || (!fwdw && rev_quad && P == 3 && eng->q3 && eng->rev_q3);
     eng->planes_q[dev] = quad;
-    if (fwdw && eng->q3 && eng->fwd_fmt >= 1) { want_planes_f16(host, dev, rows, K); return; }
+    if (fwdw && eng->q3 && (eng->fwd_fmt == 1 || eng->fwd_fmt == 2)) { want_planes_f16(host, dev, rows, K); return; }
     PlaneReq r{dev, (bw.size() + 63) & ~size_t(63)};
     bw.resize(r.off + (size_t)rows * K * P);
     for (int rr = 0; rr < rows; ++rr)
@@ -1555,7 +1577,7 @@ int umx_synchronize(umx_engine* eng) {
   if (flag) {
     HIPCHK(eng, hipMemset(eng->d_flags, 0, sizeof(int)));
     return fail(eng, UMX_ERR_RANGE, std::string("a device-pointer evaluation produced a non-finite energy") +
-                (eng->pl && eng->fwd_fmt >= 1 ? " (an activation beyond the fp16 operand range of the split-f16 / f16x2b8 forward planes: re-load with UMX_PRECISION=bf16x3 or fp32)"
+                (eng->pl && (eng->fwd_fmt == 1 || eng->fwd_fmt == 2) ? " (an activation beyond the fp16 operand range of the split-f16 / f16x2b8 forward planes: re-load with UMX_PRECISION=bf16x3 or fp32)"
                                               : " (non-finite input or an overflow in float32)"));
   }
   return UMX_OK;
@@ -1714,7 +1736,7 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
     // bit 0: set by an EARLIER evaluation through a device-pointer entry (this one has not computed an energy yet; on this stream that
     // evaluation is complete): its caller got NaN energies / forces and, most likely, derived these positions from them
     return fail(eng, UMX_ERR_RANGE, std::string("the previous device-pointer evaluation produced a non-finite energy") +
-                (eng->pl && eng->fwd_fmt >= 1 ? " (an activation beyond the fp16 operand range of the split-f16 / f16x2b8 forward planes: re-load with UMX_PRECISION=bf16x3 or fp32)"
+                (eng->pl && (eng->fwd_fmt == 1 || eng->fwd_fmt == 2) ? " (an activation beyond the fp16 operand range of the split-f16 / f16x2b8 forward planes: re-load with UMX_PRECISION=bf16x3 or fp32)"
                                               : " (non-finite input or an overflow in float32)"));
   }
   eng->last_maxdeg = img_edges[K];
@@ -1995,7 +2017,7 @@ int umx_energy_forces(umx_engine* eng, int n_images, const float* pos, double* e
     if (!std::isfinite(energy[k])) {
       (void)hipMemset(eng->d_flags, 0, sizeof(int));         // reported right here: do not fail the NEXT call for it as well
       return fail(eng, UMX_ERR_RANGE, "image " + std::to_string(k) + ": non-finite energy" +
-                  (eng->pl && eng->fwd_fmt >= 1 ? " (an activation beyond the fp16 operand range of UMX_PRECISION=split / f16x2b8: try bf16x3 or fp32)"
+                  (eng->pl && (eng->fwd_fmt == 1 || eng->fwd_fmt == 2) ? " (an activation beyond the fp16 operand range of UMX_PRECISION=split / f16x2b8: try bf16x3 or fp32)"
                                                 : " (an overflow in float32)"));
     }
   return UMX_OK;

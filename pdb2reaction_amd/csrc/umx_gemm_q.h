@@ -97,6 +97,28 @@ __device__ __forceinline__ i32x8_t q8_frag(const unsigned char* sb, int ad0, int
   return i32x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+// ---- AF = 1: the A operand as plain float32, split into its three bf16 planes IN REGISTERS (round 4) ------------------------------------
+// "QF" layout of A[rows][cols]: blocks of 4 rows x 16 columns fp32 = 256 B (the block geometry of the two-plane half format):
+//   element (r, k) -> byte ((r/4) * (cols/16) + k/16) * 256 + (r%4) * 64 + (k%16) * 4
+// LDS image: the DMA's flat chunk order with the 16-B piece index of a row XOR-ed with (row group & 3) -- conflict-free ds_read_b128.
+// The lane's 8 k-values of a fragment are two 16-B pieces; qf_split2 turns a pair of floats into the three packed bf16 dwords with ONE
+// v_cvt_pk_bf16_f32 per plane (11 VALU ops per pair: 88 per k-tile and wave beside 48 MFMAs) -- round to nearest, bit for bit the planes
+// the producers' q_split2<0> wrote, so C is bitwise what the plane form gives.  Why: 4 B instead of 6 B per A element in HBM (producer
+// write + GEMM read), 16 KB instead of 24 KB per k-tile through L2->LDS and the LDS read ports; csrc/gemm_bench.hip f16: 0.88-0.93 of the
+// plane form's time on 256 x 256 tiles, the same on 256 x 128 tiles.  (A truncating split is no cheaper and gives every plane the sign
+// of x -- the dropped terms would then be one-sided.)  The weights stay pre-split planes: their fragments are twice as many per wave.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4q_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void qf_split2(float x0, float x1, unsigned int& p0, unsigned int& p1, unsigned int& p2) {
+  p0 = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{x0, x1}, bf16x2_t));
+  const float r0 = x0 - __builtin_bit_cast(float, p0 << 16), r1 = x1 - __builtin_bit_cast(float, p0 & 0xffff0000u);
+  p1 = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{r0, r1}, bf16x2_t));
+  const float s0 = r0 - __builtin_bit_cast(float, p1 << 16), s1 = r1 - __builtin_bit_cast(float, p1 & 0xffff0000u);
+  p2 = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{s0, s1}, bf16x2_t));
+}
+
 // which plane products A_qa . B_qb a kernel accumulates:
 //   bf16, 3 x 3 planes, 6 products: qa + qb < 3 (everything down to 2^-16 of the leading term; dropped terms are 2^-24)
 //   fp16, 2 x 3 planes, 4 products: hh, hl, lh and A_hi . B_lo2 -- the weights (B, 33 bits in three half planes) are EXACT, so their
@@ -114,15 +136,16 @@ __host__ __device__ constexpr bool q_use_product(int PA, int PB, int NPROD, int 
 // (default mode), <.., 3, S> (split-bf16) and <.., 2, S, 1, 3, 2> (dev: two-plane weights); the bf16 P = 2 form is gemm_bench's.
 // S = ring stages (2: request tile kt+1 while tile kt is consumed; 3: two tiles in flight -- more tolerant of HBM latency when
 // other kernels load the memory system, at 144 KB of LDS for the wide tile).
-template <int CPLX, int WIDE, int P = 3, int S = 2, int F16 = 0, int NPROD = (P == 3 ? 6 : 3), int PB = P, int X8 = 0>
+template <int CPLX, int WIDE, int P = 3, int S = 2, int F16 = 0, int NPROD = (P == 3 ? 6 : 3), int PB = P, int X8 = 0, int AF = 0>
 __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
+  static_assert(!AF || (P == 3 && PB == 3 && F16 == 0 && X8 == 0), "AF: the six-product bf16 form with A as float32");
   static_assert(!X8 || (P == 2 && PB == 3 && F16 == 1 && NPROD == 4 && S == 2), "X8: two half planes of A, three (exact) of B, the four 16-bit products of the split-f16 form, two ring stages");
   static_assert((P == 3 && PB == 3 && NPROD == 6) || (P == 2 && PB == 2 && (NPROD == 3 || NPROD == 4)) || (P == 2 && PB == 3 && (NPROD == 4 || NPROD == 5)), "plane products");
   constexpr int BM = 256, BN = WIDE ? 256 : 128;
   constexpr int BMR = CPLX ? BM / 2 : BM, BNC = CPLX ? BN / 2 : BN;
-  constexpr int BLK = 128 * P, CPB = 8 * P;               // A: bytes per block, 16-B chunks per block (32 P bytes per row per block)
+  constexpr int BLK = AF ? 256 : 128 * P, CPB = AF ? 16 : 8 * P;   // A: bytes per block, 16-B chunks per block (32 P bytes per row per block; AF: 64)
   constexpr int BLKB = 128 * PB, CPBB = 8 * PB;           // B likewise
-  constexpr int A_BYTES = BM * 32 * P, B_BYTES = BN * 32 * PB, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_BYTES = AF ? BM * 64 : BM * 32 * P, B_BYTES = BN * 32 * PB, STAGE = A_BYTES + B_BYTES;
   constexpr int TNW = WIDE ? 4 : 2;                       // 32-column MFMA tiles per wave
   constexpr int JA = A_BYTES / 8192;                      // DMA rounds of the whole block (512 lanes x 16 B)
   constexpr int JBF = B_BYTES / 8192, BHR = (B_BYTES % 8192) ? 1 : 0;
@@ -156,7 +179,8 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
     if (CPLX) { grp = (long)mt * (BMR / 4) + (g % (BMR / 4)); offA = (g / (BMR / 4)) ? p.offA1 : p.offA0; }
     else      { grp = (long)mt * (BM / 4) + g;                offA = p.offA0; }
     if (grp >= gA) grp = gA - 1;
-    a_off[j] = (grp * a_blocks + offA / 16) * BLK + (s ^ q_swz<P>(g)) * 16;          // the 16-B half is the LSB of the chunk index
+    if (AF) a_off[j] = (grp * a_blocks + offA / 16) * BLK + (s >> 2) * 64 + (((s & 3) ^ (g & 3)) * 16);   // s = row in group * 4 + piece
+    else    a_off[j] = (grp * a_blocks + offA / 16) * BLK + (s ^ q_swz<P>(g)) * 16;          // the 16-B half is the LSB of the chunk index
   }
 #pragma unroll
   for (int j = 0; j < JBF + BHR; ++j) {
@@ -202,7 +226,9 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
   for (int t = 0; t < 2; ++t) {
     const int row = CPLX ? (t * BMR + wm * 32 + l31) : (wm * 64 + t * 32 + l31);
 #pragma unroll
-    for (int q = 0; q < P; ++q) a_ad[t][q] = q_row_off<P>(row) + ((q * 2 + h) ^ q_swz<P>(row >> 2)) * 16;
+    for (int q = 0; q < P; ++q)
+      a_ad[t][q] = AF ? ((row >> 2) * 256 + (row & 3) * 64 + ((((h * 2 + (q & 1)) ^ ((row >> 2) & 3))) * 16))     // AF: entries 0 / 1 = the lane's two 16-B pieces
+                      : (q_row_off<P>(row) + ((q * 2 + h) ^ q_swz<P>(row >> 2)) * 16);
   }
 #pragma unroll
   for (int t = 0; t < TNW; ++t) {
@@ -232,7 +258,7 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
   }
 
   const int nk = p.K / 16;
-  constexpr int TAG = 9000 + S * 100 + P * 10 + CPLX * 2 + WIDE + F16 * 1000 + NPROD * 10000 + PB * 100000 + X8 * 1000000;   // one q3_issue instance per kernel
+  constexpr int TAG = 9000 + S * 100 + P * 10 + CPLX * 2 + WIDE + F16 * 1000 + NPROD * 10000 + PB * 100000 + X8 * 1000000 + AF * 10000000;   // one q3_issue instance per kernel
   constexpr int GI = JA + JBF;                            // DMA instructions per tile per wave (+1 for the waves that fetch the half round)
 #pragma unroll
   for (int t = 0; t < S - 1; ++t)
@@ -252,10 +278,22 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
     st_cur = st_cur + 1 == S ? 0 : st_cur + 1;
     st_nxt = st_nxt + 1 == S ? 0 : st_nxt + 1;
     bf16x8_t a[2][P], b[TNW][PB];
+    if constexpr (AF) {
 #pragma unroll
-    for (int q = 0; q < P; ++q)
+      for (int t = 0; t < 2; ++t) {
+        const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(sb + a_ad[t][0]), hi = *reinterpret_cast<const f32x4_t*>(sb + a_ad[t][1]);
+        unsigned int w[3][4];
+        qf_split2(lo[0], lo[1], w[0][0], w[1][0], w[2][0]); qf_split2(lo[2], lo[3], w[0][1], w[1][1], w[2][1]);
+        qf_split2(hi[0], hi[1], w[0][2], w[1][2], w[2][2]); qf_split2(hi[2], hi[3], w[0][3], w[1][3], w[2][3]);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) a[t][q] = *reinterpret_cast<const bf16x8_t*>(sb + a_ad[t][q]);
+        for (int q = 0; q < 3; ++q) { const u32x4q_t v{w[q][0], w[q][1], w[q][2], w[q][3]}; a[t][q] = __builtin_bit_cast(bf16x8_t, v); }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < P; ++q)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) a[t][q] = *reinterpret_cast<const bf16x8_t*>(sb + a_ad[t][q]);
+    }
 #pragma unroll
     for (int q = 0; q < PB; ++q)
 #pragma unroll

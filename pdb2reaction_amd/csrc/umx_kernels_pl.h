@@ -72,7 +72,31 @@ template <int P> __device__ __forceinline__ void pl_store4(unsigned short* row, 
 //                  byte (row * (cols/64) + k/64) * 128 + plane * 64 + k%64.  25 significant bits in all.
 // element (row, k, plane q) of a matrix with `cols` columns -> byte ((row/4) * (cols/16) + k/16) * 128 P + (row%4) * 32 P + q * 32 + (k%16) * 2.
 constexpr float QF16_SCALE = 16.f;
-template <int FMT> struct QFmt { static constexpr int P = FMT ? 2 : 3; static constexpr int BLK = 128 * P; static constexpr int ROWB = 32 * P; static constexpr bool X8 = (FMT == 2); };
+//   FMT 3 ("QF"):  plain float32, 256-B blocks of 4 rows x 16 columns (row r of a block = 64 B): the A operand of the bf16x3 GEMMs since
+//                  round 4 -- umx_gemm_q.h (AF = 1) splits it into the three bf16 planes in registers, bit for bit the planes of FMT 0,
+//                  at 4 B instead of 6 B per element through HBM, L2 and LDS.
+template <int FMT> struct QFmt { static constexpr int P = FMT ? 2 : 3; static constexpr int BLK = 128 * P; static constexpr int ROWB = 32 * P; static constexpr bool X8 = (FMT == 2); static constexpr bool F32 = (FMT == 3); };
+// LDS staging of one row piece (16 columns of one row of a block = 8 P dwords at `rowbase`): two / four adjacent values at column k15 of the piece
+template <int FMT> __device__ __forceinline__ void q_split2(float x0, float x1, unsigned int (&out)[QFmt<FMT>::P]);
+template <int FMT> __device__ __forceinline__ void q_stage2(unsigned int* rowbase, int k15, float x0, float x1) {
+  if constexpr (QFmt<FMT>::F32) *reinterpret_cast<uint2*>(rowbase + k15) = make_uint2(__builtin_bit_cast(unsigned int, x0), __builtin_bit_cast(unsigned int, x1));
+  else {
+    unsigned int w[QFmt<FMT>::P];
+    q_split2<FMT>(x0, x1, w);
+#pragma unroll
+    for (int q = 0; q < QFmt<FMT>::P; ++q) rowbase[(k15 >> 1) + q * 8] = w[q];
+  }
+}
+template <int FMT> __device__ __forceinline__ void q_stage4(unsigned int* rowbase, int k15, const float (&x)[4]) {
+  if constexpr (QFmt<FMT>::F32)
+    *reinterpret_cast<uint4*>(rowbase + k15) = make_uint4(__builtin_bit_cast(unsigned int, x[0]), __builtin_bit_cast(unsigned int, x[1]), __builtin_bit_cast(unsigned int, x[2]), __builtin_bit_cast(unsigned int, x[3]));
+  else {
+    unsigned int wa[QFmt<FMT>::P], wb[QFmt<FMT>::P];
+    q_split2<FMT>(x[0], x[1], wa); q_split2<FMT>(x[2], x[3], wb);
+#pragma unroll
+    for (int q = 0; q < QFmt<FMT>::P; ++q) *reinterpret_cast<uint2*>(rowbase + (k15 >> 1) + q * 8) = make_uint2(wa[q], wb[q]);
+  }
+}
 // the 8-bit planes of two adjacent values: bits 0-15 = the two bytes of plane 0 (x1'), bits 16-31 = those of plane 1 (x2').
 // (bf8 = e5m2, largest finite value 57344: |lo| <= 2^-11 * 65504 and |residual| <= 2^-22 * 65504 stay far inside after the shifts)
 __device__ __forceinline__ unsigned int o8_split2(float x0, float x1) {
@@ -112,10 +136,11 @@ template <int FMT> __device__ __forceinline__ void q_split2(float x0, float x1, 
 }
 template <int FMT> __device__ __forceinline__ unsigned short* q_ptr(unsigned short* base, long row, int cols, int k) {
   return reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(base) + ((row >> 2) * (cols >> 4) + (k >> 4)) * QFmt<FMT>::BLK +
-                                           (row & 3) * QFmt<FMT>::ROWB + (k & 15) * 2);
+                                           (row & 3) * QFmt<FMT>::ROWB + (k & 15) * (QFmt<FMT>::F32 ? 4 : 2));
 }
 template <int FMT> __device__ __forceinline__ void q_store2(unsigned short* base, long row, int cols, int k, float x0, float x1) {
   unsigned short* d = q_ptr<FMT>(base, row, cols, k);
+  if constexpr (QFmt<FMT>::F32) { st_stream(reinterpret_cast<uint2*>(d), make_uint2(__builtin_bit_cast(unsigned int, x0), __builtin_bit_cast(unsigned int, x1))); return; }
   unsigned int w[QFmt<FMT>::P];
   q_split2<FMT>(x0, x1, w);
 #pragma unroll
@@ -123,6 +148,7 @@ template <int FMT> __device__ __forceinline__ void q_store2(unsigned short* base
 }
 template <int FMT> __device__ __forceinline__ void q_store4(unsigned short* base, long row, int cols, int k, float4 v) {
   unsigned short* d = q_ptr<FMT>(base, row, cols, k);
+  if constexpr (QFmt<FMT>::F32) { st_stream(reinterpret_cast<uint4*>(d), make_uint4(__builtin_bit_cast(unsigned int, v.x), __builtin_bit_cast(unsigned int, v.y), __builtin_bit_cast(unsigned int, v.z), __builtin_bit_cast(unsigned int, v.w))); return; }
   unsigned int a[QFmt<FMT>::P], b[QFmt<FMT>::P];
   q_split2<FMT>(v.x, v.y, a); q_split2<FMT>(v.z, v.w, b);
 #pragma unroll
@@ -155,7 +181,7 @@ template <int FMT> __device__ __forceinline__ void q_store4(unsigned short* base
     if (const long idx = __builtin_amdgcn_readfirstlane((int)(((_vb & 7) * _per + (_vb >> 3)) * 4 + (threadIdx.x >> 6))); idx < (count))
 
 // LayerNorm(128)+SiLU of the radial MLP, output as PL planes (A operand of the fc3 GEMM)
-template <int P, bool Q = false>
+template <int P, bool Q = false, int FMT = (P == 2 ? 1 : 0)>      // Q: quad-row output in format FMT (QFmt)
 __global__ __launch_bounds__(256) void k_ln_silu_fwd_pl(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, unsigned short* __restrict__ y, long rows, float odd_sign,
                                                         unsigned char* __restrict__ y8) {
@@ -169,7 +195,7 @@ __global__ __launch_bounds__(256) void k_ln_silu_fwd_pl(const float* __restrict_
   const float2 ww = *reinterpret_cast<const float2*>(w + c0), bb = *reinterpret_cast<const float2*>(b + c0);
   const float sg = row_sign(row, odd_sign);
   const float o0 = sg * silu_f(scale_rstd(v.x, rstd) * ww.x + bb.x), o1 = sg * silu_f(scale_rstd(v.y, rstd) * ww.y + bb.y);
-  if (Q) q_store2<(P == 2)>(y, row, RH, c0, o0, o1);            // Q with P = 2: the fp16 two-plane format
+  if (Q) q_store2<FMT>(y, row, RH, c0, o0, o1);
   else pl_store2<P>(y + row * (RH * P), c0, o0, o1);
   if (Q && P == 2 && y8) o8_store2(y8, row, RH, c0, o0, o1);    // (+ the 8-bit planes, FMT 2)
   }
@@ -257,11 +283,7 @@ __global__ __launch_bounds__(256) void k_gather_rotate_mod_q3(const float* __res
   const int ridx[9] = {0, 1, 2, 3, 4, 3, 4, 5, 5};   // radial row of each m-primary row
   unsigned char* gbase = reinterpret_cast<unsigned char*>(y1) + grp * (long)(XROT / 16) * BLK;
   auto put = [&](int buf, int col, float x0, float x1) {
-    unsigned int* d = &stage[buf][col >> 4][wave][(col & 15) >> 1];
-    unsigned int w[P];
-    q_split2<FMT>(x0, x1, w);
-#pragma unroll
-    for (int q = 0; q < P; ++q) d[q * 8] = w[q];
+    q_stage2<FMT>(&stage[buf][col >> 4][wave][0], col & 15, x0, x1);
     if constexpr (X8) {
       const unsigned int w8 = o8_split2(x0, x1);
       unsigned char* d8 = &stage8[buf][wave][(col >> 6) * 128 + (col & 63)];
@@ -357,11 +379,7 @@ __global__ __launch_bounds__(256) void k_gate_edge_fwd_q3(const float* __restric
     }
     const float rs = row_sign(le, odd_sign);                                      // e0 is a multiple of 8: the edge's parity is le's
     x[0] *= rs; x[1] *= rs; x[2] *= rs; x[3] *= rs;
-    unsigned int* d = &stage[buf][le >> 2][c >> 4][le & 3][(c & 15) >> 1];
-    unsigned int wa[P], wb[P];
-    q_split2<FMT>(x[0], x[1], wa); q_split2<FMT>(x[2], x[3], wb);
-#pragma unroll
-    for (int q = 0; q < P; ++q) *reinterpret_cast<uint2*>(d + q * 8) = make_uint2(wa[q], wb[q]);
+    q_stage4<FMT>(&stage[buf][le >> 2][c >> 4][le & 3][0], c & 15, x);
     if constexpr (X8) {
       const unsigned int a8 = o8_split2(x[0], x[1]), b8 = o8_split2(x[2], x[3]);
       unsigned char* d8 = &stage8[buf][le][(c >> 6) * 128 + (c & 63)];
@@ -432,11 +450,12 @@ __global__ __launch_bounds__(256) void k_rotate_back_bwd_pl(const float* __restr
 // conv-2^T GEMMs then run on the 256 x 256-tile kernel like the forward ones.  A workgroup = the four edges of one row group (one wave
 // each, XCD-contiguous row groups); per m-primary row the four waves stage their 128 columns x 3 planes in LDS in the byte order of the
 // 8 consecutive 384-B blocks and the workgroup writes them with coalesced 16-B stores (see k_gather_rotate_mod_q3).
+template <int FMT>             // 0: three bf16 planes, 3: float32 rows (QFmt)
 __global__ __launch_bounds__(256) void k_rotate_back_bwd_q3(const float* __restrict__ gnode, const float* __restrict__ msg,
                                                             const float* __restrict__ frame, const int* __restrict__ edst,
                                                             unsigned short* __restrict__ gmsg, float* __restrict__ dedd,
                                                             float* __restrict__ tau, long ne, float odd_sign) {
-  constexpr int P = 3, BLK = 384;
+  constexpr int P = QFmt<FMT>::P, BLK = QFmt<FMT>::BLK;
   __shared__ __attribute__((aligned(16))) unsigned int stage[2][8][4][8 * P];    // [buffer][16-column block][row in group][q*8 + pair]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long nvb = (((ne + 3) / 4 + 7) / 8) * 8;
@@ -480,14 +499,10 @@ __global__ __launch_bounds__(256) void k_rotate_back_bwd_q3(const float* __restr
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
     const int buf = r & 1;
-    unsigned int w[P];
-    q_split2<0>(sg * lx[r], sg * ly[r], w);
-    unsigned int* d = &stage[buf][c0 >> 4][wave][(c0 & 15) >> 1];
-#pragma unroll
-    for (int q = 0; q < P; ++q) d[q * 8] = w[q];
+    q_stage2<FMT>(&stage[buf][c0 >> 4][wave][0], c0 & 15, sg * lx[r], sg * ly[r]);
     __syncthreads();
-    // 8 blocks x 384 B = 192 chunks of 16 B
-    if (threadIdx.x < 192) {
+    // 8 blocks x 128 P bytes = 64 P chunks of 16 B
+    if (threadIdx.x < 64 * P) {
       const uint4 val = reinterpret_cast<const uint4*>(&stage[buf][0][0][0])[threadIdx.x];
       st_stream(reinterpret_cast<uint4*>(gbase + (long)r * 8 * BLK) + threadIdx.x, val);
     }
@@ -533,9 +548,10 @@ __global__ void k_gate_edge_bwd_pl(const float* __restrict__ ghid, const float* 
 // The same for the quad-row (Q3) layout (bf16x3 reverse pass): a workgroup = 8 edges = two row groups; per 128-column row (the nine
 // m-primary rows of g_hpre, then the two gate rows) the values of the 8 edges are staged in LDS in block order and written with coalesced
 // 16-B stores (see k_gate_edge_fwd_q3).  Column layout of g_hg as everywhere: [ggate l1 (128) | ggate l2 (128) | ghpre 9 x 128].
+template <int FMT>             // 0: three bf16 planes, 3: float32 rows (QFmt)
 __global__ __launch_bounds__(256) void k_gate_edge_bwd_q3(const float* __restrict__ ghid, const float* __restrict__ hg, unsigned short* __restrict__ ghg,
                                                           long ne, float odd_sign) {
-  constexpr int P = 3, BLK = 384;
+  constexpr int P = QFmt<FMT>::P, BLK = QFmt<FMT>::BLK;
   __shared__ __attribute__((aligned(16))) unsigned int stage[2][2][8][4][8 * P]; // [buffer][row group][16-column block][row][q*8 + pair]
   const long nvb = (ne + 7) / 8;
   for (long vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
@@ -559,13 +575,10 @@ __global__ __launch_bounds__(256) void k_gate_edge_bwd_q3(const float* __restric
   float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
   auto emit = [&](int it, int colblk, const float (&x)[4]) {                      // colblk: first 16-column block of this 128-column row
     const int buf = it & 1;
-    unsigned int* d = &stage[buf][le >> 2][c >> 4][le & 3][(c & 15) >> 1];
-    unsigned int wa[P], wb[P];
-    q_split2<0>(rs * x[0], rs * x[1], wa); q_split2<0>(rs * x[2], rs * x[3], wb);
-#pragma unroll
-    for (int q = 0; q < P; ++q) *reinterpret_cast<uint2*>(d + q * 8) = make_uint2(wa[q], wb[q]);
+    const float xs[4] = {rs * x[0], rs * x[1], rs * x[2], rs * x[3]};
+    q_stage4<FMT>(&stage[buf][le >> 2][c >> 4][le & 3][0], c & 15, xs);
     __syncthreads();
-    constexpr int CPG = 64 * P;                                                  // 16-B chunks per row group: 8 blocks x 24
+    constexpr int CPG = 64 * P;                                                  // 16-B chunks per row group: 8 blocks x 8 P
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
       const int ch = threadIdx.x + 256 * k2;

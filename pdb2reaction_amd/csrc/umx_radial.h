@@ -177,7 +177,7 @@ __device__ __forceinline__ void rad_mma_f16(const unsigned char* __restrict__ a_
 }
 
 // ---- forward: d, Z_src, Z_dst  ->  h1pre, h2pre (kept for the reverse pass) and the fc3 operand --------------------------------
-// OUTQ3 = 1: the fc3 operand as Q3 bf16 planes (umx_gemm_q.h), 2: as fp16 two-plane "Q2H" planes (QFmt<1>), 3: Q2H + 8-bit planes (QFmt<2>);  0: fp32 rows (fp32
+// OUTQ3 = 1: the fc3 operand as Q3 bf16 planes (umx_gemm_q.h), 2: as fp16 two-plane "Q2H" planes (QFmt<1>), 3: Q2H + 8-bit planes (QFmt<2>), 4: float32 quad-row blocks (QFmt<3>);  0: fp32 rows (fp32
 // precision mode, and the edge-degree MLP whose fc3 runs on the fp32 GEMM).   ts / tt: per-element tables of the embedding part of fc1 (tt includes the fc1 bias).
 // TR = 32-row MFMA tiles per workgroup tile (RT = 32 TR edges).  TR = 1 halves the LDS and accumulator footprint so that three
 // workgroups share a CU: the VALU-heavy LayerNorm passes of one overlap the MFMAs of the others (measured against TR = 2 below).
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
       if (!(UMX_ABL & 16) && e < ne) {
         *reinterpret_cast<float2*>(h2pre + e * RH + 2 * lane) = v;
         if (OUTQ3) {
-          q_store2<(OUTQ3 >= 2)>(reinterpret_cast<unsigned short*>(out), e, RH, 2 * lane, row_sign(e, odd_sign) * o.x, row_sign(e, odd_sign) * o.y);
+          q_store2<(OUTQ3 == 4 ? 3 : OUTQ3 >= 2 ? 1 : 0)>(reinterpret_cast<unsigned short*>(out), e, RH, 2 * lane, row_sign(e, odd_sign) * o.x, row_sign(e, odd_sign) * o.y);
           if (OUTQ3 == 3) o8_store2(out8, e, RH, 2 * lane, row_sign(e, odd_sign) * o.x, row_sign(e, odd_sign) * o.y);      // Q2H + the 8-bit planes (QFmt<2>)
         } else *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + e * RH + 2 * lane) = o;
       }

@@ -108,6 +108,8 @@ def switch_case(oracle):
     {"UMX_MFMA16": "0", "UMX_PRECISION": "split"}, {"UMX_MFMA16": "2", "UMX_PRECISION": "split"},
     {"UMX_RADIAL_TR": "1"}, {"UMX_RADIAL_FAST": "2"}, {"UMX_FUSE_MODROT": "0"}, {"UMX_FUSE_MODROT": "0", "UMX_PRECISION": "split"},
     {"UMX_REV_Q3": "0"},                                         # bf16x3 reverse operands in the PL layout (256x128 tiles)
+    {"UMX_A_F32": "0"}, {"UMX_A_F32": "0", "UMX_PRECISION": "split-bf16"},     # A operands as three pre-split bf16 planes (rounds 2-3) instead of float32 blocks
+    {"UMX_FUSED_RADIAL": "0", "UMX_A_F32": "0"}, {"UMX_Q3WIDE": "0", "UMX_A_F32": "0"}, {"UMX_Q3S": "3", "UMX_A_F32": "0"},
     {"UMX_ALT_ROWS": "0"}, {"UMX_ALT_ROWS": "0", "UMX_PRECISION": "split"},     # without the sign-alternating operand rows
 ], ids=lambda e: ",".join(f"{k[4:]}={v}" for k, v in e.items()))
 def test_documented_switches_hold_the_tolerances(weights, switch_case, env, monkeypatch):
@@ -125,6 +127,41 @@ def test_documented_switches_hold_the_tolerances(weights, switch_case, env, monk
         assert np.abs(e - e_ref).max() <= TOL_E and np.abs(f - f_ref).max() <= TOL_F
     finally:
         eng.close()
+
+
+def test_float32_operand_blocks_against_the_plane_form(weights, mode_pair=("bf16x3", "split-bf16")):
+    """Round 4: the A operands of the bf16-plane GEMMs travel as float32 (4 B per element) and are split into their three bf16 planes by the
+    GEMM in registers (umx_gemm_q.h, AF) -- round to nearest, the split the producers used to do (6 B per element, UMX_A_F32=0).  The GEMM
+    is bit for bit the plane form on the same values (csrc/gemm_bench.hip f16 checks that); the two producer instantiations round the last
+    bit of some values differently (fma contraction), so whole evaluations agree to round-off, not bitwise: far inside the tolerances."""
+    import os
+    from pdb2reaction_amd.engine import Engine
+
+    z, imgs, _ = synth.make_images(700, 2, seed=5)
+    p32 = np.asarray(imgs, dtype=np.float32)
+    old = {k: os.environ.get(k) for k in ("UMX_A_F32", "UMX_PRECISION")}
+    try:
+        for mode in mode_pair:
+            out = []
+            for a_f32 in ("1", "0"):
+                os.environ["UMX_A_F32"] = a_f32
+                os.environ["UMX_PRECISION"] = mode
+                eng = Engine(0)
+                try:
+                    eng.load_weights(weights)
+                    eng.set_system(z)
+                    out.append(eng.energy_forces(p32))
+                finally:
+                    eng.close()
+            de, df = np.abs(out[0][0] - out[1][0]).max(), np.abs(out[0][1] - out[1][1]).max()
+            print(f"[A_F32 1 vs 0, {mode}] |dE| = {de:.2e} eV, max|dF| = {df:.2e} eV/A")
+            assert de <= 2e-5 and df <= 5e-6, (mode, de, df)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 @pytest.mark.parametrize("mode,wider", [("split", "split-bf16"), ("f16x2b8", "bf16x3")])

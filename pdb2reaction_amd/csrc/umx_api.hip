@@ -83,6 +83,7 @@ struct umx_engine {
                                    // 3 = plain float32 quad-row blocks, split into three bf16 planes by the GEMM in registers (the bf16 forward planes since round 4)
   std::map<const float*, const unsigned char*> planes8;   // fwd_fmt 2: the 8-bit planes ("O8" layout, umx_gemm_q.h) of a weight
   bool a_f32 = true;               // UMX_A_F32=0: the A operands of the bf16-plane GEMMs as three pre-split bf16 planes (6 B per element; rounds 2-3) instead of float32
+  int f32rows_layout = 1;          // UMX_GRAD_F32=0: g_rad -> fc3^T as three PL planes (6 B per element) instead of float32 rows split by the GEMM (needs a_f32)
   bool rev_qf = false;             // derived at load: reverse quad-row operands (g_msg, g_hg) as float32 blocks (bf16x3, quad-row reverse layout, a_f32)
   std::string precision;           // umx_set_precision: overrides UMX_PRECISION when non-empty
   bool node_ctx = false;           // set around the node-level launches (NodeCtx): only those take the float64-accumulating kernel
@@ -273,7 +274,8 @@ int gemm_cplx(umx_engine* eng, const float* A, long lda, int offRe, int offIm, c
 // three bf16 planes in split-bf16 mode; PL layout with UMX_Q3=0), P = 2: a reverse-pass product (bf16 planes, umx_gemm_pl.h).
 // Wkey = fp32 device pointer of the weight (its plane copy is looked up); a_cols = total columns of the A matrix; offsets in columns.
 int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_cols, int offA0, int offA1, const float* Wkey, int bHalf,
-            const float* bias, float* Cp, long ldc, int offC, int offCi, long M, int N, int K, float conj) {
+            const float* bias, float* Cp, long ldc, int offC, int offCi, long M, int N, int K, float conj, bool a_f32rows = false) {
+  // a_f32rows: a reverse-pass A operand stored as plain float32 ROWS (k_modrot_bwd_pl<0>), split by umx_gemm_pl16_kernel<.., AF = 1> in registers
   if (M <= 0) return UMX_OK;
   auto it = eng->planes.find(Wkey);
   if (it == eng->planes.end()) return fail(eng, UMX_ERR_ARG, "gemm_pl: weight has no PL copy");
@@ -371,6 +373,10 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
       if (wq) { if (S == 3) hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 3, 3>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1>), gq, block, 0, eng->stream, q); }
       else    { if (S == 3) hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0, 3, 3>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0>), gq, block, 0, eng->stream, q); }
     }
+  } else if (P == 3 && a_f32rows) {
+    if (cplx || N > 128) return fail(eng, UMX_ERR_ARG, "gemm_pl: float32-row operands are instantiated for the plain N <= 128 (radial fc3^T) product only");
+    q.lda = (long)a_cols * 2;                  // row pitch in 2-byte units
+    hipLaunchKernelGGL((umx_gemm_pl16_kernel<0, 3, 2, 4, 2, 2, 2, 0, 1>), grid, block, 0, eng->stream, q);     // (an 8 x 1 wave layout measured the same)
   } else if (P == 3) {
     if (use16) {
       if (cplx) hipLaunchKernelGGL((umx_gemm_pl16_kernel<1, 3, 2, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
@@ -574,8 +580,8 @@ int radial_fwd(umx_engine* eng, const WS& w, const RadialW& r, int slot, long ne
   return radial_fwd_fc3(eng, w, r, ne, rad_out);
 }
 
-int radial_bwd_fc3(umx_engine* eng, const WS& w, const RadialW& r, long ne, const float* grad, const unsigned short* gradpl) {
-  if (gradpl) return gemm_pl(eng, 0, 2, gradpl, r.out, 0, 0, r.w3T, 0, nullptr, w.e128a, RH, 0, 0, ne, RH, r.out, 1.0f);
+int radial_bwd_fc3(umx_engine* eng, const WS& w, const RadialW& r, long ne, const float* grad, const unsigned short* gradpl, bool f32rows = false) {
+  if (gradpl) return gemm_pl(eng, 0, 2, gradpl, r.out, 0, 0, r.w3T, 0, nullptr, w.e128a, RH, 0, 0, ne, RH, r.out, 1.0f, f32rows);
   return gemm_plain(eng, grad, r.out, 0, r.w3T, r.out, nullptr, w.e128a, RH, 0, ne, RH, r.out);
 }
 int radial_bwd_tail(umx_engine* eng, const WS& w, const RadialW& r, int slot, long ne) {
@@ -900,7 +906,9 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       P.matrix([=, &w]() -> int {
         hipStream_t s = eng->stream;
         if (eng->fuse_modrot) {       // one node-centric kernel: modulation backward + rotate-back + segmented sum (g_xrot stays in registers)
-          if (eng->rev_planes == 3) hipLaunchKernelGGL(k_modrot_bwd_pl<3>, dim3((unsigned)nn), B256, 0, s, w.gy1, w.xn[i], w.frame, w.rad[i], w.row_ptr, w.out_ptr, w.out_edge,
+          if (eng->rev_qf && eng->f32rows_layout) hipLaunchKernelGGL(k_modrot_bwd_pl<0>, dim3((unsigned)nn), B256, 0, s, w.gy1, w.xn[i], w.frame, w.rad[i], w.row_ptr, w.out_ptr, w.out_edge,
+                                              w.gradpl, w.tau, w.tau2, w.G1, nn, eng->odd_sign);        // g_rad as float32 rows (sign-alternating): split by the fc3^T GEMM
+          else if (eng->rev_planes == 3) hipLaunchKernelGGL(k_modrot_bwd_pl<3>, dim3((unsigned)nn), B256, 0, s, w.gy1, w.xn[i], w.frame, w.rad[i], w.row_ptr, w.out_ptr, w.out_edge,
                                                        w.gradpl, w.tau, w.tau2, w.G1, nn, eng->odd_sign);
           else hipLaunchKernelGGL(k_modrot_bwd_pl<2>, dim3((unsigned)nn), B256, 0, s, w.gy1, w.xn[i], w.frame, w.rad[i], w.row_ptr, w.out_ptr, w.out_edge,
                                   w.gradpl, w.tau, w.tau2, w.G1, nn, eng->odd_sign);
@@ -914,7 +922,7 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       });
       P.matrix([=, &w]() -> int {
         if (side && i + 1 < NL) HIPCHK(eng, hipStreamWaitEvent(eng->stream, eng->ev_stail, 0));      // e128a: the previous layer's tail has read it
-        return radial_bwd_fc3(eng, w, Lp->rad, ne, nullptr, w.gradpl);
+        return radial_bwd_fc3(eng, w, Lp->rad, ne, nullptr, w.gradpl, eng->rev_qf && eng->f32rows_layout && eng->fuse_modrot);
       });
       // the tail feeds only the scalar dE/dd (own accumulator dedd_rad).  Side mode: layers 3..1 defer it to the next layer's gate kernel
       // (above); layer 0 has no layer below and runs it here
@@ -1109,6 +1117,7 @@ int umx_create(umx_engine** out, int device_ordinal) {
   if (const char* ev = std::getenv("UMX_NODE_F64")) e->node_f64_on = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_REV_Q3")) e->rev_q3 = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_A_F32")) e->a_f32 = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("UMX_GRAD_F32")) e->f32rows_layout = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_ALT_ROWS")) e->odd_sign = std::atoi(ev) != 0 ? -1.0f : 1.0f;
   if (const char* ev = std::getenv("UMX_DEG_SPLIT")) e->deg_split = std::atoi(ev) != 0;
   e->stream_cap = 512;

@@ -51,6 +51,21 @@ struct GemmPL {
   int x8_skip;                          // dev: bit 0 = leave out x0'.y2', bit 1 = leave out x2'.y0'
 };
 
+// float32 A operands (AF = 1 kernels here and in umx_gemm_q.h): a pair of floats -> the three packed bf16 plane dwords, round to nearest,
+// ONE v_cvt_pk_bf16_f32 per plane (11 VALU ops per pair) -- bit for bit the planes the producers' split writes
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4q_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4q_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void qf_split2(float x0, float x1, unsigned int& p0, unsigned int& p1, unsigned int& p2) {
+  p0 = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{x0, x1}, bf16x2_t));
+  const float r0 = x0 - __builtin_bit_cast(float, p0 << 16), r1 = x1 - __builtin_bit_cast(float, p0 & 0xffff0000u);
+  p1 = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{r0, r1}, bf16x2_t));
+  const float s0 = r0 - __builtin_bit_cast(float, p1 << 16), s1 = r1 - __builtin_bit_cast(float, p1 & 0xffff0000u);
+  p2 = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{s0, s1}, bf16x2_t));
+}
+
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
@@ -64,10 +79,11 @@ template <int P> __device__ __forceinline__ int pl_perm(int s, int r) {
 // (A plain __device__ function: a lambda calling the LDS-DMA builtin silently drops the host-side kernel stub, and
 //  hipcc 7.2 rejects a second kernel re-using one specialization of such a function -- hence the TAG parameter.)
 template <int JA, int JB, int TA_B, int WSTR, int TAG, int AUXA = 0>
-__device__ __forceinline__ void pl_issue(const GemmPL& p, unsigned char* sbase, const long (&a_off)[JA], const long (&b_off)[JB], long kofs, int piece) {
+__device__ __forceinline__ void pl_issue(const GemmPL& p, unsigned char* sbase, const long (&a_off)[JA], const long (&b_off)[JB], long kofs, int piece, long kofs_a = -1) {
+  if (kofs_a < 0) kofs_a = kofs;      // (float32 A rows advance by 64 shorts per k-tile, the planes of B by 32 P)
 #pragma unroll
   for (int j = 0; j < JA; ++j)
-    __builtin_amdgcn_global_load_lds(p.Apl + a_off[j] + kofs, (__attribute__((address_space(3))) void*)(sbase + piece + j * WSTR), 16, 0, AUXA);
+    __builtin_amdgcn_global_load_lds(p.Apl + a_off[j] + kofs_a, (__attribute__((address_space(3))) void*)(sbase + piece + j * WSTR), 16, 0, AUXA);
 #pragma unroll
   for (int j = 0; j < JB; ++j)
     __builtin_amdgcn_global_load_lds(p.Bpl + b_off[j] + kofs, (__attribute__((address_space(3))) void*)(sbase + TA_B + piece + j * WSTR), 16, 0, 0);
@@ -261,24 +277,30 @@ __global__ __launch_bounds__(64 * WVM * WVN, 1) void umx_gemm_pl_kernel(const Ge
 }
 
 // Same kernel on v_mfma_f32_16x16x32_bf16 (one MFMA k-step per 32-wide k-tile; the chip may hold a different clock on this shape).
-template <int CPLX, int P, int S, int WVM, int WVN, int WMT, int WNT, int ABL = 0>
+// AF = 1 (round 4): the A operand as plain float32 ROWS (row pitch lda shorts = 2 x columns; what the node-centric k_modrot_bwd_pl<0>
+// writes edge by edge), split into the three bf16 planes in registers as in umx_gemm_q.h.  A row of a k-tile is 32 floats = 128 B = the
+// geometry of the two-plane rows: the LDS slot of the lane's piece i (k = 8 h + 4 i ...) is the two-plane image's slot of (plane i,
+// k-chunk h), so the proven conflict-free pl_perm<2> serves; source chunk = 2 h + i.
+template <int CPLX, int P, int S, int WVM, int WVN, int WMT, int WNT, int ABL = 0, int AF = 0>
 __global__ __launch_bounds__(64 * WVM * WVN, 1) void umx_gemm_pl16_kernel(const GemmPL p) {
+  static_assert(!AF || P == 3, "AF: the six-product form");
   constexpr int NT = 64 * WVM * WVN;           // threads
   constexpr int BM = 32 * WVM * WMT;           // block tile rows (A rows)
   constexpr int BN = 32 * WVN * WNT;           // block tile columns (B rows)
   static_assert(!CPLX || (WMT % 2 == 0 && WNT % 2 == 0), "complex tiles need re/im and A/B halves in every wave");
   constexpr int SEG = 4 * P;                   // 16-B chunks per row per k-tile
   constexpr int ROWB = SEG * 16;               // bytes per row per k-tile (128 or 192)
-  constexpr int TA_B = BM * ROWB;
+  constexpr int SEGA = AF ? 8 : SEG, ROWA = SEGA * 16;
+  constexpr int TA_B = BM * ROWA;
   constexpr int TB_B = BN * ROWB;
   constexpr int STAGE_B = TA_B + TB_B;
   static_assert(S * STAGE_B <= 160 * 1024, "ring does not fit the 160 KiB LDS");
   __shared__ __attribute__((aligned(1024))) unsigned char ring[S * STAGE_B];
   constexpr int BMR = CPLX ? BM / 2 : BM;      // logical rows (edges) per block
   constexpr int BNC = CPLX ? BN / 2 : BN;      // logical cols (channels) per block
-  constexpr int JA = BM * SEG / NT;            // A chunks per lane per k-tile
+  constexpr int JA = BM * SEGA / NT;           // A chunks per lane per k-tile
   constexpr int JB = BN * SEG / NT;
-  static_assert(BM * SEG % NT == 0 && BN * SEG % NT == 0, "tile does not divide over the threads");
+  static_assert(BM * SEGA % NT == 0 && BN * SEG % NT == 0, "tile does not divide over the threads");
   constexpr int G = JA + JB;                   // global_load_lds instructions per wave per k-tile
   constexpr int WSTR = NT * 16;                // LDS bytes covered by one DMA round of the whole block
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -296,12 +318,13 @@ __global__ __launch_bounds__(64 * WVM * WVN, 1) void umx_gemm_pl16_kernel(const 
   long a_off[JA], b_off[JB];
 #pragma unroll
   for (int j = 0; j < JA; ++j) {
-    const int c = tid + NT * j, trow = c / SEG, s = c % SEG;
+    const int c = tid + NT * j, trow = c / SEGA, s = c % SEGA;
     long grow; int offA;
     if (CPLX) { grow = (long)mt * BMR + (trow % BMR); offA = (trow / BMR) ? p.offA1 : p.offA0; }
     else      { grow = (long)mt * BM + trow;          offA = p.offA0; }
     if (grow >= p.M) grow = p.M - 1;
-    a_off[j] = grow * p.lda + (long)offA * P + pl_perm<P>(s, trow) * 8;
+    if (AF) { const int u = pl_perm<2>(s, trow); a_off[j] = grow * p.lda + (long)offA * 2 + (2 * (u & 3) + (u >> 2)) * 8; }
+    else a_off[j] = grow * p.lda + (long)offA * P + pl_perm<P>(s, trow) * 8;
   }
 #pragma unroll
   for (int j = 0; j < JB; ++j) {
@@ -332,24 +355,38 @@ __global__ __launch_bounds__(64 * WVM * WVN, 1) void umx_gemm_pl16_kernel(const 
     b_row[t] = CPLX ? ((t / (TN / 2)) * BNC + wn * (16 * WNT) + (t % (TN / 2)) * 16 + l15) : (wn * (32 * WNT) + t * 16 + l15);
 
   const int nk = p.K / 32;
-  constexpr int TAG = 1000000 + ((((ABL * 2 + CPLX) * 4 + P) * 8 + S) * 8 + WVM) * 64 + WVN * 16 + WMT * 2 + WNT / 2;
+  constexpr int TAG = 1000000 + AF * 4000000 + ((((ABL * 2 + CPLX) * 4 + P) * 8 + S) * 8 + WVM) * 64 + WVN * 16 + WMT * 2 + WNT / 2;
   constexpr int AUXA = (ABL & 16) ? 2 : 0;   // dev: non-temporal A stream
 #pragma unroll
   for (int s = 0; s < S - 1; ++s)
-    if (s < nk) pl_issue<JA, JB, TA_B, WSTR, TAG, AUXA>(p, ring + s * STAGE_B, a_off, b_off, (long)s * 32 * P, piece);
+    if (s < nk) pl_issue<JA, JB, TA_B, WSTR, TAG, AUXA>(p, ring + s * STAGE_B, a_off, b_off, (long)s * 32 * P, piece, AF ? (long)s * 64 : -1L);
 
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + S - 2 < nk) wait_vmcnt<(S - 2) * G>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // everyone's tile kt landed; everyone finished reading tile kt-1
     if (kt + S - 1 < nk && !(ABL & 1))
-      pl_issue<JA, JB, TA_B, WSTR, TAG, AUXA>(p, ring + ((kt + S - 1) % S) * STAGE_B, a_off, b_off, (long)(kt + S - 1) * 32 * P, piece);
+      pl_issue<JA, JB, TA_B, WSTR, TAG, AUXA>(p, ring + ((kt + S - 1) % S) * STAGE_B, a_off, b_off, (long)(kt + S - 1) * 32 * P, piece, AF ? (long)(kt + S - 1) * 64 : -1L);
     const unsigned char* sbase = ring + (kt % S) * STAGE_B;
     bf16x8_t a[TM][P], b[TN][P];         // one MFMA k-step covers the whole 32-wide k-tile
+    if constexpr (AF) {
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        const f32x4q_t lo = *reinterpret_cast<const f32x4q_t*>(sbase + a_row[t] * ROWA + pl_perm<2>(h, a_row[t]) * 16);
+        const f32x4q_t hi = *reinterpret_cast<const f32x4q_t*>(sbase + a_row[t] * ROWA + pl_perm<2>(4 + h, a_row[t]) * 16);
+        unsigned int w[3][4];
+        qf_split2(lo[0], lo[1], w[0][0], w[1][0], w[2][0]); qf_split2(lo[2], lo[3], w[0][1], w[1][1], w[2][1]);
+        qf_split2(hi[0], hi[1], w[0][2], w[1][2], w[2][2]); qf_split2(hi[2], hi[3], w[0][3], w[1][3], w[2][3]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { const u32x4q_t v{w[q][0], w[q][1], w[q][2], w[q][3]}; a[t][q] = __builtin_bit_cast(bf16x8_t, v); }
+      }
+    }
 #pragma unroll
     for (int q = 0; q < P; ++q) {
       const int u = q * 4 + h;             // source chunk wanted: plane q, k-chunk h
+      if constexpr (!AF) {
 #pragma unroll
-      for (int t = 0; t < TM; ++t) a[t][q] = *reinterpret_cast<const bf16x8_t*>(sbase + a_row[t] * ROWB + pl_perm<P>(u, a_row[t]) * 16);
+        for (int t = 0; t < TM; ++t) a[t][q] = *reinterpret_cast<const bf16x8_t*>(sbase + a_row[t] * ROWB + pl_perm<P>(u, a_row[t]) * 16);
+      }
 #pragma unroll
       for (int t = 0; t < TN; ++t) b[t][q] = *reinterpret_cast<const bf16x8_t*>(sbase + TA_B + b_row[t] * ROWB + pl_perm<P>(u, b_row[t]) * 16);
     }

@@ -107,18 +107,6 @@ __device__ __forceinline__ i32x8_t q8_frag(const unsigned char* sb, int ad0, int
 // write + GEMM read), 16 KB instead of 24 KB per k-tile through L2->LDS and the LDS read ports; csrc/gemm_bench.hip f16: 0.88-0.93 of the
 // plane form's time on 256 x 256 tiles, the same on 256 x 128 tiles.  (A truncating split is no cheaper and gives every plane the sign
 // of x -- the dropped terms would then be one-sided.)  The weights stay pre-split planes: their fragments are twice as many per wave.
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4q_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void qf_split2(float x0, float x1, unsigned int& p0, unsigned int& p1, unsigned int& p2) {
-  p0 = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{x0, x1}, bf16x2_t));
-  const float r0 = x0 - __builtin_bit_cast(float, p0 << 16), r1 = x1 - __builtin_bit_cast(float, p0 & 0xffff0000u);
-  p1 = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{r0, r1}, bf16x2_t));
-  const float s0 = r0 - __builtin_bit_cast(float, p1 << 16), s1 = r1 - __builtin_bit_cast(float, p1 & 0xffff0000u);
-  p2 = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{s0, s1}, bf16x2_t));
-}
-
 // which plane products A_qa . B_qb a kernel accumulates:
 //   bf16, 3 x 3 planes, 6 products: qa + qb < 3 (everything down to 2^-16 of the leading term; dropped terms are 2^-24)
 //   fp16, 2 x 3 planes, 4 products: hh, hl, lh and A_hi . B_lo2 -- the weights (B, 33 bits in three half planes) are EXACT, so their
@@ -281,7 +269,7 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
     if constexpr (AF) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(sb + a_ad[t][0]), hi = *reinterpret_cast<const f32x4_t*>(sb + a_ad[t][1]);
+        const f32x4q_t lo = *reinterpret_cast<const f32x4q_t*>(sb + a_ad[t][0]), hi = *reinterpret_cast<const f32x4q_t*>(sb + a_ad[t][1]);
         unsigned int w[3][4];
         qf_split2(lo[0], lo[1], w[0][0], w[1][0], w[2][0]); qf_split2(lo[2], lo[3], w[0][1], w[1][1], w[2][1]);
         qf_split2(hi[0], hi[1], w[0][2], w[1][2], w[2][2]); qf_split2(hi[2], hi[3], w[0][3], w[1][3], w[2][3]);

@@ -723,10 +723,11 @@ __global__ __launch_bounds__(256) void k_modrot_bwd_pl(const float* __restrict__
       gax[k] += gv[r].x * px[r]; gay[k] += gv[r].y * py[r];
       hx[r] = gv[r].x * rv[k].x; hy[r] = gv[r].y * rv[k].y;
     }
-    if constexpr (P == 0) {      // fp32 precision mode: g_rad as plain float32 rows (the A operand of the fp32-MFMA fc3^T GEMM), no row signs
-      float* gr = reinterpret_cast<float*>(grad) + e * (long)RAD;
+    if constexpr (P == 0) {      // g_rad as plain float32 rows: the A operand of the fp32-MFMA fc3^T GEMM (fp32 mode, odd_sign = +1) or of
+      float* gr = reinterpret_cast<float*>(grad) + e * (long)RAD;      // umx_gemm_pl16_kernel<.., AF = 1> (bf16x3, sign-alternating rows)
+      const float sg = row_sign(e, odd_sign);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) *reinterpret_cast<float2*>(gr + k * 2 * C + half + c0) = make_float2(gax[k], gay[k]);
+      for (int k = 0; k < 6; ++k) *reinterpret_cast<float2*>(gr + k * 2 * C + half + c0) = make_float2(sg * gax[k], sg * gay[k]);
     } else {
       unsigned short* gr = grad + e * (long)(RAD * P);
       const float sg = row_sign(e, odd_sign);

@@ -108,6 +108,7 @@ def switch_case(oracle):
     {"UMX_MFMA16": "0", "UMX_PRECISION": "split"}, {"UMX_MFMA16": "2", "UMX_PRECISION": "split"},
     {"UMX_RADIAL_TR": "1"}, {"UMX_RADIAL_FAST": "2"}, {"UMX_FUSE_MODROT": "0"}, {"UMX_FUSE_MODROT": "0", "UMX_PRECISION": "split"},
     {"UMX_REV_Q3": "0"},                                         # bf16x3 reverse operands in the PL layout (256x128 tiles)
+    {"UMX_GRAD_F32": "0"},                                       # g_rad -> fc3^T as three PL planes instead of float32 rows
     {"UMX_A_F32": "0"}, {"UMX_A_F32": "0", "UMX_PRECISION": "split-bf16"},     # A operands as three pre-split bf16 planes (rounds 2-3) instead of float32 blocks
     {"UMX_FUSED_RADIAL": "0", "UMX_A_F32": "0"}, {"UMX_Q3WIDE": "0", "UMX_A_F32": "0"}, {"UMX_Q3S": "3", "UMX_A_F32": "0"},
     {"UMX_ALT_ROWS": "0"}, {"UMX_ALT_ROWS": "0", "UMX_PRECISION": "split"},     # without the sign-alternating operand rows

@@ -73,7 +73,7 @@ static int pmc_mode(int reps, bool x3 = false) {
       hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 3, 2, 0, 6, 3, 0, 1>), grid(0, 1, 768), dim3(512), 0, 0, mk(3, 1408, 0, 0, 0, 2304, 0, 0, 768, 640));
       hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1, 3, 2, 0, 6, 3, 0, 1>), grid(1, 1, 512), dim3(512), 0, 0, mk(3, 1408, 640, 896, 512, 2304, 768, 1280, 512, 256));
       hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1, 3, 2, 0, 6, 3, 0, 1>), grid(1, 1, 256), dim3(512), 0, 0, mk(3, 1408, 1152, 1280, 256, 2304, 1792, 2048, 256, 128));
-      hipLaunchKernelGGL((umx_gemm_pl16_kernel<0, 3, 2, 4, 2, 2, 2>), grid(0, 0, 128), dim3(512), 0, 0, mk(3, 1536, 0, 0, 0, 128, 0, 0, 128, 1536));
+      { GemmPL qg = mk(3, 1536, 0, 0, 0, 128, 0, 0, 128, 1536); qg.lda = 2L * 1536; hipLaunchKernelGGL((umx_gemm_pl16_kernel<0, 3, 2, 4, 2, 2, 2, 0, 1>), grid(0, 0, 128), dim3(512), 0, 0, qg); }   // g_rad as float32 rows
     }
     CK(hipDeviceSynchronize());
     printf("pmc3 mode: %d x 14 GEMM launches done\n", reps);

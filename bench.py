@@ -21,7 +21,14 @@ Rank 0 prints ONE JSON line (contract in the task statement) carrying
   both passes) are emulation overhead, reported separately as `mfma_pipe_util` (executed FLOPs / peak).
   `traffic` (HBM bytes per launch from rocprofv3 PMC passes) is only emitted when the committed summary under profiles/
   was measured on EXACTLY this build (source digest compiled into libumx.so), else null + `traffic_source` says why;
-* `f16x2b8_mode`: the same workload in the other >= 24-bit mode (opt-in `UMX_PRECISION=f16x2b8`, NOTES.md section 10);
+* `serial_schedule`: since round 5 the engine runs large batches on TWO LANES (two chunks in flight, the matrix segments of one beside
+  the HBM-bound segments of the other; bitwise the same results).  Kernels of different families then overlap, so "the step is the sum
+  of its families" is measured on a side run with `UMX_STREAMS=1`: per-family times, the HBM regime's remainder, and what the lanes buy;
+* `shard`: what ONE rank of the 8-GPU headline run does per iteration -- the 2-image batch through the same evaluator plus the RCCL
+  all-gather of [E | status | F] (a one-rank nccl group here: the collective runs, on this GPU alone) -- driver-timed; the it/s derived
+  from it is a PROJECTION, not a measurement;
+* `--config c1|c2|c4|c5`: the other BASELINE configs through the same evaluator (`config.workload` names them; c4 adds the
+  finite-difference Hessian loop of `uma_pysis.py:595-686` on a bounded sample of its 2 x 3N_active displaced geometries);
 * `fast_mode`: the same workload in the opt-in fast mode (`UMX_PRECISION=split`: 22-23-bit forward activations, 16-bit reverse
   products -- narrower than float32, hence not the headline) and `fp32_mode`: on the fp32 MFMA (`UMX_PRECISION=fp32`), a few
   steps each, timed the same way (N=1 only);
@@ -36,6 +43,10 @@ import json
 import os
 import sys
 import time
+
+# Runtime environment BEFORE anything can initialise HSA / RCCL (an HSA_* variable set after torch.cuda has come up has no effect).
+# dmabuf IPC is the only form this pool's host driver supports; without it RCCL's peer exchange fails with hipIpcGetMemHandle.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch
@@ -126,13 +137,27 @@ def cpu_baseline(edges_per_iter: float, n_atoms: int, n_images: int, budget_s: f
     }
 
 
+CONFIGS = {     # BASELINE.json configs: (atoms, images, what it is)
+    "c1": (50, 8, "c1: 50-atom small molecule, GSM 8 images (BASELINE: plumbing)"),
+    "c2": (500, 12, "c2: ~500-atom active-site cluster, GSM 12 images, 1 GPU"),
+    "c3": (2000, 16, "c3: ~2000-atom active-site cluster, GSM 16 images (the config BASELINE's metric is quoted on)"),
+    "c4": (2000, 24, "c4: ~2000-atom cluster, DMF path_opt 24 images (+ the freq FD Hessian, `hessian` object)"),
+    "c5": (20000, 8, "c5: ~20 000-atom protein-ligand complex, 8 images (one image per chunk on one GPU; one image per GPU on the node)"),
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--atoms", type=int, default=2000)
-    ap.add_argument("--images", type=int, default=16)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3", help="BASELINE config (default c3, the headline); --atoms / --images override its sizes")
+    ap.add_argument("--atoms", type=int, default=None)
+    ap.add_argument("--images", type=int, default=None)
+    ap.add_argument("--no-shard", action="store_true", help="skip the `shard` leg (2-image batch + one-rank RCCL all-gather)")
+    ap.add_argument("--shard-steps", type=int, default=20)
+    ap.add_argument("--no-serial", action="store_true", help="skip the `serial_schedule` side run (UMX_STREAMS=1)")
+    ap.add_argument("--hessian-sample-atoms", type=int, default=100, help="c4: atoms whose 3 DOF columns the FD-Hessian sample builds (2 x 3 x this many displaced geometries)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-mode", action="store_true")
     ap.add_argument("--no-fast-mode", action="store_true")
@@ -143,6 +168,11 @@ def main():
     ap.add_argument("--fp32-steps", type=int, default=5)
     ap.add_argument("--fp32-warmup", type=int, default=2)
     args = ap.parse_args()
+    if args.atoms is None:
+        args.atoms = CONFIGS[args.config][0]
+    if args.images is None:
+        args.images = CONFIGS[args.config][1]
+    headline = args.config == "c3" and args.atoms == 2000 and args.images == 16
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -158,7 +188,6 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -174,21 +203,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def make_engine(precision: str):
+    def make_engine(precision: str, lanes: str = ""):
         os.environ["UMX_PRECISION"] = precision              # read by umx_load_weights
-        eng = Engine(local_rank)
+        if lanes:
+            os.environ["UMX_STREAMS"] = lanes                # read by umx_create ("" = the engine's own choice)
+        try:
+            eng = Engine(local_rank)
+        finally:
+            if lanes:
+                os.environ.pop("UMX_STREAMS", None)
         eng.load_weights(weights)
         eng.set_system(z, charge=0, spin=1, task="omol")
         return eng
 
-    def run(precision: str, steps: int, warmup: int):
-        """W untimed + K timed string iterations on a fresh engine in `precision` mode; returns (dt, profile, edges, maxdeg, resolved mode)."""
-        eng = make_engine(precision)
-        x = torch.as_tensor(imgs * ANG2BOHR, dtype=torch.float64, device=dev).reshape(k, -1)   # string state: Bohr, float64, in HBM
+    def run(precision: str, steps: int, warmup: int, lanes: str = "", images=None, force_collective: bool = False):
+        """W untimed + K timed string iterations on a fresh engine in `precision` mode; returns (dt, profile, edges, maxdeg, resolved mode).
+        `images`: another batch of the same system (the 2-image shard); `force_collective`: issue the all-gather in a one-rank group too."""
+        eng = make_engine(precision, lanes)
+        imgs_run = imgs if images is None else images
+        k = len(imgs_run)
+        x = torch.as_tensor(imgs_run * ANG2BOHR, dtype=torch.float64, device=dev).reshape(k, -1)   # string state: Bohr, float64, in HBM
         # the device evaluator of parallel.py: float32 Angstrom positions into the engine's device-pointer entry on torch's current stream,
         # frozen rows zeroed, Hartree / Bohr out, the k images sharded over the ranks + ONE all-gather.  check="deferred": the gathered
         # energies are checked on the device and the flag is read behind the engine's own per-call synchronisation (no extra host sync)
-        ev = EngineStringEvaluator(eng, n, dev, frozen=frozen, check="deferred", max_images=kl_max)
+        ev = EngineStringEvaluator(eng, n, dev, frozen=frozen, check="deferred", max_images=(kl_max if images is None else k), force_collective=force_collective)
 
         def step(xc):
             e, f = ev(xc)
@@ -211,8 +249,9 @@ def main():
         if not bool(torch.isfinite(e).all()) or eng.widened:
             raise SystemExit("bench.py: non-finite energies / a precision change inside the timed region")
         resolved = eng.precision_mode()
+        lanes_used = eng.last_lanes()
         eng.close()
-        return dt, prof, ne_local, maxdeg, resolved
+        return dt, prof, ne_local, maxdeg, resolved, lanes_used
 
     def run_gsm(precision: str, cycles: int, warmup: int):
         """The REAL driver: `gsm.GrowingStringDriver` on a fully grown k-image string (reference construction:
@@ -272,8 +311,47 @@ def main():
                        "the share it would have of a cycle of the 8-GPU run (the string update is replicated on every rank)")
         return res
 
+    def run_hessian(precision: str, sample_atoms: int):
+        """c4's "freq Hessian (3N force batches)" (uma_pysis.py:595-686: 2 central-difference force calls per active DOF, h = 1e-3 A): the batched
+        loop `hessian.fd_hessian` on a BOUNDED sample -- the columns of `sample_atoms` atoms (every other atom frozen for the sample, which
+        changes the number of columns, not the cost of one: each displaced geometry is a full 2000-atom E+F) -- and the extrapolation to the
+        5940 active columns of the config (20 frozen atoms), stated as such."""
+        from pdb2reaction_amd.hessian import fd_hessian
+
+        eng = make_engine(precision)
+        sample = list(range(0, n, max(1, n // sample_atoms)))[:sample_atoms]
+        frz = sorted(set(range(n)) - set(sample))
+        x0 = imgs[k // 2]
+        calls = {"n": 0, "geoms": 0}
+
+        def batch_forces(disp):
+            calls["n"] += 1
+            calls["geoms"] += len(disp)
+            return eng.energy_forces(disp)[1]
+
+        eng.reserve_images(64)
+        batch_forces(np.repeat(x0[None], 64, axis=0))                     # warm-up: workspace for 64-image batches
+        calls.update(n=0, geoms=0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        h = fd_hessian(batch_forces, x0, frz, device=dev, double=True, partial=False, batch=64, engine=eng)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ne, _ = eng.graph_stats()
+        ok = bool(torch.isfinite(h).all())
+        eng.close()
+        cols = 3 * len(sample)
+        full_cols = 3 * (n - len(frozen))
+        return {"columns": cols, "displaced_geometries": calls["geoms"], "engine_calls": calls["n"], "seconds": dt, "columns_per_s": cols / dt,
+                "ms_per_displaced_geometry": dt / calls["geoms"] * 1e3, "finite": ok, "batch": 64,
+                "full_hessian_columns": full_cols, "extrapolated_full_hessian_s": full_cols / (cols / dt),
+                "algorithmic_tflops": FLOP_PER_EDGE * (ne / 64.0) * calls["geoms"] / dt / 1e12,
+                "note": f"hessian.fd_hessian (host-pointer entry: PCIe copies of 64 x {n} x 3 floats per call included), {cols} columns = {calls['geoms']} displaced "
+                        f"{n}-atom geometries in batches of 64; extrapolated_full_hessian_s scales columns/s to the {full_cols} active columns of c4 "
+                        "(an extrapolation of the same loop, not a second measurement)"}
+
     mode_req = os.environ.get("UMX_PRECISION", "auto")           # "auto" = bf16x3: >= 24-bit products in both passes (include/umx.h)
-    dt, prof, ne_local, maxdeg, resolved = run(mode_req, args.steps, args.warmup)
+    dt, prof, ne_local, maxdeg, resolved, lanes_used = run(mode_req, args.steps, args.warmup)
     mode = {"split-f16": "split", "split-bf16": "split-bf16", "bf16x3": "bf16x3", "f16x2b8": "f16x2b8", "fp32": "fp32"}[resolved]
     tt = torch.tensor([dt, float(ne_local)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
@@ -306,7 +384,7 @@ def main():
         peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
         alg = dom["alg_flops"] / max(dom["ms"], 1e-9) / 1e9          # algorithmic TFLOP/s of the dominant family (2*M*N*K per product)
         executed = dom["mfma_flops"] / max(dom["ms"], 1e-9) / 1e9    # what the matrix cores executed (the plane products of the split)
-        pmc, pmc_note = pmc_summary(digest, mode) if (n == 2000 and k == 16 and world == 1 and split) else (None, "PMC summary exists for c3 / 1 GPU / split modes only")
+        pmc, pmc_note = pmc_summary(digest, mode) if (headline and world == 1 and split) else (None, "PMC summary exists for c3 / 1 GPU / split modes only")
         out = {
             "metric": "path_opt_string_iterations_per_s", "value": it_s, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -317,9 +395,10 @@ def main():
             "image_atom_steps_per_s": k * n * it_s,
             "algorithmic_tflops": FLOP_PER_EDGE * edges_iter * it_s / 1e12,
             "build_digest": digest,
-            "config": {"workload": f"c3: {n}-atom synthetic active-site cluster x {k} images, GSM-style string iteration "
-                                   f"(batched UMA-S E+F of all images + string update), UMA-S shapes, synthetic weights",
-                       "atoms": n, "images": k, "directed_edges_per_iteration": int(edges_iter), "max_degree": maxdeg,
+            "config": {"workload": f"{CONFIGS[args.config][2] if (n, k) == CONFIGS[args.config][:2] else args.config + ' (sizes overridden)'}: {n}-atom synthetic "
+                                   f"active-site cluster x {k} images, GSM-style string iteration (batched UMA-S E+F of all images + string update), "
+                                   f"UMA-S shapes, synthetic weights",
+                       "name": args.config, "atoms": n, "images": k, "directed_edges_per_iteration": int(edges_iter), "max_degree": maxdeg,
                        "parallelism": f"images sharded {k}/{world} per GPU, 1 all-gather/iteration" if world > 1 else "single GPU, all images batched"},
             "roofline": {"bound": "mfma", "achieved": alg, "peak": peak, "unit": "TFLOP/s", "frac": alg / peak,
                          "definition": "achieved = algorithmic FLOPs (2*M*N*K per product, SURVEY.md 8d) of the family / its HIP-event time; "
@@ -341,13 +420,37 @@ def main():
         # second regime: the HBM-bound gather / rotate / gate / segmented-reduce kernels.  Everything outside the two GEMM
         # families is timed as the remainder of the step; the fused radial-MLP kernels (VALU / fp32-MFMA bound, not HBM bound) are timed
         # live as their own family (ABI v7) and taken OUT of the HBM figure, so that `achieved` is not a blend of two bounds.
-        rad = prof["radial"]
-        rad_ms = rad["ms"] / args.steps
-        rest_ms = ms - (dom["ms"] + (f32["ms"] if split else 0.0)) / args.steps
+        # Two lanes (the engine's choice for large batches since round 5) overlap kernels of different families, so the remainder of the
+        # step is no longer "the other kernels": the family breakdown comes from a serial-schedule side run (UMX_STREAMS=1) of the same
+        # workload, the headline stays what the product does by default.
+        two_lanes = lanes_used == 2
+        ser = None
+        if world == 1 and two_lanes and not args.no_serial:
+            try:
+                sdt, sprof, _, _, _, _ = run(mode_req, max(2, min(args.steps, 5)), 1, lanes="1")
+                ssteps = max(2, min(args.steps, 5))
+                ser = {"ms_per_step": sdt / ssteps * 1e3, "steps": ssteps, "prof": sprof}
+            except Exception as exc:
+                out["serial_schedule"] = {"error": f"{type(exc).__name__}: {exc}"}
+        bprof, bsteps, bms = (ser["prof"], ser["steps"], ser["ms_per_step"]) if ser else (prof, args.steps, ms)
+        bdom = bprof["split_bf16"] if split else bprof["fp32"]
+        bf32 = bprof["fp32"]
+        rad = bprof["radial"]
+        rad_ms = rad["ms"] / bsteps
+        rest_ms = bms - (bdom["ms"] + (bf32["ms"] if split else 0.0)) / bsteps
         edge_ms = rest_ms - rad_ms
+        if ser:
+            out["serial_schedule"] = {"ms_per_step": bms, "steps": bsteps, "gemm_family_ms_per_step": bdom["ms"] / bsteps, "node_gemm_ms_per_step": bf32["ms"] / bsteps if split else 0.0,
+                                      "radial_ms_per_step": rad_ms, "hbm_regime_ms_per_step": edge_ms, "two_lane_gain_ms": bms - ms,
+                                      "gemm_family_tflops": bdom["alg_flops"] / max(bdom["ms"], 1e-9) / 1e9,
+                                      "note": "UMX_STREAMS=1 side run of the same workload: one lane, kernels strictly one after another, so the step is the plain sum of its "
+                                              "families (roofline.hbm_regime is taken from it); the headline above is the engine's default schedule (two lanes for this batch size, "
+                                              "bitwise the same results)"}
+        out["roofline"]["lanes"] = lanes_used
         hb = {"bound": "hbm", "kernels": "HBM-bound edge / node kernels: k_gather_rotate_mod_q3, k_modrot_bwd_pl, k_gate_edge_*, k_rotate_back_*, norms, graph build "
                                          "(everything outside the GEMM families and the fused radial-MLP kernels)",
-              "ms_per_step": edge_ms, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "traffic_per_step": None, "achieved": None, "frac": None,
+              "ms_per_step": edge_ms, "schedule": "serial side run (UMX_STREAMS=1)" if ser else "the timed region (one lane)",
+              "peak": PEAK_HBM_GBPS, "unit": "GB/s", "traffic_per_step": None, "achieved": None, "frac": None,
               "traffic_source": pmc_note,
               "radial": {"kernels": "k_radial_head / k_radial_tail (fused radial-MLP layers: libm-accurate VALU transcendentals + fp32 MFMA)", "bound": "valu/mfma-f32",
                          "ms_per_step": rad_ms, "launches": rad["launches"], "achieved": rad["alg_flops"] / max(rad["ms"], 1e-9) / 1e9, "unit": "TFLOP/s",
@@ -366,7 +469,7 @@ def main():
 
         def side_mode(name: str, steps: int, warmup: int, fam: str, peak_tf: float, detail: str):
             try:
-                dts, profs, _, _, res_mode = run(name, steps, warmup)
+                dts, profs, _, _, res_mode, _ = run(name, steps, warmup)
                 gg = profs[fam]
                 return {"value": steps / dts, "unit": "iterations/s", "ms_per_step": dts / steps * 1e3, "steps": steps, "warmup": warmup,
                         "precision_mode": res_mode, "dtype": detail, "gemm_ms_per_step": gg["ms"] / steps,
@@ -381,21 +484,44 @@ def main():
             # reference's float32, so it is NOT the headline; tolerances are met with margin (tests/test_gpu_baseline_sizes.py)
             out["fast_mode"] = side_mode("split", args.fp32_steps, args.fp32_warmup, "split_bf16", PEAK_BF16_MFMA_TFLOPS,
                                          "f16-split (fwd 2 x 3 fp16 planes / 4 products, reverse 2 x 2 bf16 planes / 3 products): narrower than float32")
-        if world == 1 and not args.no_fast_mode and mode == "bf16x3":
-            # a second >= 24-bit mode (opt-in): the forward GEMMs' two 2^-22-order plane products on the block-scaled bf8 matrix instruction
-            out["f16x2b8_mode"] = side_mode("f16x2b8", args.fp32_steps, args.fp32_warmup, "split_bf16", PEAK_BF16_MFMA_TFLOPS,
-                                            "forward: 2 fp16 + 2 bf8 activation planes x 3 exact fp16 + 2 bf8 weight planes, 4 fp16 products + 2 bf8 products "
-                                            "(>= 24-bit products in 5 instruction slots); reverse as bf16x3")
         if world == 1 and split and not args.no_fp32_mode:
             # every GEMM on v_mfma_f32_32x32x2_f32: the same float32 products as the headline mode's, on the fp32 matrix pipe
             out["fp32_mode"] = side_mode("fp32", args.fp32_steps, args.fp32_warmup, "fp32", PEAK_FP32_MFMA_TFLOPS, "f32 (all GEMMs on v_mfma_f32_32x32x2_f32)")
         os.environ["UMX_PRECISION"] = mode_req
+        if world == 1 and headline and not args.no_shard:
+            # what ONE rank of the 8-GPU run does per iteration (BASELINE c3: "16 images sharded 2-images/GPU across 8 x MI355X"): the 2-image batch
+            # through the same evaluator + the all-gather, issued for real on a one-rank RCCL group (nccl backend; the identity, but the call, its
+            # stream ordering and its latency are there).  Driver-timed; any it/s derived from it is a projection of the 8-GPU run, not a measurement.
+            try:
+                own_group = False
+                if not dist.is_initialized():
+                    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29400 + os.getpid() % 500}", rank=0, world_size=1, device_id=dev)
+                    own_group = True
+                sdt, _, se, _, _, _ = run(mode_req, args.shard_steps, 3, images=imgs[:2], force_collective=True)
+                sdt0, _, _, _, _, _ = run(mode_req, args.shard_steps, 3, images=imgs[:2], force_collective=False)
+                if own_group:
+                    dist.destroy_process_group()
+                sms = sdt / args.shard_steps * 1e3
+                out["shard"] = {"ms_per_step": sms, "steps": args.shard_steps, "warmup": 3, "images": 2, "directed_edges": int(se),
+                                "ms_per_step_without_collective": sdt0 / args.shard_steps * 1e3,
+                                "collective": "all_gather_into_tensor of [E | status | F] float64 rows on a ONE-rank nccl (RCCL) group, every step",
+                                "projected_8gpu_iterations_per_s": 1e3 / sms,
+                                "note": "the per-rank share of the 8-GPU headline (2 of the 16 images + the gather + the replicated string step), timed like the "
+                                        "headline; projected_8gpu_iterations_per_s = 1 / this is a PROJECTION (xGMI all-gather latency of 8 ranks and rank skew "
+                                        "are not in it), not a measurement -- RCCL has never run on more than one rank here"}
+            except Exception as exc:
+                out["shard"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if world == 1 and args.config == "c4":
+            try:
+                out["hessian"] = run_hessian(mode_req, args.hessian_sample_atoms)
+            except Exception as exc:
+                out["hessian"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and args.driver == "gsm":
             try:
                 out["gsm"] = run_gsm(mode_req, args.gsm_cycles, 3)
             except Exception as exc:
                 out["gsm"] = {"error": f"{type(exc).__name__}: {exc}"}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "c3":
             try:
                 out["cpu_baseline"] = cpu_baseline(edges_iter, n, k)
             except Exception as exc:  # the baseline is informative; never lose the GPU numbers to it

@@ -88,6 +88,21 @@ const char* umx_last_error(const umx_engine* eng);
 #define UMX_ENERGY_TOL_EV_FP32(n_atoms) ((n_atoms) * 2.98023223876953125e-8 > 1.0e-4 ? (n_atoms) * 2.98023223876953125e-8 : 1.0e-4)
 int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes);
 
+/* MODEL VARIANTS (ABI v10).  The blob's tensors decide which of the forms SURVEY.md (section 2.4 K8, Appendix A) lists as possible for the
+ * checkpoint that pretrained_mlip.get_predict_unit("uma-s-1p1") returns (uma_pysis.py:246-250) is evaluated -- [3P-UNVERIFIED] names:
+ *   K8 feed-forward:  blocks.<i>.atom_wise.{scalar_mlp, so3_linear_1, so3_linear_2}.*  -> SpectralAtomwise (ff_type = "spectral");
+ *                     blocks.<i>.atom_wise.grid_mlp.{0,2,4}.weight (128 x 128, optional .bias) + so3_grid.to_grid_mat / from_grid_mat
+ *                     (G <= 128 rows x 9 coefficients, l-primary order l*l+l+m; the buffers of the checkpoint's SO3_Grid, taken as data)
+ *                     -> GridAtomwise (ff_type = "grid"): to-grid, point-wise Linear-SiLU-Linear-SiLU-Linear, from-grid;
+ *   charge / spin embedding:  {charge,spin}_embedding.weight (201 / 101 x 128 lookup tables)      -> chg_spin_emb_type = "rand_emb";
+ *                     {charge,spin}_embedding.W (64 frequencies: [sin(2 pi v W) | cos(2 pi v W)], null spin 0 -> 0)  -> "pos_emb";
+ *                     {charge,spin}_embedding.lin_emb.{weight (128 x 1), bias}  (null spin 0 -> -100)               -> "lin_emb";
+ *   datasets:         dataset_embedding.weight with 1..32 rows in the ORDER OF THE CHECKPOINT's dataset_list (umx_set_system's task_index
+ *                     is a row of it; the Python side maps task names through the list in the blob trailer), or absent with a
+ *                     mix_csd.weight of 128 x 256 (use_dataset_embedding = False).
+ * umx_model_variant: "ff=spectral|grid(G=..);emb=rand_emb|pos_emb|lin_emb;datasets=N" of the loaded blob ("" before).                 */
+const char* umx_model_variant(const umx_engine* eng);
+
 /* Precision mode for the NEXT umx_load_weights ("auto", "bf16x3" (= "split-exact"), "split" (= "split-f16"), "split-bf16", "f16x2b8", "fp32"); NULL or "" = back to
  * the UMX_PRECISION environment variable.  The Python binding uses it to re-load an engine in split-bf16 when an evaluation
  * returned UMX_ERR_RANGE (ABI v6).                                                                                   */
@@ -98,7 +113,8 @@ int umx_set_precision(umx_engine* eng, const char* mode);
 const char* umx_precision_mode(const umx_engine* eng);
 
 /* Bind the chemical system shared by every image: atomic numbers, total charge, spin
- * multiplicity, task ("dataset") index into {oc20, omol, omat, odac, omc}; cutoff radius in
+ * multiplicity, task ("dataset") index = row of the blob's dataset_embedding.weight ({oc20, omol, omat, odac, omc} for UMA's
+ * dataset_list; ignored by a model without dataset embedding); cutoff radius in
  * Angstrom (<=0: model default 6.0) and neighbour cap (<=0: model default 300).
  * Replaces: UMAcore.__init__ elem/charge/spin/task (uma_pysis.py:266-273) and the per-call
  * AtomicData.from_ase(...)/data.dataset/collate of _ase_to_batch (uma_pysis.py:312-322).       */
@@ -166,6 +182,12 @@ int umx_last_graph_stats(const umx_engine* eng, int64_t* n_edges_total, int32_t*
  * (~72 KB per edge) and share one region for the GEMM operands, with the graph-parallel plan's exchange points summed locally (ABI v7);
  * beyond that -- ~1.5x the atoms -- UMX_ERR_CAPACITY names the multi-GPU graph-parallel mode.                                    */
 int umx_last_partitions(const umx_engine* eng);
+
+/* Lanes of the most recent evaluation (ABI v10): 2 = two chunks of images were in flight on two streams, the large-GEMM segments of one
+ * beside the HBM-bound segments of the other (the engine's choice for batches of >= 1.2 M directed edges whose largest image fits half the
+ * workspace budget; UMX_STREAMS=1 / 2 forces it); results are bitwise those of one lane.  Kernel families then overlap in time, so
+ * per-family times no longer add up to the step (bench.py measures them on a UMX_STREAMS=1 side run).                                */
+int umx_last_lanes(const umx_engine* eng);
 
 /* Workspace hint (ABI v8): the caller expects batches of up to `n_images` images of the bound system.  The workspace grows with the largest
  * batch seen, and every growth is a release + allocation of the whole region, which the driver clears at ~50 ms per GiB (2 s for the 43 GiB of

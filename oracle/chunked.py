@@ -135,15 +135,9 @@ class ChunkedForces:
                     agg.index_add_(0, g["dst"], torch.bmm(g["wig"].transpose(1, 2), msg * g["env"][:, None, None]))
                 xmid = xin + agg
                 xn2 = O.rms_norm_sh(xmid, p[f"{b}.norm_2.affine_weight"], p[f"{b}.norm_2.affine_bias"])
-                gs_pre = xn2[:, 0, :] @ p[f"{pa}.scalar_mlp.weight"].T + p[f"{pa}.scalar_mlp.bias"]
-                h1 = torch.einsum("nmi,moi->nmo", xn2, p[f"{pa}.so3_linear_1.weight"][L_OF_LP])
-                h1 = torch.cat([h1[:, 0:1] + p[f"{pa}.so3_linear_1.bias"][None, None], h1[:, 1:]], dim=1)
-                sg = torch.sigmoid(O.silu(gs_pre)).reshape(n, W.LMAX, H)
-                hg = torch.cat([O.silu(h1[:, 0:1]), h1[:, 1:] * sg[:, L_OF_LP[1:] - 1]], dim=1)
-                o2 = torch.einsum("nmi,moi->nmo", hg, p[f"{pa}.so3_linear_2.weight"][L_OF_LP])
-                o2 = torch.cat([o2[:, 0:1] + p[f"{pa}.so3_linear_2.bias"][None, None], o2[:, 1:]], dim=1)
+                o2, saved = ST.atomwise_fwd(p, pa, xn2)
                 x = xmid + o2
-                keep.append(dict(xin=xin, xn=xn, xmid=xmid, gspre=gs_pre, ffh=h1, x=x))
+                keep.append(dict(xin=xin, xn=xn, xmid=xmid, ff=saved, x=x))
                 if log:
                     log(f"forward layer {i} done")
             xf = O.rms_norm_sh(x, p["norm.affine_weight"], p["norm.affine_bias"])
@@ -163,17 +157,7 @@ class ChunkedForces:
                 b = f"blocks.{i}"
                 pa = f"{b}.atom_wise"
                 k = keep[i]
-                g_hg = torch.einsum("nmo,moi->nmi", g_x, p[f"{pa}.so3_linear_2.weight"][L_OF_LP])
-                h1, gs_pre = k["ffh"], k["gspre"]
-                gs = O.silu(gs_pre)
-                sg = torch.sigmoid(gs)
-                sgx = sg.reshape(n, W.LMAX, H)[:, L_OF_LP[1:] - 1]
-                g_h1 = torch.cat([g_hg[:, 0:1] * ST.silu_grad(h1[:, 0:1]), g_hg[:, 1:] * sgx], dim=1)
-                prod = g_hg[:, 1:] * h1[:, 1:]
-                g_sg = torch.stack([prod[:, 0:3].sum(1), prod[:, 3:8].sum(1)], dim=1).reshape(n, W.LMAX * H)
-                g_gspre = g_sg * sg * (1 - sg) * ST.silu_grad(gs_pre)
-                g_xn2 = torch.einsum("nmo,moi->nmi", g_h1, p[f"{pa}.so3_linear_1.weight"][L_OF_LP])
-                g_xn2[:, 0, :] = g_xn2[:, 0, :] + g_gspre @ p[f"{pa}.scalar_mlp.weight"]
+                g_xn2 = ST.atomwise_bwd(p, pa, g_x, k["ff"])
                 g_xmid = g_x + ST.norm_bwd(g_xn2, k["xmid"], p[f"{b}.norm_2.affine_weight"])
                 g_xn = torch.zeros(n, S, C, dtype=self.dtype)
                 c2 = 2 * C

@@ -16,7 +16,7 @@ and independence from the choice of edge-frame roll angle.
 Stage map:  K1 radius graph -> :func:`radius_graph`;  K2 edge frames /
 Wigner-D -> :func:`edge_rotation`, :func:`wigner_blocks`;  K3 edge scalars -> :func:`edge_scalars`;
 K4 node init;  K5 edge-degree embedding;  K6 RMS-norm-SH -> :func:`rms_norm_sh`;  K7 Edgewise ->
-:func:`so2_conv`, :func:`edgewise`;  K8 spectral atom-wise FF -> :func:`atomwise`;  K9 energy
+:func:`so2_conv`, :func:`edgewise`;  K8 atom-wise FF (spectral or grid) -> :func:`atomwise`, :func:`grid_atomwise`;  K9 energy
 readout;  K10 forces by autograd;  K11 normaliser + element references.
 
 Conventions (ours; any consistent real-SH convention yields the same E/F because the SO(2)
@@ -200,8 +200,28 @@ def gate_m_primary(gate: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return torch.cat([silu(x[:, 0:1, :]), x[:, 1:, :] * g[:, l_of, :]], dim=1)
 
 
+def grid_atomwise(p, prefix: str, x: torch.Tensor) -> torch.Tensor:
+    """K8, ``ff_type = "grid"`` ([3P-UNVERIFIED]): GridAtomwise = project the coefficients
+    onto the S2 grid (``to_grid_mat`` (G,9): x_grid[n,g,c] = sum_i T[g,i] x[n,i,c]), a point-wise 3-layer SiLU MLP over the channels
+    (C -> H -> H -> C, bias-free in fairchem; a bias tensor is honoured when the weight set carries one), project back
+    (``from_grid_mat`` (G,9): y[n,i,c] = sum_g F[g,i] o[n,g,c]).  The two matrices are DATA of the weight set (buffers of the
+    checkpoint's SO3_Grid), never restated here."""
+    tg, fg = p["so3_grid.to_grid_mat"], p["so3_grid.from_grid_mat"]
+    h = torch.einsum("gi,nic->ngc", tg, x)
+    for k, li in enumerate((0, 2, 4)):
+        h = h @ p[f"{prefix}.grid_mlp.{li}.weight"].T
+        if f"{prefix}.grid_mlp.{li}.bias" in p:
+            h = h + p[f"{prefix}.grid_mlp.{li}.bias"]
+        if k < 2:
+            h = silu(h)
+    return torch.einsum("gi,ngc->nic", fg, h)
+
+
 def atomwise(p, prefix: str, x: torch.Tensor) -> torch.Tensor:
-    """K8: SpectralAtomwise = scalar MLP gates, SO3_Linear -> gate -> SO3_Linear (l-primary)."""
+    """K8: the atom-wise feed-forward of the weight set -- GridAtomwise when it carries ``grid_mlp`` tensors, else
+    SpectralAtomwise = scalar MLP gates, SO3_Linear -> gate -> SO3_Linear (l-primary)."""
+    if f"{prefix}.grid_mlp.0.weight" in p:
+        return grid_atomwise(p, prefix, x)
     n = x.shape[0]
     l_of = torch.tensor(W.L_OF_LP)
     gs = silu(x[:, 0, :] @ p[f"{prefix}.scalar_mlp.weight"].T + p[f"{prefix}.scalar_mlp.bias"])
@@ -223,8 +243,12 @@ class Oracle:
     """UMA-S forward / forces for ONE system (the reference evaluates one image per call)."""
 
     def __init__(self, weights: Dict[str, np.ndarray], dtype=torch.float64, cutoff: float = W.CUTOFF,
-                 max_neigh: Optional[int] = W.MAX_NEIGHBORS):
+                 max_neigh: Optional[int] = W.MAX_NEIGHBORS, dataset_list=None):
+        """``dataset_list``: the order of the rows of ``dataset_embedding.weight`` (the checkpoint's ``dataset_list``); default: the
+        weight set's own record (``weights.meta["model"]["dataset_list"]``) or the UMA order of tables.py."""
         self.dtype = dtype
+        meta = (getattr(weights, "meta", None) or {}).get("model") or {}
+        self.dataset_list = tuple(dataset_list or meta.get("dataset_list") or W.DATASET_LIST)
         self.cutoff = float(cutoff)
         self.max_neigh = max_neigh
         self.p = {k: torch.as_tensor(np.asarray(v), dtype=dtype) for k, v in weights.items()}
@@ -238,11 +262,27 @@ class Oracle:
         gauss = torch.exp(coeff * (dist[:, None] - mu[None, :]) ** 2)
         return torch.cat([gauss, self.p["source_embedding.weight"][z_src], self.p["target_embedding.weight"][z_dst]], dim=1)
 
+    def charge_spin_embedding(self, which: str, value: int):
+        """ChgSpinEmbedding (fairchem ``chg_spin_emb_type`` [3P-UNVERIFIED]) -- the form is read off the
+        tensors the weight set carries: ``rand_emb`` = a lookup table indexed by charge + 100 / by the multiplicity;
+        ``pos_emb`` = [sin(2 pi v W), cos(2 pi v W)] with a fixed frequency vector W (C/2), the null spin 0 embedding to zero;
+        ``lin_emb`` = Linear(1 -> C) of the value (null spin 0 -> -100)."""
+        p = self.p
+        if f"{which}_embedding.W" in p:
+            ang = 2.0 * math.pi * float(value) * p[f"{which}_embedding.W"]
+            emb = torch.cat([torch.sin(ang), torch.cos(ang)])
+            return torch.zeros_like(emb) if (which == "spin" and value == 0) else emb
+        if f"{which}_embedding.lin_emb.weight" in p:
+            v = -100.0 if (which == "spin" and value == 0) else float(value)
+            return p[f"{which}_embedding.lin_emb.weight"][:, 0] * v + p[f"{which}_embedding.lin_emb.bias"]
+        return p[f"{which}_embedding.weight"][value + (W.CHARGE_OFFSET if which == "charge" else 0)]
+
     def system_embedding(self, charge: int, spin: int, task: str):
         p = self.p
-        v = torch.cat([p["charge_embedding.weight"][charge + W.CHARGE_OFFSET], p["spin_embedding.weight"][spin],
-                       p["dataset_embedding.weight"][W.DATASET_LIST.index(task)]])
-        return silu(p["mix_csd.weight"] @ v + p["mix_csd.bias"])
+        parts = [self.charge_spin_embedding("charge", charge), self.charge_spin_embedding("spin", spin)]
+        if "dataset_embedding.weight" in p:          # (use_dataset_embedding = False: mix_csd takes [charge | spin] only)
+            parts.append(p["dataset_embedding.weight"][self.dataset_list.index(task)])
+        return silu(p["mix_csd.weight"] @ torch.cat(parts) + p["mix_csd.bias"])
 
     # -- forward ----------------------------------------------------------------------------------
     def model_energy(self, z: torch.Tensor, pos: torch.Tensor, charge=0, spin=1, task="omol",

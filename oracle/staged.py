@@ -71,6 +71,52 @@ def norm_bwd(g_y, x, aw):
     return torch.cat([g0, g_feat[:, 1:, :]], dim=1)
 
 
+# ---- K8 atom-wise feed-forward with its hand-derived reverse (spectral = SO3_Linear -> gate -> SO3_Linear; grid = to-grid ->
+#      point-wise SiLU MLP -> from-grid).  Shared by Staged and oracle/chunked.py; `saved` holds what the reverse pass needs.
+def atomwise_fwd(p, pa: str, xn2: torch.Tensor):
+    n = xn2.shape[0]
+    if f"{pa}.grid_mlp.0.weight" in p:
+        tg = p["so3_grid.to_grid_mat"]
+        bias = [p.get(f"{pa}.grid_mlp.{li}.bias") for li in (0, 2, 4)]
+        g1 = torch.einsum("gi,nic->ngc", tg, xn2) @ p[f"{pa}.grid_mlp.0.weight"].T
+        g1 = g1 if bias[0] is None else g1 + bias[0]
+        g2 = O.silu(g1) @ p[f"{pa}.grid_mlp.2.weight"].T
+        g2 = g2 if bias[1] is None else g2 + bias[1]
+        g3 = O.silu(g2) @ p[f"{pa}.grid_mlp.4.weight"].T
+        g3 = g3 if bias[2] is None else g3 + bias[2]
+        return torch.einsum("gi,ngc->nic", p["so3_grid.from_grid_mat"], g3), dict(ffg1=g1, ffg2=g2)
+    gs_pre = xn2[:, 0, :] @ p[f"{pa}.scalar_mlp.weight"].T + p[f"{pa}.scalar_mlp.bias"]
+    h1 = torch.einsum("nmi,moi->nmo", xn2, p[f"{pa}.so3_linear_1.weight"][L_OF_LP])
+    h1 = torch.cat([h1[:, 0:1] + p[f"{pa}.so3_linear_1.bias"][None, None], h1[:, 1:]], dim=1)
+    sg = torch.sigmoid(O.silu(gs_pre)).reshape(n, W.LMAX, H)
+    hg = torch.cat([O.silu(h1[:, 0:1]), h1[:, 1:] * sg[:, L_OF_LP[1:] - 1]], dim=1)
+    o2 = torch.einsum("nmi,moi->nmo", hg, p[f"{pa}.so3_linear_2.weight"][L_OF_LP])
+    o2 = torch.cat([o2[:, 0:1] + p[f"{pa}.so3_linear_2.bias"][None, None], o2[:, 1:]], dim=1)
+    return o2, dict(gspre=gs_pre, ffh=h1, ffhg=hg)
+
+
+def atomwise_bwd(p, pa: str, g_o: torch.Tensor, saved) -> torch.Tensor:
+    """dE/d(xn2) from dE/d(atom-wise output) (N,9,C)."""
+    n = g_o.shape[0]
+    if "ffg1" in saved:
+        g3 = torch.einsum("gi,nic->ngc", p["so3_grid.from_grid_mat"], g_o)
+        g2 = (g3 @ p[f"{pa}.grid_mlp.4.weight"]) * silu_grad(saved["ffg2"])
+        g1 = (g2 @ p[f"{pa}.grid_mlp.2.weight"]) * silu_grad(saved["ffg1"])
+        return torch.einsum("gi,ngc->nic", p["so3_grid.to_grid_mat"], g1 @ p[f"{pa}.grid_mlp.0.weight"])
+    g_hg = torch.einsum("nmo,moi->nmi", g_o, p[f"{pa}.so3_linear_2.weight"][L_OF_LP])
+    h1, gs_pre = saved["ffh"], saved["gspre"]
+    gs = O.silu(gs_pre)
+    sg = torch.sigmoid(gs)
+    sgx = sg.reshape(n, W.LMAX, H)[:, L_OF_LP[1:] - 1]
+    g_h1 = torch.cat([g_hg[:, 0:1] * silu_grad(h1[:, 0:1]), g_hg[:, 1:] * sgx], dim=1)
+    prod = g_hg[:, 1:] * h1[:, 1:]
+    g_sg = torch.stack([prod[:, 0:3].sum(1), prod[:, 3:8].sum(1)], dim=1).reshape(n, W.LMAX * H)
+    g_gspre = g_sg * sg * (1 - sg) * silu_grad(gs_pre)
+    g_xn2 = torch.einsum("nmo,moi->nmi", g_h1, p[f"{pa}.so3_linear_1.weight"][L_OF_LP])
+    g_xn2[:, 0, :] = g_xn2[:, 0, :] + g_gspre @ p[f"{pa}.scalar_mlp.weight"]
+    return g_xn2
+
+
 class Staged:
     def __init__(self, weights: Dict[str, np.ndarray], dtype=torch.float64, cutoff=W.CUTOFF):
         self.o = O.Oracle(weights, dtype=dtype, cutoff=cutoff)
@@ -152,15 +198,11 @@ class Staged:
             # atomwise
             pa = f"{b}.atom_wise"
             xn2 = O.rms_norm_sh(x, p[f"{b}.norm_2.affine_weight"], p[f"{b}.norm_2.affine_bias"])
-            gs_pre = xn2[:, 0, :] @ p[f"{pa}.scalar_mlp.weight"].T + p[f"{pa}.scalar_mlp.bias"]
-            h1 = torch.einsum("nmi,moi->nmo", xn2, p[f"{pa}.so3_linear_1.weight"][L_OF_LP])
-            h1 = torch.cat([h1[:, 0:1] + p[f"{pa}.so3_linear_1.bias"][None, None], h1[:, 1:]], dim=1)
-            sg = torch.sigmoid(O.silu(gs_pre)).reshape(n, W.LMAX, H)
-            hg = torch.cat([O.silu(h1[:, 0:1]), h1[:, 1:] * sg[:, L_OF_LP[1:] - 1]], dim=1)
-            o2 = torch.einsum("nmi,moi->nmo", hg, p[f"{pa}.so3_linear_2.weight"][L_OF_LP])
-            o2 = torch.cat([o2[:, 0:1] + p[f"{pa}.so3_linear_2.bias"][None, None], o2[:, 1:]], dim=1)
+            o2, saved = atomwise_fwd(p, pa, xn2)
             x = x + o2
-            t[f"xn2.{i}"], t[f"gspre.{i}"], t[f"ffh.{i}"], t[f"ffhg.{i}"], t[f"x.{i}"] = xn2, gs_pre, h1, hg, x
+            t[f"xn2.{i}"], t[f"x.{i}"], t[f"ffsaved.{i}"] = xn2, x, saved
+            for kk, vv in saved.items():
+                t[f"{kk}.{i}"] = vv
         xf = O.rms_norm_sh(x, p["norm.affine_weight"], p["norm.affine_bias"])
         pre1 = xf[:, 0, :] @ p["energy_block.0.weight"].T + p["energy_block.0.bias"]
         pre2 = O.silu(pre1) @ p["energy_block.2.weight"].T + p["energy_block.2.bias"]
@@ -210,17 +252,7 @@ class Staged:
             b = f"blocks.{i}"
             pa = f"{b}.atom_wise"
             # ---- atomwise backward
-            g_hg = torch.einsum("nmo,moi->nmi", g_x, p[f"{pa}.so3_linear_2.weight"][L_OF_LP])
-            h1, gs_pre = t[f"ffh.{i}"], t[f"gspre.{i}"]
-            gs = O.silu(gs_pre)
-            sg = torch.sigmoid(gs)
-            sgx = sg.reshape(n, W.LMAX, H)[:, L_OF_LP[1:] - 1]
-            g_h1 = torch.cat([g_hg[:, 0:1] * silu_grad(h1[:, 0:1]), g_hg[:, 1:] * sgx], dim=1)
-            prod = g_hg[:, 1:] * h1[:, 1:]
-            g_sg = torch.stack([prod[:, 0:3].sum(1), prod[:, 3:8].sum(1)], dim=1).reshape(n, W.LMAX * H)
-            g_gspre = g_sg * sg * (1 - sg) * silu_grad(gs_pre)
-            g_xn2 = torch.einsum("nmo,moi->nmi", g_h1, p[f"{pa}.so3_linear_1.weight"][L_OF_LP])
-            g_xn2[:, 0, :] = g_xn2[:, 0, :] + g_gspre @ p[f"{pa}.scalar_mlp.weight"]
+            g_xn2 = atomwise_bwd(p, pa, g_x, t[f"ffsaved.{i}"])
             g_xmid = g_x + norm_bwd(g_xn2, t[f"xmid.{i}"], p[f"{b}.norm_2.affine_weight"])
             t[f"g_xmid.{i}"] = g_xmid
             # ---- edgewise backward

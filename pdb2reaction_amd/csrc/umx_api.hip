@@ -44,7 +44,8 @@ struct LayerW {
   const float *n1w, *n1b, *n2w, *n2b;
   const float *c1m0, *c1m0b, *c1m0T, *c1m1, *c1m1T, *c1m2, *c1m2T;
   const float *c2m0, *c2m0b, *c2m0T, *c2m1, *c2m1T, *c2m2, *c2m2T;
-  const float *smlp, *smlpb, *smlpT, *l1w, *l1b, *l1T, *l2w, *l2b, *l2T;
+  const float *smlp, *smlpb, *smlpT, *l1w, *l1b, *l1T, *l2w, *l2b, *l2T;       // K8 spectral feed-forward
+  const float *g1w, *g1b, *g1T, *g2w, *g2b, *g2T, *g3w, *g3b, *g3T;            // K8 grid feed-forward (ff_grid): grid_mlp.{0,2,4} (+ optional biases), transposes
   RadialW rad;
 };
 
@@ -97,7 +98,12 @@ struct umx_engine {
   bool wide_tiles = true;          // UMX_WIDE=0: 256x128 tiles for every GEMM
   int mfma16 = 1;                  // UMX_MFMA16: 0 = v_mfma_f32_32x32x16_bf16 everywhere, 1 = 16x16x32 where it measured faster, 2 = everywhere
   bool fuse_modrot = true;         // UMX_FUSE_MODROT=0: separate k_modulate_bwd_pl + k_gather_rotate_bwd (debug: exposes g_xrot)
-  int n_lanes = 1;                 // UMX_STREAMS (1 or 2): two chunks in flight, matrix segments alternating between the lanes
+  int n_lanes = 0;                 // UMX_STREAMS: 1 = one lane, 2 = two chunks in flight (matrix segments alternating between the lanes), unset / 0 = the
+                                   // engine's choice (round 5): two lanes for batches of >= lanes_auto_edges directed edges whose largest image fits half
+                                   // the workspace budget.  Measured A/B on one box (profiles/r05_lanes_ab.txt): c3 (16 x 2000 atoms, 2.28 M edges) 505.2 ->
+                                   // 499.0 ms, c4 string (24 images) 761.2 -> 751.4 ms, bitwise identical results; the 2-image shard of the 8-GPU run +-0;
+                                   // c2 (366 k edges) +2 %, c1 +25 % -- small batches lose to the halved chunks, hence the threshold
+  long lanes_auto_edges = 1200000; // UMX_LANES_AUTO_EDGES
   int stream_cap = 0;              // UMX_STREAM_BLOCKS: two-lane mode caps the grids of the grid-stride streaming kernels at this many
                                    // workgroups (multiple of 8; default 512 = two per CU) so they run BESIDE the other lane's GEMM
   bool throttle = false;           // set while a two-lane evaluation is being issued
@@ -124,6 +130,14 @@ struct umx_engine {
               *e2 = nullptr, *e2b = nullptr, *e2T = nullptr, *e4 = nullptr, *e4b = nullptr;
   double rmsd = 1.0;
   std::vector<double> elem_refs;
+  // model variant, read off the tensors of the blob (umx_load_weights; SURVEY.md section 2.4 K8 / Appendix A.5 list them as possible for UMA-S)
+  bool ff_grid = false;            // K8 = GridAtomwise (to-grid -> point-wise SiLU MLP -> from-grid) instead of SpectralAtomwise
+  int grid_G = 0;                  // grid points (rows of so3_grid.to_grid_mat / from_grid_mat)
+  const float *to_grid = nullptr, *from_grid = nullptr;
+  bool grid_f64 = true;            // UMX_GRID_F64=0: the grid MLP's three GEMMs on the fp32 MFMA instead of the float64-accumulating node kernel
+  int emb_type = 0;                // charge / spin embedding: 0 rand_emb (lookup tables), 1 pos_emb (sin / cos of 2 pi v W), 2 lin_emb (Linear(1 -> C))
+  int n_datasets = 5;              // rows of dataset_embedding.weight (0: the model has no dataset embedding, mix_csd takes [charge | spin])
+  std::string variant;             // "ff=...;emb=...;datasets=N" (umx_model_variant)
   // system
   bool have_system = false;
   int natoms = 0;
@@ -146,6 +160,7 @@ struct umx_engine {
   int force_parts = 0;             // UMX_FORCE_PARTS (dev / tests): evaluate every image in this many target-node partitions
   int* d_part_deg = nullptr; float* d_part_f = nullptr; long part_cap = 0;
   int last_parts = 0;              // partitions used by the most recent evaluation (0: the ordinary path)
+  int last_lanes = 1;              // lanes (chunks in flight) of the most recent evaluation (umx_last_lanes)
   int arena_allocs = 0;            // how often the workspace has been (re-)allocated (umx_workspace_stats)
   int radial_f16 = 0;              // UMX_RADIAL_F16: bit 0 = fc1, bit 1 = fc2 of the fused radial head on four fp16 plane products (default mode, TR = 2, FAST = 0)
   bool ws_eager = false;           // UMX_WS_EAGER=1: size the workspace for the whole batch at once (the behaviour before ABI v8)
@@ -257,6 +272,14 @@ int gemm_plain(umx_engine* eng, const float* A, long lda, int offA, const float*
 
 // the same for a NODE-level linear (rows = atoms): float64 accumulation when the engine asks for it (umx_engine::node_f64_on)
 template <class... Args> int gemm_node(umx_engine* eng, Args... args) {
+  NodeCtx node(eng);
+  return gemm_plain(eng, args...);
+}
+
+// ... and for the (node x grid point) rows of the grid feed-forward: float64-accumulated like the other node-level linears unless
+// UMX_GRID_F64=0 (fp32 MFMA)
+template <class... Args> int gemm_grid(umx_engine* eng, Args... args) {
+  if (!eng->grid_f64) return gemm_plain(eng, args...);
   NodeCtx node(eng);
   return gemm_plain(eng, args...);
 }
@@ -411,6 +434,9 @@ struct WS {
   float *xn2, *ffhg, *xf, *pre1, *pre2, *enode;
   float* gspre[NL];
   float* ffh[NL];
+  float* ffg1[NL];                 // grid feed-forward: pre-activations of the two hidden layers, (nodes x G) rows x H, kept for the reverse pass
+  float* ffg2[NL];
+  float *gridA, *gridB;            // grid feed-forward: (nodes x G) x C temporaries
   float *G0, *G1, *G2, *ggs, *n128a, *n128b;
   // edge level
   int *esrc, *edst, *ez, *out_ptr, *out_cur, *out_edge;
@@ -437,12 +463,14 @@ struct Bump {
 
 // workspace mode: 0 = fp32 path, else (planes of the forward operands) + 16 when the reverse operands have three planes
 inline int ws_mode(const umx_engine* eng) { return !eng->pl ? 0 : ((eng->q3 && (eng->fwd_fmt == 1 || eng->fwd_fmt == 3)) ? 2 : 3) + (eng->rev_planes == 3 ? 16 : 0) + (eng->rev_qf ? 32 : 0); }   // (fwd_fmt 2: two half planes + two byte planes = 3 x 2 bytes)
+// ... + the grid points of the grid feed-forward in bits 8+ (its per-node buffers scale with G; 0 = spectral feed-forward)
+inline int ws_mode_g(const umx_engine* eng) { return ws_mode(eng) | ((eng->ff_grid ? eng->grid_G : 0) << 8); }
 
 // Workspace layout.  PERSISTENT buffers live from the forward to the reverse pass of an evaluation (node-level state, the graph, and the
 // per-edge activations of all four layers: ~72 KB per directed edge); TRANSIENT buffers are the operands between a producer and a GEMM
 // (~48 KB per edge) and are dead at every exchange point of the plan -- which is what lets the partitions of ONE oversized image share a
 // single transient region (eval_partitioned).  pl: 0 = fp32 path, else the number of planes of the forward operands (3 bf16 / 2 fp16).
-void carve_persist(Bump& b, long nn, long ne, WS& t) {
+void carve_persist(Bump& b, long nn, long ne, WS& t, int gridG = 0) {
   t.deg = nullptr;  // deg comes from the per-call array
   t.row_ptr = b.take<int>(nn + 1); t.stats = b.take<int>(4);
   for (auto& x : t.xs) x = b.take<float>(nn * ROW);
@@ -451,6 +479,9 @@ void carve_persist(Bump& b, long nn, long ne, WS& t) {
   t.pre1 = b.take<float>(nn * H); t.pre2 = b.take<float>(nn * H); t.enode = b.take<float>(nn);
   for (auto& x : t.gspre) x = b.take<float>(nn * 2 * H);
   for (auto& x : t.ffh) x = b.take<float>(nn * ROW);
+  for (auto& x : t.ffg1) x = gridG ? b.take<float>(nn * gridG * H) : nullptr;
+  for (auto& x : t.ffg2) x = gridG ? b.take<float>(nn * gridG * H) : nullptr;
+  t.gridA = gridG ? b.take<float>(nn * gridG * C) : nullptr; t.gridB = gridG ? b.take<float>(nn * gridG * C) : nullptr;
   t.G0 = b.take<float>(nn * ROW); t.G1 = b.take<float>(nn * ROW); t.G2 = b.take<float>(nn * ROW);
   t.ggs = b.take<float>(nn * 2 * H); t.n128a = b.take<float>(nn * H); t.n128b = b.take<float>(nn * H);
   t.esrc = b.take<int>(ne); t.edst = b.take<int>(ne); t.ez = b.take<int>(ne); t.out_edge = b.take<int>(ne);
@@ -486,8 +517,8 @@ void carve_trans(Bump& b, long ne, WS& t, int pl) {
 size_t carve(char* base, long nn, long ne, WS* w, int pl) {
   Bump b{base};
   WS t;
-  carve_persist(b, nn, ne, t);
-  carve_trans(b, ne, t, pl);
+  carve_persist(b, nn, ne, t, pl >> 8);
+  carve_trans(b, ne, t, pl & 255);
   if (w) *w = t;
   return (b.off + 255) & ~size_t(255);
 }
@@ -811,6 +842,20 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       DBG("hg" + t, w.hg[i], ne * HG); DBG("msg" + t, w.msg[i], ne * ROW); DBG("xmid" + t, xmid, nn * ROW);
       // K8 atom-wise
       hipLaunchKernelGGL(k_norm_fwd, dim3(nblk(nn, 4)), B256, 0, s, xmid, L.n2w, L.n2b, (const double*)nullptr, w.xn2, nn);
+      if (eng->ff_grid) {
+        // GridAtomwise: to-grid -> Linear, SiLU, Linear, SiLU, Linear over the channels of every grid point -> from-grid (+ residual).
+        // The hidden pre-activations stay resident for the reverse pass; the SiLUs are applied while the next GEMM stages its A operand.
+        const int G = eng->grid_G;
+        const long ng = nn * G;
+        hipLaunchKernelGGL(k_grid_expand, dim3(nblk(nn, 4)), B256, 0, s, w.xn2, eng->to_grid, G, w.gridA, nn);
+        CHK(gemm_grid(eng, w.gridA, C, 0, L.g1w, C, L.g1b, w.ffg1[i], H, 0, ng, H, C));
+        CHK(gemm_grid(eng, w.ffg1[i], H, 0, L.g2w, H, L.g2b, w.ffg2[i], H, 0, ng, H, H, A_SILU));
+        CHK(gemm_grid(eng, w.ffg2[i], H, 0, L.g3w, H, L.g3b, w.gridA, C, 0, ng, C, H, A_SILU));
+        hipLaunchKernelGGL(k_grid_contract, dim3(nblk(nn, 4)), B256, 0, s, w.gridA, eng->from_grid, G, xmid, xout, nn);
+        HIPCHK(eng, hipGetLastError());
+        DBG("xn2" + t, w.xn2, nn * ROW); DBG("ffg1" + t, w.ffg1[i], ng * H); DBG("ffg2" + t, w.ffg2[i], ng * H); DBG("x" + t, xout, nn * ROW);
+        return UMX_OK;
+      }
       CHK(gemm_node(eng, w.xn2, ROW, 0, L.smlp, C, L.smlpb, w.gspre[i], 2 * H, 0, nn, 2 * H, C));
       CHK(so3_linear(eng, w.xn2, L.l1w, L.l1b, w.ffh[i], nn, nullptr));
       hipLaunchKernelGGL(k_gate_node_fwd, dim3(nblk(nn * H, 256)), B256, 0, s, w.ffh[i], w.gspre[i], w.ffhg, nn);
@@ -860,10 +905,23 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       hipStream_t s = eng->stream;
       const LayerW& L = *Lp;
       const std::string t = "." + std::to_string(i);
+      if (eng->ff_grid) {
+        // reverse of GridAtomwise: from-grid^T -> W3^T, SiLU', W2^T, SiLU', W1^T -> to-grid^T
+        const int G = eng->grid_G;
+        const long ng = nn * G;
+        hipLaunchKernelGGL(k_grid_expand, dim3(nblk(nn, 4)), B256, 0, s, w.G0, eng->from_grid, G, w.gridA, nn);
+        CHK(gemm_grid(eng, w.gridA, C, 0, L.g3T, C, nullptr, w.gridB, H, 0, ng, H, C));
+        hipLaunchKernelGGL(k_silu_bwd, dim3(nblk(ng * H, 256)), B256, 0, s, w.gridB, (long)H, w.ffg2[i], w.gridA, ng, H);
+        CHK(gemm_grid(eng, w.gridA, H, 0, L.g2T, H, nullptr, w.gridB, H, 0, ng, H, H));
+        hipLaunchKernelGGL(k_silu_bwd, dim3(nblk(ng * H, 256)), B256, 0, s, w.gridB, (long)H, w.ffg1[i], w.gridA, ng, H);
+        CHK(gemm_grid(eng, w.gridA, H, 0, L.g1T, H, nullptr, w.gridB, C, 0, ng, C, H));
+        hipLaunchKernelGGL(k_grid_contract, dim3(nblk(nn, 4)), B256, 0, s, w.gridB, eng->to_grid, G, (const float*)nullptr, w.G1, nn);     // G1 = g_xn2
+      } else {
       CHK(so3_linear(eng, w.G0, L.l2T, nullptr, w.G1, nn, nullptr));                         // G1 = g_ffhg
       hipLaunchKernelGGL(k_gate_node_bwd, dim3(nblk(nn * H, 256)), B256, 0, s, w.G1, w.ffh[i], w.gspre[i], w.G2, w.ggs, nn);
       CHK(so3_linear(eng, w.G2, L.l1T, nullptr, w.G1, nn, nullptr));                         // G1 = g_xn2
       CHK(gemm_node(eng, w.ggs, 2 * H, 0, L.smlpT, 2 * H, nullptr, w.G1, ROW, 0, nn, C, 2 * H, A_PLAIN, 1, 0, 0, w.G1, ROW, 0, 0));
+      }
       hipLaunchKernelGGL(k_norm_bwd, dim3(nblk(nn, 4)), B256, 0, s, w.G1, xmid, L.n2w, w.G0, w.G2, nn);   // G2 = g_xmid
       HIPCHK(eng, hipGetLastError());
       DBG("g_xmid" + t, w.G2, nn * ROW);
@@ -1075,7 +1133,7 @@ std::vector<float> transpose(const float* src, int rows, int cols) {
 // ================================================================================================
 extern "C" {
 
-int umx_abi_version(void) { return 9; }
+int umx_abi_version(void) { return 10; }
 
 #ifndef UMX_SRC_DIGEST
 #define UMX_SRC_DIGEST "unknown"
@@ -1107,7 +1165,8 @@ int umx_create(umx_engine** out, int device_ordinal) {
   if (const char* ev = std::getenv("UMX_FUSED_RADIAL")) e->fused_radial = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_Q3S")) e->q3_stages = std::atoi(ev) == 3 ? 3 : 2;
   if (const char* ev = std::getenv("UMX_FUSE_MODROT")) e->fuse_modrot = std::atoi(ev) != 0;
-  if (const char* ev = std::getenv("UMX_STREAMS")) e->n_lanes = std::atoi(ev) >= 2 ? 2 : 1;
+  if (const char* ev = std::getenv("UMX_STREAMS")) e->n_lanes = std::atoi(ev) >= 2 ? 2 : (std::atoi(ev) == 1 ? 1 : 0);
+  if (const char* ev = std::getenv("UMX_LANES_AUTO_EDGES")) e->lanes_auto_edges = std::max(0L, std::atol(ev));
   if (const char* ev = std::getenv("UMX_SIDE")) e->side = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_FORCE_PARTS")) e->force_parts = std::max(0, std::min(16, std::atoi(ev)));
   if (const char* ev = std::getenv("UMX_WS_GB")) e->ws_cap_default = (size_t)std::max(0L, std::atol(ev)) << 30;
@@ -1115,6 +1174,7 @@ int umx_create(umx_engine** out, int device_ordinal) {
   if (const char* ev = std::getenv("UMX_WS_EAGER")) e->ws_eager = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_WS_SOFT_EDGES")) e->ws_soft_edges = std::max(1L, std::atol(ev));
   if (const char* ev = std::getenv("UMX_NODE_F64")) e->node_f64_on = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("UMX_GRID_F64")) e->grid_f64 = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_REV_Q3")) e->rev_q3 = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_A_F32")) e->a_f32 = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_GRAD_F32")) e->f32rows_layout = std::atoi(ev) != 0;
@@ -1254,7 +1314,25 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
     return UMX_OK;
   };
   CHK(radial_derive("edge_degree_embedding.rad_func", 3 * C));
-  struct LayOff { size_t c1m0T, c1m1T, c1m2T, c2m0T, c2m1T, c2m2T, smlpT, l1T, l2T; };
+  // ---- model variant: what the blob carries decides (pdb2reaction_amd/weights.py variant_of applies the same rule)
+  const bool ff_grid = eng->wt.count("blocks.0.atom_wise.grid_mlp.0.weight") != 0;
+  int grid_G = 0;
+  if (ff_grid) {
+    auto it = eng->wt.find("so3_grid.to_grid_mat");
+    if (it == eng->wt.end() || it->second.shape.size() != 2 || it->second.shape[1] != S || it->second.shape[0] < 1 || it->second.shape[0] > 128)
+      return fail(eng, UMX_ERR_WEIGHTS, "weight blob: the grid feed-forward needs so3_grid.to_grid_mat of shape (G <= 128, 9)");
+    grid_G = it->second.shape[0];
+    if (!need("so3_grid.from_grid_mat", {grid_G, S})) return UMX_ERR_WEIGHTS;
+  }
+  const int emb_type = eng->wt.count("charge_embedding.W") ? 1 : eng->wt.count("charge_embedding.lin_emb.weight") ? 2 : 0;
+  int n_datasets = 0;
+  if (eng->wt.count("dataset_embedding.weight")) {
+    const Tensor& t = eng->wt["dataset_embedding.weight"];
+    if (t.shape.size() != 2 || t.shape[1] != C || t.shape[0] < 1 || t.shape[0] > 32)
+      return fail(eng, UMX_ERR_WEIGHTS, "weight blob: dataset_embedding.weight must be (1..32, 128)");
+    n_datasets = t.shape[0];
+  }
+  struct LayOff { size_t c1m0T, c1m1T, c1m2T, c2m0T, c2m1T, c2m2T, smlpT, l1T, l2T, g1T, g2T, g3T; };
   LayOff loff[NL];
   auto half_T = [&](const float* src, int half, int kin) {   // W (2*half x kin) -> (2, kin, half)
     std::vector<float> t((size_t)2 * half * kin);
@@ -1275,12 +1353,20 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
     const std::string c1 = bpre + ".edge_wise.so2_conv_1", c2 = bpre + ".edge_wise.so2_conv_2", aw = bpre + ".atom_wise";
     const Tensor *a = need(c1 + ".fc_m0.weight", {640, 768}), *b1m = need(c1 + ".so2_m_conv.0.fc.weight", {512, 512}),
                  *c = need(c1 + ".so2_m_conv.1.fc.weight", {256, 256}), *d = need(c2 + ".fc_m0.weight", {384, 384}),
-                 *e = need(c2 + ".so2_m_conv.0.fc.weight", {512, 256}), *f = need(c2 + ".so2_m_conv.1.fc.weight", {256, 128}),
-                 *g = need(aw + ".scalar_mlp.weight", {256, 128}), *h1 = need(aw + ".so3_linear_1.weight", {3, 128, 128}),
-                 *h2 = need(aw + ".so3_linear_2.weight", {3, 128, 128});
-    if (!a || !b1m || !c || !d || !e || !f || !g || !h1 || !h2) return UMX_ERR_WEIGHTS;
-    if (!need(c1 + ".fc_m0.bias", {640}) || !need(c2 + ".fc_m0.bias", {384}) || !need(aw + ".scalar_mlp.bias", {256}) ||
-        !need(aw + ".so3_linear_1.bias", {128}) || !need(aw + ".so3_linear_2.bias", {128}) ||
+                 *e = need(c2 + ".so2_m_conv.0.fc.weight", {512, 256}), *f = need(c2 + ".so2_m_conv.1.fc.weight", {256, 128});
+    if (!a || !b1m || !c || !d || !e || !f) return UMX_ERR_WEIGHTS;
+    const Tensor *g = nullptr, *h1 = nullptr, *h2 = nullptr, *q1 = nullptr, *q2 = nullptr, *q3 = nullptr;
+    if (ff_grid) {
+      q1 = need(aw + ".grid_mlp.0.weight", {128, 128}); q2 = need(aw + ".grid_mlp.2.weight", {128, 128}); q3 = need(aw + ".grid_mlp.4.weight", {128, 128});
+      if (!q1 || !q2 || !q3) return UMX_ERR_WEIGHTS;
+      for (const char* li : {".grid_mlp.0.bias", ".grid_mlp.2.bias", ".grid_mlp.4.bias"})
+        if (eng->wt.count(aw + li) && !need(aw + li, {128})) return UMX_ERR_WEIGHTS;
+    } else {
+      g = need(aw + ".scalar_mlp.weight", {256, 128}); h1 = need(aw + ".so3_linear_1.weight", {3, 128, 128}); h2 = need(aw + ".so3_linear_2.weight", {3, 128, 128});
+      if (!g || !h1 || !h2 || !need(aw + ".scalar_mlp.bias", {256}) || !need(aw + ".so3_linear_1.bias", {128}) || !need(aw + ".so3_linear_2.bias", {128}))
+        return UMX_ERR_WEIGHTS;
+    }
+    if (!need(c1 + ".fc_m0.bias", {640}) || !need(c2 + ".fc_m0.bias", {384}) ||
         !need(bpre + ".norm_1.affine_weight", {3, 128}) || !need(bpre + ".norm_1.affine_bias", {128}) ||
         !need(bpre + ".norm_2.affine_weight", {3, 128}) || !need(bpre + ".norm_2.affine_bias", {128}))
       return UMX_ERR_WEIGHTS;
@@ -1291,18 +1377,27 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
     loff[i].c2m0T = push(transpose(hw + d->off, 384, 384));
     loff[i].c2m1T = push(half_T(hw + e->off, 256, 256));
     loff[i].c2m2T = push(half_T(hw + f->off, 128, 128));
-    loff[i].smlpT = push(transpose(hw + g->off, 256, 128));
-    loff[i].l1T = push(per_l_T(hw + h1->off));
-    loff[i].l2T = push(per_l_T(hw + h2->off));
+    loff[i].smlpT = loff[i].l1T = loff[i].l2T = loff[i].g1T = loff[i].g2T = loff[i].g3T = 0;
+    if (ff_grid) {
+      loff[i].g1T = push(transpose(hw + q1->off, 128, 128)); loff[i].g2T = push(transpose(hw + q2->off, 128, 128)); loff[i].g3T = push(transpose(hw + q3->off, 128, 128));
+    } else {
+      loff[i].smlpT = push(transpose(hw + g->off, 256, 128));
+      loff[i].l1T = push(per_l_T(hw + h1->off));
+      loff[i].l2T = push(per_l_T(hw + h2->off));
+    }
   }
   const Tensor *te0 = need("energy_block.0.weight", {128, 128}), *te2 = need("energy_block.2.weight", {128, 128}),
                *te4 = need("energy_block.4.weight", {1, 128});
   if (!te0 || !te2 || !te4 || !need("energy_block.0.bias", {128}) || !need("energy_block.2.bias", {128}) ||
       !need("energy_block.4.bias", {1}) || !need("norm.affine_weight", {3, 128}) || !need("norm.affine_bias", {128}) ||
-      !need("sphere_embedding.weight", {NZ, 128}) || !need("charge_embedding.weight", {201, 128}) ||
-      !need("spin_embedding.weight", {101, 128}) || !need("dataset_embedding.weight", {5, 128}) ||
-      !need("mix_csd.weight", {128, 384}) || !need("mix_csd.bias", {128}) || !need("normalizer.rmsd", {1}) ||
+      !need("sphere_embedding.weight", {NZ, 128}) ||
+      !need("mix_csd.weight", {128, (n_datasets ? 3 : 2) * 128}) || !need("mix_csd.bias", {128}) || !need("normalizer.rmsd", {1}) ||
       !need("element_refs", {NZ}))
+    return UMX_ERR_WEIGHTS;
+  if (emb_type == 0 && (!need("charge_embedding.weight", {201, 128}) || !need("spin_embedding.weight", {101, 128}))) return UMX_ERR_WEIGHTS;
+  if (emb_type == 1 && (!need("charge_embedding.W", {64}) || !need("spin_embedding.W", {64}))) return UMX_ERR_WEIGHTS;
+  if (emb_type == 2 && (!need("charge_embedding.lin_emb.weight", {128, 1}) || !need("charge_embedding.lin_emb.bias", {128}) ||
+                        !need("spin_embedding.lin_emb.weight", {128, 1}) || !need("spin_embedding.lin_emb.bias", {128})))
     return UMX_ERR_WEIGHTS;
   const size_t oe0T = push(transpose(hw + te0->off, 128, 128)), oe2T = push(transpose(hw + te2->off, 128, 128));
 
@@ -1493,9 +1588,18 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
     L.c2m0 = W(c2 + ".fc_m0.weight"); L.c2m0b = W(c2 + ".fc_m0.bias"); L.c2m0T = D(loff[i].c2m0T);
     L.c2m1 = W(c2 + ".so2_m_conv.0.fc.weight"); L.c2m1T = D(loff[i].c2m1T);
     L.c2m2 = W(c2 + ".so2_m_conv.1.fc.weight"); L.c2m2T = D(loff[i].c2m2T);
-    L.smlp = W(aw + ".scalar_mlp.weight"); L.smlpb = W(aw + ".scalar_mlp.bias"); L.smlpT = D(loff[i].smlpT);
-    L.l1w = W(aw + ".so3_linear_1.weight"); L.l1b = W(aw + ".so3_linear_1.bias"); L.l1T = D(loff[i].l1T);
-    L.l2w = W(aw + ".so3_linear_2.weight"); L.l2b = W(aw + ".so3_linear_2.bias"); L.l2T = D(loff[i].l2T);
+    L.smlp = L.smlpb = L.smlpT = L.l1w = L.l1b = L.l1T = L.l2w = L.l2b = L.l2T = nullptr;
+    L.g1w = L.g1b = L.g1T = L.g2w = L.g2b = L.g2T = L.g3w = L.g3b = L.g3T = nullptr;
+    if (ff_grid) {
+      auto WB = [&](const std::string& nm) -> const float* { return eng->wt.count(nm) ? W(nm) : nullptr; };
+      L.g1w = W(aw + ".grid_mlp.0.weight"); L.g1b = WB(aw + ".grid_mlp.0.bias"); L.g1T = D(loff[i].g1T);
+      L.g2w = W(aw + ".grid_mlp.2.weight"); L.g2b = WB(aw + ".grid_mlp.2.bias"); L.g2T = D(loff[i].g2T);
+      L.g3w = W(aw + ".grid_mlp.4.weight"); L.g3b = WB(aw + ".grid_mlp.4.bias"); L.g3T = D(loff[i].g3T);
+    } else {
+      L.smlp = W(aw + ".scalar_mlp.weight"); L.smlpb = W(aw + ".scalar_mlp.bias"); L.smlpT = D(loff[i].smlpT);
+      L.l1w = W(aw + ".so3_linear_1.weight"); L.l1b = W(aw + ".so3_linear_1.bias"); L.l1T = D(loff[i].l1T);
+      L.l2w = W(aw + ".so3_linear_2.weight"); L.l2b = W(aw + ".so3_linear_2.bias"); L.l2T = D(loff[i].l2T);
+    }
     fill_rad(L.rad, c1 + ".rad_func", RAD);
   }
   eng->emb_sphere = W("sphere_embedding.weight");
@@ -1506,6 +1610,11 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
   eng->rmsd = (double)hw[eng->wt["normalizer.rmsd"].off];
   eng->elem_refs.assign(NZ, 0.0);
   for (int z = 0; z < NZ; ++z) eng->elem_refs[z] = (double)hw[eng->wt["element_refs"].off + z];
+  if (ff_grid != eng->ff_grid || grid_G != eng->grid_G) { eng->cap_nodes = 0; eng->cap_edges = 0; }     // the per-node workspace changes with the variant
+  eng->ff_grid = ff_grid; eng->grid_G = grid_G; eng->emb_type = emb_type; eng->n_datasets = n_datasets;
+  eng->to_grid = ff_grid ? W("so3_grid.to_grid_mat") : nullptr; eng->from_grid = ff_grid ? W("so3_grid.from_grid_mat") : nullptr;
+  eng->variant = std::string("ff=") + (ff_grid ? "grid(G=" + std::to_string(grid_G) + ")" : std::string("spectral")) + ";emb=" +
+                 (emb_type == 1 ? "pos_emb" : emb_type == 2 ? "lin_emb" : "rand_emb") + ";datasets=" + std::to_string(n_datasets);
   eng->have_weights = true;
   eng->have_system = false;
   return UMX_OK;
@@ -1521,13 +1630,19 @@ const char* umx_precision_mode(const umx_engine* eng) {
   return !eng->pl ? "fp32" : (eng->q3 && eng->fwd_fmt == 2) ? "f16x2b8" : (eng->q3 && eng->fwd_fmt == 1) ? "split-f16" : eng->rev_planes == 3 ? "bf16x3" : "split-bf16";
 }
 
+const char* umx_model_variant(const umx_engine* eng) {
+  if (!eng || !eng->have_weights) return "";
+  return eng->variant.c_str();
+}
+
 int umx_set_system(umx_engine* eng, int n_atoms, const int32_t* z, int charge, int spin, int task_index, float radius, int max_neigh) {
   if (!eng) return UMX_ERR_ARG;
   if (!eng->have_weights) return fail(eng, UMX_ERR_ARG, "umx_set_system: load weights first");
   if (n_atoms <= 0 || !z) return fail(eng, UMX_ERR_ARG, "umx_set_system: empty system");
   if (charge < -100 || charge > 100) return fail(eng, UMX_ERR_ARG, "umx_set_system: charge outside [-100, 100]");
   if (spin < 0 || spin > 100) return fail(eng, UMX_ERR_ARG, "umx_set_system: spin multiplicity outside [0, 100]");
-  if (task_index < 0 || task_index > 4) return fail(eng, UMX_ERR_ARG, "umx_set_system: task index outside [0, 4]");
+  if (eng->n_datasets > 0 && (task_index < 0 || task_index >= eng->n_datasets))
+    return fail(eng, UMX_ERR_ARG, "umx_set_system: task index outside [0, " + std::to_string(eng->n_datasets - 1) + "] (rows of the blob's dataset_embedding.weight)");
   HIPCHK(eng, hipSetDevice(eng->dev));
   double rs = 0.0;
   for (int i = 0; i < n_atoms; ++i) {
@@ -1544,17 +1659,41 @@ int umx_set_system(umx_engine* eng, int n_atoms, const int32_t* z, int charge, i
     // added to EVERY atom in every layer, so any error in it is a same-sign energy bias that grows with N.
     const float* hw = eng->h_w.data();
     auto HW = [&](const std::string& nm) -> const float* { return hw + eng->wt[nm].off; };
-    const float* chg = HW("charge_embedding.weight") + (size_t)(charge + 100) * C;
-    const float* spn = HW("spin_embedding.weight") + (size_t)spin * C;
-    const float* dst = HW("dataset_embedding.weight") + (size_t)task_index * C;
+    // ChgSpinEmbedding in the blob's form (fairchem chg_spin_emb_type [3P-UNVERIFIED]): rand_emb = table row (charge + 100 / multiplicity);
+    // pos_emb = [sin(2 pi v W) | cos(2 pi v W)], the null spin 0 embedding to zero; lin_emb = Linear(1 -> C) of v (null spin 0 -> -100)
+    double chg[C], spn[C], dst[C];
+    auto emb = [&](const char* which, int v, bool is_spin, double* out) {
+      const std::string pre = std::string(which) + "_embedding.";
+      if (eng->emb_type == 1) {
+        const float* w = HW(pre + "W");
+        for (int k = 0; k < C / 2; ++k) {
+          const double ang = 2.0 * 3.14159265358979323846 * (double)v * (double)w[k];
+          out[k] = (is_spin && v == 0) ? 0.0 : std::sin(ang);
+          out[C / 2 + k] = (is_spin && v == 0) ? 0.0 : std::cos(ang);
+        }
+      } else if (eng->emb_type == 2) {
+        const float *w = HW(pre + "lin_emb.weight"), *b = HW(pre + "lin_emb.bias");
+        const double x = (is_spin && v == 0) ? -100.0 : (double)v;
+        for (int k = 0; k < C; ++k) out[k] = (double)w[k] * x + (double)b[k];
+      } else {
+        const float* t = HW(pre + "weight") + (size_t)(v + (is_spin ? 0 : 100)) * C;
+        for (int k = 0; k < C; ++k) out[k] = t[k];
+      }
+    };
+    emb("charge", charge, false, chg);
+    emb("spin", spin, true, spn);
+    const int nd = eng->n_datasets;
+    for (int k = 0; k < C; ++k) dst[k] = nd ? (double)HW("dataset_embedding.weight")[(size_t)task_index * C + k] : 0.0;
     const float* mw = HW("mix_csd.weight");
     const float* mb = HW("mix_csd.bias");
+    const size_t ldm = (size_t)(nd ? 3 : 2) * C;
     double se[C];
     for (int o = 0; o < C; ++o) {
       double acc = mb[o];
-      for (int k = 0; k < C; ++k)
-        acc += (double)mw[(size_t)o * 3 * C + k] * chg[k] + (double)mw[(size_t)o * 3 * C + C + k] * spn[k] +
-               (double)mw[(size_t)o * 3 * C + 2 * C + k] * dst[k];
+      for (int k = 0; k < C; ++k) {
+        if (nd) acc += (double)mw[o * ldm + k] * chg[k] + (double)mw[o * ldm + C + k] * spn[k] + (double)mw[o * ldm + 2 * C + k] * dst[k];
+        else acc += (double)mw[o * ldm + k] * chg[k] + (double)mw[o * ldm + C + k] * spn[k];
+      }
       se[o] = acc / (1.0 + std::exp(-acc));
     }
     HIPCHK(eng, hipMemcpy(eng->d_sysemb, se, sizeof(se), hipMemcpyHostToDevice));
@@ -1640,10 +1779,11 @@ static int eval_partitioned(umx_engine* eng, hipStream_t s, const float* d_pos, 
   if (flag & 2) { HIPCHK(eng, hipMemsetAsync(eng->d_flags, 0, sizeof(int), s)); return fail(eng, UMX_ERR_ARG, "umx_energy_forces: non-finite position (device buffer)"); }
   // layout: P persistent regions, then one transient region sized for the largest partition
   const int mode = ws_mode(eng);
+  const int gridG = eng->ff_grid ? eng->grid_G : 0;
   std::vector<size_t> off(P + 1, 0);
   size_t tmax = 0;
   for (int p = 0; p < P; ++p) {
-    Bump bp{nullptr}; WS t; carve_persist(bp, N, cnt[p], t);
+    Bump bp{nullptr}; WS t; carve_persist(bp, N, cnt[p], t, gridG);
     off[p + 1] = off[p] + ((bp.off + 255) & ~size_t(255));
     Bump bt{nullptr}; carve_trans(bt, cnt[p], t, mode);
     tmax = std::max(tmax, (bt.off + 255) & ~size_t(255));
@@ -1661,7 +1801,7 @@ static int eval_partitioned(umx_engine* eng, hipStream_t s, const float* d_pos, 
   eng->cap_nodes = 0; eng->cap_edges = 0;                    // the ordinary path re-carves (and re-sizes) the arena on its next call
   std::vector<WS> ws(P);
   for (int p = 0; p < P; ++p) {
-    Bump bp{eng->arena + off[p]}; carve_persist(bp, N, cnt[p], ws[p]);
+    Bump bp{eng->arena + off[p]}; carve_persist(bp, N, cnt[p], ws[p], gridG);
     Bump bt{eng->arena + off[P]}; carve_trans(bt, cnt[p], ws[p], mode);
   }
   std::vector<Plan> plans(P);
@@ -1762,10 +1902,15 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
     if (eng->ws_cap_default && budget > eng->ws_cap_default) {
       long emax = 0;
       for (long k = 0; k < K; ++k) emax = std::max(emax, (long)img_edges[k]);
-      if (carve(nullptr, N, emax, nullptr, ws_mode(eng)) <= eng->ws_cap_default) budget = eng->ws_cap_default;   // (a single image larger than the cap keeps the full budget)
+      if (carve(nullptr, N, emax, nullptr, ws_mode_g(eng)) <= eng->ws_cap_default) budget = eng->ws_cap_default;   // (a single image larger than the cap keeps the full budget)
     }
   }
   int lanes = (eng->n_lanes >= 2 && K >= 2 && !eng->dbg_on && !eng->gp) ? 2 : 1;      // debug captures name ONE chunk's buffers
+  if (eng->n_lanes == 0 && K >= 2 && !eng->dbg_on && !eng->gp && eng->force_parts < 2 && eng->last_edges >= eng->lanes_auto_edges) {
+    long emax = 0;
+    for (long k = 0; k < K; ++k) emax = std::max(emax, (long)img_edges[k]);
+    if (carve(nullptr, N, emax, nullptr, ws_mode_g(eng)) <= budget / 2) lanes = 2;
+  }
   budget /= lanes;
   // Amortised workspace (ABI v8).  Allocating device memory costs ~45 ms per GiB on this driver (it is cleared), so a workspace sized for the
   // whole batch -- up to the 160 GiB cap: 7 s -- is only worth it for a run that lasts: a one-off finite-difference Hessian of a 500-atom
@@ -1779,10 +1924,10 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
       long emax = 1, etot = 0;
       for (long k = 0; k < K; ++k) { emax = std::max(emax, (long)img_edges[k]); etot += img_edges[k]; }
       const long per = std::max(1L, (eng->ws_soft_edges + emax - 1) / emax);                      // images per chunk for ~ws_soft_edges
-      const size_t want = carve(nullptr, per * N, per * (emax + emax / 20 + 64), nullptr, ws_mode(eng));
-      const size_t cur = eng->cap_nodes > 0 ? carve(nullptr, eng->cap_nodes, eng->cap_edges, nullptr, ws_mode(eng)) : 0;
+      const size_t want = carve(nullptr, per * N, per * (emax + emax / 20 + 64), nullptr, ws_mode_g(eng));
+      const size_t cur = eng->cap_nodes > 0 ? carve(nullptr, eng->cap_nodes, eng->cap_edges, nullptr, ws_mode_g(eng)) : 0;
       size_t soft = std::min(budget, std::max(want, cur));
-      const size_t full = std::min(budget, carve(nullptr, K * N, etot + etot / 50 + 1024, nullptr, ws_mode(eng)));
+      const size_t full = std::min(budget, carve(nullptr, K * N, etot + etot / 50 + 1024, nullptr, ws_mode_g(eng)));
       if (full > soft && (now - eng->t_first_eval) >= 8.0 * 0.045 * (double)(full >> 20) / 1024.0) soft = full;
       budget = soft;
     }
@@ -1797,12 +1942,12 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
       long k1 = k0, e = 0;
       while (k1 < K && (k1 - k0) < cap) {
         const long e2 = e + img_edges[k1];
-        if (k1 > k0 && carve(nullptr, (k1 - k0 + 1) * N, e2, nullptr, ws_mode(eng)) > budget) break;
+        if (k1 > k0 && carve(nullptr, (k1 - k0 + 1) * N, e2, nullptr, ws_mode_g(eng)) > budget) break;
         e = e2; ++k1;
       }
-      if (carve(nullptr, (k1 - k0) * N, e, nullptr, ws_mode(eng)) > budget)
+      if (carve(nullptr, (k1 - k0) * N, e, nullptr, ws_mode_g(eng)) > budget)
         return fail(eng, UMX_ERR_CAPACITY, "one image (" + std::to_string(N) + " atoms, " + std::to_string(e) + " directed edges) needs " +
-                                               std::to_string(carve(nullptr, N, e, nullptr, ws_mode(eng)) >> 20) + " MiB of workspace, budget is " +
+                                               std::to_string(carve(nullptr, N, e, nullptr, ws_mode_g(eng)) >> 20) + " MiB of workspace, budget is " +
                                                std::to_string(budget >> 20) + " MiB: a structure of this size has to be evaluated in the graph-parallel mode, its edges "
                                                "partitioned over several GPUs (umx_gp_begin / umx_gp_step; uma_pysis(workers=<ranks>) under torch.distributed, one rank per GPU)");
       chunks.push_back({k0, k1});
@@ -1851,7 +1996,7 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
     if (const char* ev = std::getenv("UMX_MAX_CHUNK_IMAGES")) { const long v = std::atol(ev); if (v > 0) hint_img = std::min(hint_img, v); }
     hint_nodes = hint_img * N;
     hint_edges = hint_img * (emax + emax / 20 + 64);
-    if ((hint_nodes <= eng->cap_nodes && hint_edges <= eng->cap_edges) || carve(nullptr, hint_nodes, hint_edges, nullptr, ws_mode(eng)) > budget) hint_nodes = hint_edges = 0;
+    if ((hint_nodes <= eng->cap_nodes && hint_edges <= eng->cap_edges) || carve(nullptr, hint_nodes, hint_edges, nullptr, ws_mode_g(eng)) > budget) hint_nodes = hint_edges = 0;
   }
   // (the hint alone triggers ONE allocation; after that it only enlarges a growth the batches themselves ask for -- otherwise every batch
   // whose densest image is a little denser than the last one's would re-allocate)
@@ -1862,22 +2007,30 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
     HIPCHK(eng, hipStreamSynchronize(eng->stream2));
     if (eng->arena) { HIPCHK(eng, hipFree(eng->arena)); eng->arena = nullptr; eng->arena_bytes = 0; }
     long cn = std::max(std::max(need_nodes, hint_nodes), eng->cap_nodes), ce = std::max(std::max(need_edges + need_edges / 50 + 1024, hint_edges), eng->cap_edges);
-    size_t bytes = carve(nullptr, cn, ce, nullptr, ws_mode(eng));
+    size_t bytes = carve(nullptr, cn, ce, nullptr, ws_mode_g(eng));
     if (bytes > budget && (hint_nodes || hint_edges)) {      // hint and need combined overshoot: size for the need alone
       cn = std::max(need_nodes, eng->cap_nodes); ce = std::max(need_edges + need_edges / 50 + 1024, eng->cap_edges);
-      bytes = carve(nullptr, cn, ce, nullptr, ws_mode(eng));
+      bytes = carve(nullptr, cn, ce, nullptr, ws_mode_g(eng));
     }
     long ce2 = ce;
-    if (bytes > budget) { ce2 = std::max(need_edges, 1L); bytes = carve(nullptr, cn, ce2, nullptr, ws_mode(eng)); }
+    if (bytes > budget) { ce2 = std::max(need_edges, 1L); bytes = carve(nullptr, cn, ce2, nullptr, ws_mode_g(eng)); }
     HIPCHK(eng, hipMalloc(&eng->arena, lanes * bytes));     // one workspace per lane
     ++eng->arena_allocs;
     eng->arena_bytes = lanes * bytes; eng->cap_nodes = cn; eng->cap_edges = ce2;
   }
   WS wl[2];
-  if (lanes == 2 && eng->arena_bytes < 2 * carve(nullptr, eng->cap_nodes, eng->cap_edges, nullptr, ws_mode(eng))) lanes = 1;   // arena was sized for one lane
-  const size_t lane_bytes = carve(eng->arena, eng->cap_nodes, eng->cap_edges, &wl[0], ws_mode(eng));
-  if (eng->arena_bytes >= 2 * lane_bytes) carve(eng->arena + lane_bytes, eng->cap_nodes, eng->cap_edges, &wl[1], ws_mode(eng));
+  long use_nodes = eng->cap_nodes, use_edges = eng->cap_edges;
+  if (lanes == 2 && eng->arena_bytes < 2 * carve(nullptr, use_nodes, use_edges, nullptr, ws_mode_g(eng))) {
+    // the arena was sized for ONE lane of larger chunks (an engine that has seen smaller batches, or one lane, before): two lanes of THIS
+    // call's chunks may still fit it -- else one lane
+    const long ce = need_edges + need_edges / 50 + 1024;
+    if (2 * carve(nullptr, need_nodes, ce, nullptr, ws_mode_g(eng)) <= eng->arena_bytes) { use_nodes = need_nodes; use_edges = ce; }
+    else lanes = 1;
+  }
+  const size_t lane_bytes = carve(eng->arena, use_nodes, use_edges, &wl[0], ws_mode_g(eng));
+  if (lanes == 2) carve(eng->arena + lane_bytes, use_nodes, use_edges, &wl[1], ws_mode_g(eng));
   if (eng->dbg_on) eng->dbg.clear();
+  eng->last_lanes = (lanes == 2 && chunks.size() > 1) ? 2 : 1;
   if (lanes == 2) {          // lane 1 starts after everything enqueued so far on the primary stream (degree pass, caller's work)
     HIPCHK(eng, hipEventRecord(eng->ev_fork, s));
     HIPCHK(eng, hipStreamWaitEvent(eng->stream2, eng->ev_fork, 0));
@@ -2049,6 +2202,7 @@ int umx_last_graph_stats(const umx_engine* eng, int64_t* n_edges_total, int32_t*
 }
 
 int umx_last_partitions(const umx_engine* eng) { return eng ? eng->last_parts : 0; }
+int umx_last_lanes(const umx_engine* eng) { return eng ? eng->last_lanes : 0; }
 
 int umx_workspace_stats(const umx_engine* eng, int64_t* bytes, int32_t* allocations) {
   if (!eng) return UMX_ERR_ARG;

@@ -76,7 +76,13 @@ __global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ deg, long
 }
 
 // Rows keep ascending source order.  A target with more than max_neigh candidates keeps its max_neigh nearest
-// (rank by (d^2, source index), the oracle's stable argsort) -- the rare path scans the image once per candidate chunk.
+// (rank by (d^2, source index), the oracle's stable argsort).  Round 5: the cap is the checkpoint's to choose (uma_pysis.py:301-309), and
+// with a binding cap EVERY atom takes this path -- measured on c3 with max_neigh = 30: 16.5 ms per launch (7 % of the step) for the
+// first form, which re-scanned the whole image once per candidate chunk (O(N^2 / 64) shuffles per node).  Now the wave compacts the
+// target's candidates as 64-bit keys (d^2 bits << 32 | source: unique, ordered like the oracle's comparator) into its own LDS slice,
+// ranks each key against the others with broadcast reads (cand^2 / 64 compares per lane) and writes the kept ones in source order.
+// More than GF_MAXC candidates (> 1 atom / A^3 at a 6 A cutoff) keep the slow form.
+constexpr int GF_MAXC = 1024;
 __global__ __launch_bounds__(256) void k_graph_fill(const float* __restrict__ pos, int natoms, long nt, float rc2, int max_neigh,
                                                     const int* __restrict__ cand, const int* __restrict__ row_ptr, int* __restrict__ esrc,
                                                     int* __restrict__ edst, float* __restrict__ evec, long lo, long hi) {
@@ -84,8 +90,51 @@ __global__ __launch_bounds__(256) void k_graph_fill(const float* __restrict__ po
   if (node < lo || node >= hi) return;           // wave-uniform: rows outside the owned target range are empty
   const long base = (node / natoms) * natoms;
   const float xi = pos[node * 3 + 0], yi = pos[node * 3 + 1], zi = pos[node * 3 + 2];
-  const bool truncate = cand[node] > max_neigh;
+  const int nc = cand[node];
+  const bool truncate = nc > max_neigh;
   int w = row_ptr[node];
+  __shared__ unsigned long long gf_keys[4][GF_MAXC];
+  if (truncate && nc <= GF_MAXC) {               // wave-uniform
+    unsigned long long* keys = gf_keys[threadIdx.x >> 6];
+    int c = 0;
+    for (int j0 = 0; j0 < natoms; j0 += 64) {
+      const int j = j0 + lane;
+      bool ok = false;
+      float d2 = 0.f;
+      if (j < natoms) {
+        const float dx = pos[(base + j) * 3 + 0] - xi, dy = pos[(base + j) * 3 + 1] - yi, dz = pos[(base + j) * 3 + 2] - zi;
+        d2 = dist2_f(dx, dy, dz);
+        ok = (d2 <= rc2) && (d2 > 0.0f) && (base + j != node);
+      }
+      const unsigned long long m = __ballot(ok);
+      if (ok) keys[c + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)j;
+      c += __popcll(m);
+    }
+    // the slice is private to this wave and its DS operations execute in order: only the compiler must not move the reads up
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int c0 = 0; c0 < c; c0 += 64) {
+      const int ci = c0 + lane;
+      const bool have = ci < c;
+      const unsigned long long k = have ? keys[ci] : ~0ull;
+      int rank = 0;
+      for (int q = 0; q < c; ++q) rank += keys[q] < k ? 1 : 0;
+      const bool keep = have && rank < max_neigh;
+      const unsigned long long m = __ballot(keep);
+      if (keep) {
+        const int j = (int)(unsigned)(k & 0xffffffffull);
+        const float dx = pos[(base + j) * 3 + 0] - xi, dy = pos[(base + j) * 3 + 1] - yi, dz = pos[(base + j) * 3 + 2] - zi;
+        const float d = sqrtf(__uint_as_float((unsigned)(k >> 32))), inv = 1.0f / d;
+        const int slot = w + __popcll(m & ((1ull << lane) - 1ull));
+        esrc[slot] = (int)(base + j);
+        edst[slot] = (int)node;
+        *reinterpret_cast<float4*>(evec + (long)slot * 4) = make_float4(dx * inv, dy * inv, dz * inv, d);
+      }
+      w += __popcll(m);
+    }
+    return;
+  }
   for (int j0 = 0; j0 < natoms; j0 += 64) {
     const int j = j0 + lane;
     bool ok = false;
@@ -361,6 +410,51 @@ __global__ __launch_bounds__(256) void k_ln_silu_bwd(const float* __restrict__ g
   const float m2 = wave_sum(gw0 * xh0 + gw1 * xh1) * (1.0f / RH);
   *reinterpret_cast<float2*>(gx + row * RH + c0) =
       make_float2(rstd * (gw0 - m1 - xh0 * m2), rstd * (gw1 - m1 - xh1 * m2));
+  }
+}
+
+// K8, ff_type = grid (fairchem GridAtomwise [3P-UNVERIFIED]): the S2-grid projections of the atom-wise block.
+// The (G, 9) matrices are DATA of the weight blob (so3_grid.to_grid_mat / from_grid_mat).  One wave per node, two channels per lane:
+// every access is one contiguous 512-B row; the matrix entries are wave-uniform (scalar loads).
+//   expand:   out[n, g, :] = sum_i M[g, i] x[n, i, :]      (to-grid forward with M = to_grid; reverse of from-grid with M = from_grid)
+//   contract: out[n, i, :] = resid[n, i, :] + sum_g M[g, i] y[n, g, :]   (from-grid forward + residual; reverse of to-grid with M = to_grid),
+//             G-term sums accumulated in double and rounded once (the same sum enters every atom's residual stream in every layer)
+__global__ __launch_bounds__(256) void k_grid_expand(const float* __restrict__ x, const float* __restrict__ M, int G, float* __restrict__ out, long nt) {
+  UMX_WAVE_ITEM(node, nt)
+  const int c0 = lane * 2;
+  float2 v[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) v[r] = *reinterpret_cast<const float2*>(x + node * ROW + r * C + c0);
+  float* op = out + node * (long)G * C + c0;
+  for (int g = 0; g < G; ++g) {
+    const float* m = M + g * 9;
+    float ax = 0.f, ay = 0.f;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) ax = fmaf(m[r], v[r].x, ax);
+    asm volatile("" : "+v"(ax));          // keeps the backend from pairing the two chains into v_pk_fma_f32 (build.check_no_packed_fp32)
+#pragma unroll
+    for (int r = 0; r < 9; ++r) ay = fmaf(m[r], v[r].y, ay);
+    *reinterpret_cast<float2*>(op + (long)g * C) = make_float2(ax, ay);
+  }
+}
+__global__ __launch_bounds__(256) void k_grid_contract(const float* __restrict__ y, const float* __restrict__ M, int G, const float* __restrict__ resid,
+                                                       float* __restrict__ out, long nt) {
+  UMX_WAVE_ITEM(node, nt)
+  const int c0 = lane * 2;
+  double ax[9], ay[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) { ax[r] = 0.0; ay[r] = 0.0; }
+  const float* yp = y + node * (long)G * C + c0;
+  for (int g = 0; g < G; ++g) {
+    const float2 v = *reinterpret_cast<const float2*>(yp + (long)g * C);
+    const float* m = M + g * 9;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) { ax[r] = fma((double)m[r], (double)v.x, ax[r]); ay[r] = fma((double)m[r], (double)v.y, ay[r]); }
+  }
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    if (resid) { const float2 q = *reinterpret_cast<const float2*>(resid + node * ROW + r * C + c0); ax[r] += (double)q.x; ay[r] += (double)q.y; }
+    *reinterpret_cast<float2*>(out + node * ROW + r * C + c0) = make_float2((float)ax[r], (float)ay[r]);
   }
 }
 

@@ -71,6 +71,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "umx_load_weights": ([vp, vp, C.c_size_t], i32),
         "umx_set_precision": ([vp, C.c_char_p], i32),
         "umx_precision_mode": ([vp], C.c_char_p),
+        "umx_model_variant": ([vp], C.c_char_p),
         "umx_set_system": ([vp, i32, C.POINTER(C.c_int32), i32, i32, i32, C.c_float, i32], i32),
         "umx_set_workspace_limit": ([vp, C.c_size_t], i32),
         "umx_energy_forces": ([vp, i32, fp, dp, fp], i32),
@@ -80,6 +81,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "umx_synchronize": ([vp], i32),
         "umx_last_graph_stats": ([vp, i64p, C.POINTER(C.c_int32)], i32),
         "umx_last_partitions": ([vp], i32),
+        "umx_last_lanes": ([vp], i32),
         "umx_reserve_images": ([vp, i32], i32),
         "umx_workspace_stats": ([vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32)], i32),
         "umx_profile_enable": ([vp, i32], i32),
@@ -117,9 +119,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = (
-    "umx_abi_version", "umx_build_digest", "umx_create", "umx_destroy", "umx_last_error", "umx_load_weights", "umx_set_precision", "umx_precision_mode", "umx_set_system",
+    "umx_abi_version", "umx_build_digest", "umx_create", "umx_destroy", "umx_last_error", "umx_load_weights", "umx_set_precision", "umx_precision_mode", "umx_model_variant", "umx_set_system",
     "umx_set_workspace_limit", "umx_energy_forces", "umx_energy_forces_dev", "umx_gp_begin", "umx_gp_step", "umx_synchronize",
-    "umx_last_graph_stats", "umx_last_partitions", "umx_reserve_images", "umx_workspace_stats", "umx_profile_enable", "umx_profile_read", "umx_bond_changes", "umx_debug_fetch", "umx_debug_keep",
+    "umx_last_graph_stats", "umx_last_partitions", "umx_last_lanes", "umx_reserve_images", "umx_workspace_stats", "umx_profile_enable", "umx_profile_read", "umx_bond_changes", "umx_debug_fetch", "umx_debug_keep",
 )
 
 
@@ -141,6 +143,7 @@ class Engine:
         self.widened = False            # True once an fp16 range violation moved this engine to bf16 forward planes (split-bf16 / bf16x3)
         self._blob = None
         self._system = None
+        self.dataset_list = tuple(W.DATASET_LIST)      # order of the rows of the loaded blob's dataset_embedding.weight (load_weights)
         if precision is not None:
             self._chk(self.lib.umx_set_precision(self._h, precision.encode()), "umx_set_precision")
 
@@ -167,14 +170,21 @@ class Engine:
         self._blob = bytes(blob)        # kept (~27 MB) so that a range violation can re-load the engine in split-bf16
         buf = C.create_string_buffer(self._blob, len(self._blob))
         self._chk(self.lib.umx_load_weights(self._h, C.cast(buf, C.c_void_p), len(self._blob)), "umx_load_weights")
+        # task names -> rows of dataset_embedding.weight: the checkpoint's own dataset_list when the blob records one (checkpoint.py), else UMA's
+        meta = weights.meta if hasattr(weights, "meta") else W.blob_meta(self._blob)
+        self.dataset_list = tuple((meta.get("model") or {}).get("dataset_list") or W.DATASET_LIST)
+
+    def model_variant(self) -> str:
+        """"ff=spectral|grid(G=..);emb=rand_emb|pos_emb|lin_emb;datasets=N" -- the model variant the loaded blob is (``umx_model_variant``)."""
+        return self.lib.umx_model_variant(self._h).decode()
 
     def set_system(self, atomic_numbers: Sequence[int], charge: int = 0, spin: int = 1, task: str = "omol",
                    radius: Optional[float] = None, max_neigh: Optional[int] = None):
         z = np.ascontiguousarray(atomic_numbers, dtype=np.int32)
-        if task not in W.DATASET_LIST:
-            raise ValueError(f"task_name {task!r} not in {W.DATASET_LIST}")
+        if task not in self.dataset_list:
+            raise ValueError(f"task_name {task!r} not in {self.dataset_list}")
         self._chk(self.lib.umx_set_system(self._h, len(z), z.ctypes.data_as(C.POINTER(C.c_int32)), int(charge), int(spin),
-                                          W.DATASET_LIST.index(task), float(radius or 0.0), int(max_neigh or 0)),
+                                          self.dataset_list.index(task), float(radius or 0.0), int(max_neigh or 0)),
                   "umx_set_system")
         self.natoms = len(z)
         self._system = (z.copy(), int(charge), int(spin), task, radius, max_neigh)
@@ -301,6 +311,10 @@ class Engine:
     def last_partitions(self) -> int:
         """Target-node partitions per image of the most recent evaluation (0: the ordinary path; see ``umx_last_partitions``)."""
         return int(self.lib.umx_last_partitions(self._h))
+
+    def last_lanes(self) -> int:
+        """Chunks in flight (1 or 2) of the most recent evaluation (``umx_last_lanes``)."""
+        return int(self.lib.umx_last_lanes(self._h))
 
     def profile_enable(self, on: bool = True):
         self._chk(self.lib.umx_profile_enable(self._h, int(on)), "umx_profile_enable")

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libumx.so does not export {n} declared in include/umx.h"
     assert sorted(E.EXPORTED_SYMBOLS) == names
-    assert lib.umx_abi_version() == 9
+    assert lib.umx_abi_version() == 10
 
 
 def test_missing_library_is_loud(tmp_path):

@@ -135,19 +135,24 @@ def test_model_config_is_read_and_held_against_the_engine():
     assert model["cutoff"] == 6.0 and model["max_neighbors"] == 300 and model["num_experts"] == 4
     assert "ff_type" in model["checked"] and "lmax" in model["checked"] and model["unknown_keys"] == []
     assert "use_pbc" in model["unchecked_engine_keys"]                      # not mentioned by this config: reported, not assumed
-    for key, val, word in [("ff_type", "grid", "ff_type='grid'"), ("lmax", 3, "lmax=3"), ("mmax", 1, "mmax=1"), ("sphere_channels", 256, "sphere_channels=256"),
+    for key, val, word in [("ff_type", "s2_mlp", "ff_type='s2_mlp'"), ("lmax", 3, "lmax=3"), ("mmax", 1, "mmax=1"), ("sphere_channels", 256, "sphere_channels=256"),
                            ("hidden_channels", 64, "hidden_channels"), ("edge_channels", 64, "edge_channels"), ("num_layers", 6, "num_layers=6"),
                            ("num_distance_basis", 128, "num_distance_basis=128"), ("distance_function", "bessel", "distance_function"),
-                           ("norm_type", "layer_norm_sh", "norm_type"), ("act_type", "s2", "act_type"), ("chg_spin_emb_type", "pos_emb", "chg_spin_emb_type"),
+                           ("norm_type", "layer_norm_sh", "norm_type"), ("act_type", "s2", "act_type"), ("chg_spin_emb_type", "fourier", "chg_spin_emb_type"),
                            ("direct_forces", True, "direct_forces"), ("regress_stress", True, "regress_stress"), ("always_use_pbc", True, "always_use_pbc"),
                            ("max_num_elements", 118, "max_num_elements"), ("cutoff", -1.0, "cutoff"), ("max_neighbors", 0, "max_neighbors"),
-                           ("dataset_list", ["omol", "oc20", "omat", "odac", "omc"], "dataset_list")]:
+                           ("dataset_list", ["omol", "omol"], "dataset_list"), ("grid_resolution", 14, "grid_resolution")]:
         with pytest.raises(CK.UnsupportedCheckpoint, match=word.split("=")[0]) as ei:
             CK.validate_model_config({**UMA_S_CONFIG, key: val})
         assert word.split("=")[0] in str(ei.value)
     with pytest.raises(CK.UnsupportedCheckpoint) as ei:                      # every mismatch is named, not just the first
-        CK.validate_model_config({**UMA_S_CONFIG, "ff_type": "grid", "lmax": 4})
-    assert "ff_type" in str(ei.value) and "lmax" in str(ei.value)
+        CK.validate_model_config({**UMA_S_CONFIG, "act_type": "s2", "lmax": 4})
+    assert "act_type" in str(ei.value) and "lmax" in str(ei.value)
+    # round 5: the variants SURVEY.md lists as possible are SELECTED, not refused -- and recorded for the loader
+    m_g = CK.validate_model_config({**UMA_S_CONFIG, "ff_type": "grid", "chg_spin_emb_type": "pos_emb", "dataset_list": ["omol", "oc20", "omat", "odac", "omc"],
+                                    "grid_resolution": None})
+    assert m_g["ff_type"] == "grid" and m_g["chg_spin_emb_type"] == "pos_emb" and m_g["dataset_list"] == ["omol", "oc20", "omat", "odac", "omc"]
+    assert CK.validate_model_config({**UMA_S_CONFIG, "use_dataset_embedding": False})["dataset_list"] == []
     # free parameters: taken over, aliases understood
     m2 = CK.validate_model_config({**{k: v for k, v in UMA_S_CONFIG.items() if k not in ("cutoff", "max_neighbors")}, "radius": 5.0, "max_neigh": 40})
     assert m2["cutoff"] == 5.0 and m2["max_neighbors"] == 40
@@ -213,3 +218,83 @@ def test_convert_checkpoint_finds_the_config_and_the_blob_carries_the_graph_defa
                 U.UMAcore(["O", "H", "H"], model=path, workers_per_node=4)
         finally:
             E.Engine = real
+
+
+def _fairchem_style(w, dataset_list):
+    """The variant weight set under the module names fairchem gives them [3P-UNVERIFIED]: lookup tables under ``.rand_emb``, one (1, C)
+    dataset table per NAME, (lat, long, 9) grid buffers."""
+    state = {}
+    for name, arr in w.items():
+        if name in ("normalizer.rmsd", "element_refs"):
+            continue
+        if name in ("charge_embedding.weight", "spin_embedding.weight"):
+            state["backbone." + name.replace(".weight", ".rand_emb.weight")] = torch.tensor(arr)
+        elif name == "dataset_embedding.weight":
+            for i, d in enumerate(dataset_list):
+                state[f"backbone.dataset_embedding.dataset_emb_dict.{d}.weight"] = torch.tensor(arr[i:i + 1])
+        elif name.startswith("so3_grid."):
+            state["backbone.SO3_grid.lmax_lmax." + name[len("so3_grid."):]] = torch.tensor(arr.reshape(6, 7, 9))
+        else:
+            state["backbone." + name] = torch.tensor(arr)
+    state["backbone.SO3_grid.lmax_mmax.to_grid_mat"] = torch.zeros(6, 7, 9)           # the other grid of the module tree: dropped
+    return state
+
+
+@pytest.mark.parametrize("variant", [dict(ff_type="grid"), dict(chg_spin_emb_type="pos_emb"), dict(chg_spin_emb_type="lin_emb"),
+                                     dict(ff_type="grid", chg_spin_emb_type="pos_emb", dataset_list=("omol", "omat", "oc20")), dict(dataset_list=())])
+def test_model_variants_are_converted_not_refused(variant):
+    """grid feed-forward (its S2-grid matrices taken from the checkpoint), pos_emb / lin_emb charge-spin embedding,
+    a dataset_list in another order or absent -- state dict under fairchem-style names -> blob == the variant's own weight set, the
+    blob trailer names the variant and the dataset order, and the blob packs / unpacks."""
+    dl = tuple(variant.get("dataset_list", W.DATASET_LIST))
+    w = W.make_synthetic_weights(0, **variant)
+    state = _fairchem_style(w, dl)
+    cfg = {**UMA_S_CONFIG, "ff_type": variant.get("ff_type", "spectral"), "chg_spin_emb_type": variant.get("chg_spin_emb_type", "rand_emb"),
+           "dataset_list": list(dl) or ["omol"], "use_dataset_embedding": bool(dl), "num_experts": 1}
+    extra = {"normalizer.rmsd": w["normalizer.rmsd"], "atom_refs": {"omol_elem_refs": w["element_refs"], "omat_elem_refs": np.zeros(100)},
+             "form_elem_refs": {"omol": np.ones(100)}}
+    blob = CK.convert(state, extra=extra, model_config=cfg, task="omol")
+    back = W.unpack_blob(blob)
+    assert list(back) == list(w) and all(np.array_equal(back[k], w[k]) for k in w)          # atom_refs[omol] -> element_refs; form refs not applied
+    v = W.variant_of(back)
+    assert back.meta["model"]["ff_type"] == v["ff_type"] == variant.get("ff_type", "spectral")
+    assert back.meta["model"]["chg_spin_emb_type"] == v["chg_spin_emb_type"] == variant.get("chg_spin_emb_type", "rand_emb")
+    assert back.meta["model"]["dataset_list"] == list(dl) and v["n_datasets"] == len(dl)
+    # the config and the tensors must tell the same story
+    with pytest.raises(CK.UnsupportedCheckpoint, match="ff_type"):
+        CK.convert(state, extra=extra, model_config={**cfg, "ff_type": "grid" if v["ff_type"] == "spectral" else "spectral"}, task="omol")
+    if v["ff_type"] == "grid":
+        no_grid = {k: t for k, t in state.items() if "SO3_grid" not in k}
+        with pytest.raises(KeyError, match="dumped from the loaded model"):             # never re-derived: must come from the checkpoint
+            CK.convert(no_grid, extra=extra, model_config=cfg, task="omol")
+        got = CK.from_state_dict(no_grid, extra={**extra, "so3_grid.to_grid_mat": w["so3_grid.to_grid_mat"].reshape(6, 7, 9),
+                                                 "so3_grid.from_grid_mat": w["so3_grid.from_grid_mat"]}, task="omol")
+        assert np.array_equal(got["so3_grid.to_grid_mat"], w["so3_grid.to_grid_mat"])
+
+
+def test_element_references_as_the_reference_obtains_them():
+    """uma_pysis.py:231-239 hands fairchem ``atom_refs`` and ``form_elem_refs``; both are accepted here."""
+    a = {"omol_elem_refs": np.arange(100.0), "omat": np.arange(100.0) * 2}
+    f = {"omol": np.full(100, 0.5)}
+    assert np.array_equal(CK.element_refs_from(a, f, task="omol"), np.arange(100.0))
+    assert np.array_equal(CK.element_refs_from(a, f, task="omol", formation_energy=True), np.arange(100.0) - 0.5)
+    assert np.array_equal(CK.element_refs_from(a, None, task="omat"), np.arange(100.0) * 2)
+    assert np.array_equal(CK.element_refs_from(np.arange(120.0) * (np.arange(120) < 100), None, task="omol"), np.arange(100.0))
+    with pytest.raises(KeyError, match="odac"):
+        CK.element_refs_from(a, None, task="odac")
+    with pytest.raises(ValueError, match="not representable"):
+        CK.element_refs_from(np.arange(120.0), None, task="omol")
+
+
+def test_mole_routing_sees_the_variant_s_system_embedding():
+    """alpha depends on sys_emb: the pos_emb / per-name-dataset forms must feed the routing network the same vector the engine adds."""
+    from oracle.escn_md_oracle import Oracle
+
+    dl = ("omol", "omat", "oc20")
+    w = W.make_synthetic_weights(0, chg_spin_emb_type="pos_emb", dataset_list=dl)
+    state = _fairchem_style(w, dl)
+    sd = {k[len("backbone."):]: v.double().numpy() for k, v in state.items()}
+    se = CK.system_embedding(lambda n: sd[n], lambda n: n in sd, -1, 2, "omat", dl)
+    want = Oracle(w).system_embedding(-1, 2, "omat").numpy()
+    np.testing.assert_allclose(se, want, rtol=1e-13, atol=1e-15)
+    assert np.abs(se - CK.system_embedding(lambda n: sd[n], lambda n: n in sd, -1, 0, "omat", dl)).max() > 1e-3       # null spin differs

@@ -40,8 +40,8 @@ def test_bench_json_line_contract():
     assert f["value"] > 0 and f["dtype"].startswith("f32") and 0.0 < f["gemm_frac"] < 1.0 and f["steps"] >= 5 and f["warmup"] >= 2
     fm = d["fast_mode"]                                                              # the opt-in narrower mode, reported beside, never as `value`
     assert fm["value"] > 0 and fm["precision_mode"] == "split-f16" and "narrower" in fm["dtype"]
-    x8 = d["f16x2b8_mode"]                                                           # the other >= 24-bit mode (opt-in), beside
-    assert x8["value"] > 0 and x8["precision_mode"] == "f16x2b8" and "bf8" in x8["dtype"]
+    assert r["lanes"] == 1 and "serial_schedule" not in d and "shard" not in d       # a tiny batch runs on one lane; the shard leg belongs to the headline sizes
+    assert d["config"]["name"] == "c3" and "sizes overridden" in d["config"]["workload"]
     g = d["gsm"]                                                                     # the real driver on the fully grown string
     assert "error" not in g, g
     for leg in ("climb_off", "climb_on"):
@@ -53,3 +53,23 @@ def test_bench_json_line_contract():
         assert key in c, key
     assert c["kind"] in ("reference", "port") and c["value"] and c["value"] > 0 and c["cores"] >= 1
     assert "c1 in full" in c["sample"] and "3 of 12 images" in c["sample"] and c["c3_images_timed"] in (1, 2)
+
+
+def test_bench_other_configs_and_the_hessian_leg():
+    """`--config`: the BASELINE configs the headline line does not carry -- c1 in full, and c4's FD-Hessian leg on a
+    reduced size so the test stays short (the loop, its accounting and the extrapolation are what is checked; profiles/r05_bench_c4.json
+    has the real size)."""
+    out = subprocess.run([sys.executable, "bench.py", "--config", "c1", "--steps", "3", "--warmup", "1", "--driver", "string", "--no-fp32-mode", "--no-fast-mode"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["name"] == "c1" and d["config"]["atoms"] == 50 and d["config"]["images"] == 8 and d["config"]["workload"].startswith("c1: 50-atom")
+    assert "cpu_baseline" not in d and d["roofline"]["frac"] > 0
+    out = subprocess.run([sys.executable, "bench.py", "--config", "c4", "--atoms", "120", "--images", "6", "--steps", "2", "--warmup", "1", "--driver", "string",
+                          "--no-fp32-mode", "--no-fast-mode", "--hessian-sample-atoms", "4"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    h = d["hessian"]
+    assert "error" not in h, h
+    assert h["columns"] == 12 and h["displaced_geometries"] == 24 and h["engine_calls"] == 1 and h["finite"] and h["columns_per_s"] > 0
+    assert h["full_hessian_columns"] == 3 * (120 - 12) and h["extrapolated_full_hessian_s"] == pytest.approx(h["full_hessian_columns"] / h["columns_per_s"], rel=1e-9)

@@ -352,7 +352,7 @@ def main():
 
     mode_req = os.environ.get("UMX_PRECISION", "auto")           # "auto" = bf16x3: >= 24-bit products in both passes (include/umx.h)
     dt, prof, ne_local, maxdeg, resolved, lanes_used = run(mode_req, args.steps, args.warmup)
-    mode = {"split-f16": "split", "split-bf16": "split-bf16", "bf16x3": "bf16x3", "f16x2b8": "f16x2b8", "fp32": "fp32"}[resolved]
+    mode = {"split-f16": "split", "split-bf16": "split-bf16", "bf16x3": "bf16x3", "fp32": "fp32"}[resolved]
     tt = torch.tensor([dt, float(ne_local)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         tmax = tt.clone()
@@ -365,9 +365,6 @@ def main():
     DTYPE = {"bf16x3": ("bf16x3-split", "every large GEMM of BOTH passes on 3 x 3 bf16 planes (exact split of the float32 operands), the 6 plane products of "
                         "order <= 2 on v_mfma_f32_*_bf16, fp32 accumulate: >= 24 significant bits per product, the like-for-like arithmetic to the "
                         "reference's float32; node-level linears float64-accumulated; everything else fp32"),
-             "f16x2b8": ("f16x2+bf8-split", "forward GEMMs: activations as 2 fp16 planes + 2 bf8 planes (25 significant bits), weights as 3 exact fp16 planes + 2 bf8 planes; the "
-                         "four products down to 2^-11 on v_mfma_f32_*_f16, the two 2^-22-order products on v_mfma_scale_f32_32x32x64_f8f6f4 (bf8, K = 64, twice the rate): "
-                         ">= 24 significant bits per product; reverse GEMMs as bf16x3 (3 x 3 bf16 planes, 6 products); fp32 accumulate; node-level linears float64-accumulated"),
              "split": ("f16-split", "forward GEMMs: 2 fp16 activation planes x 3 exact fp16 weight planes, 4 MFMA products (22-23 bit activations); reverse GEMMs: "
                        "2 x 2 bf16 planes, 3 products (16-bit) -- NARROWER than the reference's float32; fp32 accumulate; node-level linears float64-accumulated"),
              "split-bf16": ("bf16-split", "forward GEMMs: 3 x 3 bf16 planes, 6 MFMA products (24-bit); reverse GEMMs: 2 x 2 bf16 planes, 3 products (16-bit); "
@@ -447,6 +444,12 @@ def main():
                                               "families (roofline.hbm_regime is taken from it); the headline above is the engine's default schedule (two lanes for this batch size, "
                                               "bitwise the same results)"}
         out["roofline"]["lanes"] = lanes_used
+        if ser:
+            # the timed region ran on two lanes: a GEMM launch there shares the chip with the other lane's HBM-bound kernels and takes longer than alone
+            # (that is the price of the overlap; the step is shorter all the same).  Both figures, so that neither hides the other:
+            out["roofline"]["schedule"] = "two lanes (engine default for this batch): per-launch times include the slowdown from co-running HBM-bound kernels"
+            out["roofline"]["serial_schedule_achieved"] = bdom["alg_flops"] / max(bdom["ms"], 1e-9) / 1e9
+            out["roofline"]["serial_schedule_frac"] = out["roofline"]["serial_schedule_achieved"] / peak
         hb = {"bound": "hbm", "kernels": "HBM-bound edge / node kernels: k_gather_rotate_mod_q3, k_modrot_bwd_pl, k_gate_edge_*, k_rotate_back_*, norms, graph build "
                                          "(everything outside the GEMM families and the fused radial-MLP kernels)",
               "ms_per_step": edge_ms, "schedule": "serial side run (UMX_STREAMS=1)" if ser else "the timed region (one lane)",
@@ -468,14 +471,23 @@ def main():
         out["roofline"]["hbm_regime"] = hb
 
         def side_mode(name: str, steps: int, warmup: int, fam: str, peak_tf: float, detail: str):
+            """The same workload in another precision mode: `value` on the engine's default schedule (as the headline); the GEMM family's
+            figures from a serial-schedule run when the default schedule overlaps kernels (two lanes), else from the same run."""
             try:
-                dts, profs, _, _, res_mode, _ = run(name, steps, warmup)
+                dts, profs, _, _, res_mode, lanes_s = run(name, steps, warmup)
+                res = {"value": steps / dts, "unit": "iterations/s", "ms_per_step": dts / steps * 1e3, "steps": steps, "warmup": warmup,
+                       "precision_mode": res_mode, "dtype": detail, "lanes": lanes_s}
+                gsteps, gsched = steps, "the timed run (one lane)"
+                if lanes_s == 2:
+                    gsteps = 2
+                    _, profs, _, _, _, _ = run(name, gsteps, 1, lanes="1")
+                    gsched = "serial side run (UMX_STREAMS=1, 2 steps)"
                 gg = profs[fam]
-                return {"value": steps / dts, "unit": "iterations/s", "ms_per_step": dts / steps * 1e3, "steps": steps, "warmup": warmup,
-                        "precision_mode": res_mode, "dtype": detail, "gemm_ms_per_step": gg["ms"] / steps,
-                        "gemm_tflops": gg["alg_flops"] / max(gg["ms"], 1e-9) / 1e9, "gemm_peak": peak_tf,
-                        "gemm_frac": gg["alg_flops"] / max(gg["ms"], 1e-9) / 1e9 / peak_tf,
-                        "executed_tflops": gg["mfma_flops"] / max(gg["ms"], 1e-9) / 1e9}
+                res.update({"gemm_schedule": gsched, "gemm_ms_per_step": gg["ms"] / gsteps,
+                            "gemm_tflops": gg["alg_flops"] / max(gg["ms"], 1e-9) / 1e9, "gemm_peak": peak_tf,
+                            "gemm_frac": gg["alg_flops"] / max(gg["ms"], 1e-9) / 1e9 / peak_tf,
+                            "executed_tflops": gg["mfma_flops"] / max(gg["ms"], 1e-9) / 1e9})
+                return res
             except Exception as exc:
                 return {"value": None, "error": f"{type(exc).__name__}: {exc}"}
 

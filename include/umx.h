@@ -72,11 +72,6 @@ const char* umx_last_error(const umx_engine* eng);
  *                significant bits) x three fp16 planes (weights, exact), 4 MFMA products; reverse pass two bf16 planes, 3 products
  *                (16-bit).  Meets the tolerances with a 250x margin on forces; operand range +-4094 (UMX_ERR_RANGE beyond).
  *   split-bf16 : forward as bf16x3 (6 products), reverse as split (3 products).
- *   f16x2b8    : (opt-in) forward operands as two fp16 planes + two bf8 planes of 16 x activation (25 significant bits) x three
- *                exact fp16 planes + two bf8 planes of the weights: the four products down to 2^-11 on v_mfma_f32_*_f16, the two
- *                2^-22-order ones on v_mfma_scale_f32_32x32x64_f8f6f4 (bf8, K = 64, twice the rate) -- >= 24-bit products in 5
- *                instruction slots instead of 6; reverse pass as bf16x3.  Operand range as split (+-4094).  0.7 % faster than bf16x3
- *                at c3 (the GEMMs are power- and fill-limited, not issue-limited: umx_gemm_q.h).
  *   fp32       : every GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32).
  * ENERGY ERROR BOUNDS against float64 arithmetic on the same weights (pre-registered here; tests/test_gpu_baseline_sizes.py asserts
  * exactly these): UMX_ENERGY_TOL_EV in the default and the split modes at every BASELINE size (up to 20 000 atoms per image),
@@ -103,12 +98,12 @@ int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes);
  * umx_model_variant: "ff=spectral|grid(G=..);emb=rand_emb|pos_emb|lin_emb;datasets=N" of the loaded blob ("" before).                 */
 const char* umx_model_variant(const umx_engine* eng);
 
-/* Precision mode for the NEXT umx_load_weights ("auto", "bf16x3" (= "split-exact"), "split" (= "split-f16"), "split-bf16", "f16x2b8", "fp32"); NULL or "" = back to
+/* Precision mode for the NEXT umx_load_weights ("auto", "bf16x3" (= "split-exact"), "split" (= "split-f16"), "split-bf16", "fp32"); NULL or "" = back to
  * the UMX_PRECISION environment variable.  The Python binding uses it to re-load an engine in split-bf16 when an evaluation
  * returned UMX_ERR_RANGE (ABI v6).                                                                                   */
 int umx_set_precision(umx_engine* eng, const char* mode);
 
-/* The arithmetic the engine is in NOW: "bf16x3", "split-f16", "split-bf16", "f16x2b8" or "fp32" ("" before weights are loaded) -- what "auto"
+/* The arithmetic the engine is in NOW: "bf16x3", "split-f16", "split-bf16" or "fp32" ("" before weights are loaded) -- what "auto"
  * resolved to (ABI v7).  The returned string is static.                                                              */
 const char* umx_precision_mode(const umx_engine* eng);
 

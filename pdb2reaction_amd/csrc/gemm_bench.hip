@@ -290,9 +290,9 @@ static int f16_mode(long M, int N, int K) {
         CK(hipMemcpy(c0.data(), C, c0.size() * 4, hipMemcpyDeviceToHost));
         CK(hipMemset(C, 0, M * (long)N * 4)); hipLaunchKernelGGL((gemm_qf_kernel<1, 2>), gw, dim3(512), 0, 0, gf); CK(hipDeviceSynchronize()); cmp("bench kernel gemm_qf_kernel<1, 2>");
         CK(hipMemset(C, 0, M * (long)N * 4)); GemmPL gl = gf; gl.lda = 3L * K;      // (the library kernels keep lda = 3 x columns for every six-product form)
-        hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 3, 2, 0, 6, 3, 0, 1>), gw, dim3(512), 0, 0, gl); CK(hipDeviceSynchronize()); cmp("library kernel AF = 1, 256x256");
+        hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 3, 2, 0, 6, 3, 1>), gw, dim3(512), 0, 0, gl); CK(hipDeviceSynchronize()); cmp("library kernel AF = 1, 256x256");
         const dim3 gn2((unsigned)(((nm + 7) / 8) * 8 * ((N + 127) / 128)));
-        CK(hipMemset(C, 0, M * (long)N * 4)); hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0, 3, 2, 0, 6, 3, 0, 1>), gn2, dim3(512), 0, 0, gl); CK(hipDeviceSynchronize()); cmp("library kernel AF = 1, 256x128");
+        CK(hipMemset(C, 0, M * (long)N * 4)); hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0, 3, 2, 0, 6, 3, 1>), gn2, dim3(512), 0, 0, gl); CK(hipDeviceSynchronize()); cmp("library kernel AF = 1, 256x128");
         CK(hipMemset(C, 0, M * (long)N * 4)); hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0>), gn2, dim3(512), 0, 0, g3); CK(hipDeviceSynchronize()); cmp("library kernel planes, 256x128");
       }
       CK(hipMemset(C, 0, M * (long)N * 4));
@@ -306,32 +306,7 @@ static int f16_mode(long M, int N, int K) {
     }
     CK(hipMemset(C, 0, M * (long)N * 4));
     report("Q2 f16 x2 planes, 4 products", timeit([&] { hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 2, 2, 1, 4, 2>), gw, dim3(512), 0, 0, g2); }));
-    if (K % 64 == 0) {
-      GemmPL g8 = g2; g8.A8 = A8; g8.lda8 = 2L * K; g8.B8 = B8; g8.Bpl = reinterpret_cast<const unsigned short*>(Bq3h); g8.ldb = 3L * K;
-      CK(hipMemset(C, 0, M * (long)N * 4));
-      report("f16 x2 + bf8 / exact weights (X8)", timeit([&] { hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 2, 2, 1, 4, 3, 1>), gw, dim3(512), 0, 0, g8); }));
-      // what does each 8-bit product add?  (C with it) - (C without it) against the host sum of the decoded planes
-      std::vector<unsigned char> ha8((size_t)R * K * 2), hb8((size_t)N * K * 2);
-      CK(hipMemcpy(ha8.data(), A8, ha8.size(), hipMemcpyDeviceToHost)); CK(hipMemcpy(hb8.data(), B8, hb8.size(), hipMemcpyDeviceToHost));
-      auto dec = [](unsigned char b) { const int e = (b >> 2) & 31, m = b & 3; const double v = e ? std::ldexp(1.0 + m / 4.0, e - 15) : std::ldexp(m / 4.0, -14); return (b & 0x80) ? -v : v; };
-      auto at = [&](const std::vector<unsigned char>& v, int r, int k, int q) { return dec(v[((size_t)r * (K / 64) + k / 64) * 128 + q * 64 + k % 64]); };
-      std::vector<float> cs[4];
-      for (int skip = 0; skip < 4; ++skip) {
-        g8.x8_skip = skip; CK(hipMemset(C, 0, M * (long)N * 4));
-        hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 2, 2, 1, 4, 3, 1>), gw, dim3(512), 0, 0, g8); CK(hipDeviceSynchronize());
-        cs[skip].resize((size_t)R * N); CK(hipMemcpy(cs[skip].data(), C, cs[skip].size() * 4, hipMemcpyDeviceToHost));
-      }
-      for (int pr = 0; pr < 2; ++pr) {
-        double sxy = 0, sxx = 0, syy = 0;
-        for (int r = 0; r < 64; ++r) for (int n = 0; n < N; ++n) {
-          double want = 0; for (int k = 0; k < K; ++k) want += at(ha8, r, k, pr) * at(hb8, n, k, 1 - pr);
-          want = std::ldexp(want, -Q8_SHIFT);       // (2^-10 * 2^-10 and 2^-20 * 1)
-          const double got = (double)cs[pr ? 1 : 2][(size_t)r * N + n] - (double)cs[3][(size_t)r * N + n];     // skip = 2 keeps product 0, skip = 1 keeps product 1
-          sxy += want * got; sxx += want * want; syy += got * got;
-        }
-        printf("         8-bit product %d: (C with) - (C without) = %.4f x host sum of the decoded planes  (correlation %.4f, rms host %.3e)\n", pr, sxy / sxx, sxy / std::sqrt(sxx * syy), std::sqrt(sxx / (64.0 * N)));
-      }
-    }
+    // (the "f16 x2 + bf8" X8 form measured here in round 4 was removed in round 5: profiles/r04_gemm_shape_times_f16x2b8.txt, NOTES.md section 10)
     CK(hipMemset(C, 0, M * (long)N * 4));
     report("Q2 f16 x2 planes, 3 products", timeit([&] { hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 2, 2, 1, 3, 2>), gw, dim3(512), 0, 0, g2); }));
     CK(hipMemset(C, 0, M * (long)N * 4));

@@ -36,7 +36,7 @@ std::string g_create_err;
 struct Tensor { size_t off = 0; std::vector<int> shape; size_t count = 0; };
 
 struct RadialW {          // one RadialMLP (forward + transposed copies)
-  const float *w1g, *w1gT, *ts, *tt, *ln1w, *ln1b, *w2, *w2T, *b2, *ln2w, *ln2b, *w3, *w3T, *b3;
+  const float *w1g, *w1gT, *ln1w, *ln1b, *w2, *w2T, *b2, *ln2w, *ln2b, *w3, *w3T, *b3;
   const double *tsd, *ttd;     // the element tables of fc1 in double (fused radial head)
   int out;
 };
@@ -63,49 +63,29 @@ struct umx_engine {
   hipStream_t stream2 = nullptr;   // second lane: half-chunks alternate streams so HBM-bound producers overlap the other lane's GEMMs
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev_tok[2] = {nullptr, nullptr};   // matrix-pipe token of the two lanes (run_plans_alternating)
-  // side stream (round 3): the fused radial-MLP kernels are VALU-bound and depend on the edge geometry only (forward) / feed only the
-  // scalar dE/dd (reverse), so they are issued on stream2 NEXT TO an HBM-bound edge kernel of the main stream (fork / join by events)
-  bool side = false;               // UMX_SIDE=1 enables it.  Measured on c3 (A/B, one box): 401.4 -> 399.8 ms.  The overlap happens, but beside the main
-                                   // stream's edge kernel (whose small workgroups keep refilling every CU) the side kernels run 3x longer and spill into
-                                   // the next GEMM, which slows down by as much as was hidden; stream priorities change nothing on this pool.  Off by default.
-  hipEvent_t ev_sf = nullptr, ev_shead = nullptr, ev_stail = nullptr;
-  int radial_tr = 2;               // UMX_RADIAL_TR: 32-row MFMA tiles per workgroup tile of the fused radial kernels (1: 3 workgroups per CU, 2: 2)
-  int radial_fast = 0;             // UMX_RADIAL_FAST: transcendentals inside the fused radial kernels: 0 libm (default), 1 raw hardware, 2 refined hardware (umx_radial.h)
-  bool fused_radial = true;        // UMX_FUSED_RADIAL=0: the radial MLP's small layers as separate GEMM / LayerNorm launches (umx_radial.h fuses them)
-  int q3_stages = 2;               // UMX_Q3S: LDS ring depth of the forward Q3 GEMMs (2 or 3)
-  bool q3_wide = true;             // UMX_Q3WIDE=0 (dev): 256x128 tiles for every forward GEMM
-  bool q3 = true;                  // UMX_Q3=0: forward operands in the 32-column PL layout + 256x128 tiles (set before umx_load_weights)
-  bool rev_q3 = true;              // UMX_REV_Q3=0: reverse operands of the bf16x3 mode in the PL layout (256x128 tiles) instead of the quad-row layout
+  // Round 5 pruned the development levers whose A/B is settled (NOTES.md sections 5, 9, 10 keep the measurements): the PL-layout forward
+  // operands, pre-split A planes, three-plane PL reverse operands, ring depth 3, two-plane fp16 weights, hardware transcendentals / fp16
+  // products inside the fused radial kernels, the side stream, the unfused radial layers, the f16x2b8 mode.  What is left below is what runs.
   std::map<const float*, bool> planes_q;                  // weight plane copies stored in the quad-row layout (else PL)
   float odd_sign = -1.0f;          // sign-alternating operand rows (umx_kernels_pl.h): -1 = on (default), +1 = off (UMX_ALT_ROWS=0, dev A/B)
   int rev_planes = 2;              // bf16 planes of the REVERSE-pass operands: 2 (3 products, 16-bit) or 3 (6 products, 24-bit: UMX_PRECISION=bf16x3)
-  int fwd_fmt = 1;                 // forward operand format (QFmt, umx_kernels_pl.h): 1 = two fp16 planes (UMX_PRECISION=split), 0 = three bf16 planes (split-bf16),
-                                   // 2 = two fp16 planes + two 8-bit planes (UMX_PRECISION=f16x2b8: 24-bit products, the third-plane terms on the bf8 matrix instruction)
-                                   // 3 = plain float32 quad-row blocks, split into three bf16 planes by the GEMM in registers (the bf16 forward planes since round 4)
-  std::map<const float*, const unsigned char*> planes8;   // fwd_fmt 2: the 8-bit planes ("O8" layout, umx_gemm_q.h) of a weight
-  bool a_f32 = true;               // UMX_A_F32=0: the A operands of the bf16-plane GEMMs as three pre-split bf16 planes (6 B per element; rounds 2-3) instead of float32
-  int f32rows_layout = 1;          // UMX_GRAD_F32=0: g_rad -> fc3^T as three PL planes (6 B per element) instead of float32 rows split by the GEMM (needs a_f32)
-  bool rev_qf = false;             // derived at load: reverse quad-row operands (g_msg, g_hg) as float32 blocks (bf16x3, quad-row reverse layout, a_f32)
+  int fwd_fmt = 3;                 // forward operand format (QFmt, umx_kernels_pl.h): 1 = two fp16 planes (UMX_PRECISION=split),
+                                   // 3 = plain float32 quad-row blocks, split into three bf16 planes by the GEMM in registers (bf16x3, split-bf16)
+  bool rev_qf = false;             // derived at load: reverse quad-row operands (g_msg, g_hg) as float32 blocks (bf16x3)
   std::string precision;           // umx_set_precision: overrides UMX_PRECISION when non-empty
   bool node_ctx = false;           // set around the node-level launches (NodeCtx): only those take the float64-accumulating kernel
   bool node_f64_on = true;         // UMX_NODE_F64=0: node-level linears (atom-wise SO(3) linears, scalar MLP, readout and their transposes) on the
                                    // fp32 MFMA instead of the float64-accumulating kernel (k_gemm_f64acc).  Measured (round 3): the fp32-MFMA form of
                                    // these 14 chained GEMMs shifts the energy by a one-signed -2e-8 eV per atom; the double form costs +1 % at c3
-  bool deg_split = true;           // UMX_DEG_SPLIT=0 (dev): edge-degree fc3 / fc3^T on the fp32-MFMA GEMM instead of the split path
-  int f16_prod = 4;                // plane products of the fp16 form (UMX_F16_PRODUCTS): 4 = exact three-plane weights (hh, hl, lh, h.lo2),
-                                   // 3 = two-plane weights (hh, hl, lh; biases the energy by ~2.5e-8 eV/atom)
   std::map<const float*, float> plane_scale;             // fp16 form: power-of-two scale folded into the weight planes
-  bool wide_tiles = true;          // UMX_WIDE=0: 256x128 tiles for every GEMM
-  int mfma16 = 1;                  // UMX_MFMA16: 0 = v_mfma_f32_32x32x16_bf16 everywhere, 1 = 16x16x32 where it measured faster, 2 = everywhere
-  bool fuse_modrot = true;         // UMX_FUSE_MODROT=0: separate k_modulate_bwd_pl + k_gather_rotate_bwd (debug: exposes g_xrot)
   int n_lanes = 0;                 // UMX_STREAMS: 1 = one lane, 2 = two chunks in flight (matrix segments alternating between the lanes), unset / 0 = the
                                    // engine's choice (round 5): two lanes for batches of >= lanes_auto_edges directed edges whose largest image fits half
                                    // the workspace budget.  Measured A/B on one box (profiles/r05_lanes_ab.txt): c3 (16 x 2000 atoms, 2.28 M edges) 505.2 ->
                                    // 499.0 ms, c4 string (24 images) 761.2 -> 751.4 ms, bitwise identical results; the 2-image shard of the 8-GPU run +-0;
                                    // c2 (366 k edges) +2 %, c1 +25 % -- small batches lose to the halved chunks, hence the threshold
   long lanes_auto_edges = 1200000; // UMX_LANES_AUTO_EDGES
-  int stream_cap = 0;              // UMX_STREAM_BLOCKS: two-lane mode caps the grids of the grid-stride streaming kernels at this many
-                                   // workgroups (multiple of 8; default 512 = two per CU) so they run BESIDE the other lane's GEMM
+  int stream_cap = 512;            // two-lane mode caps the grids of the grid-stride streaming kernels at this many workgroups (two per CU) so
+                                   // that they run BESIDE the other lane's GEMM
   bool throttle = false;           // set while a two-lane evaluation is being issued
   // graph-parallel single-image mode (umx_gp_begin / umx_gp_step): this rank builds the incoming edges of targets [gp_lo, gp_hi)
   bool gp = false; long gp_lo = 0, gp_hi = 0;
@@ -162,7 +142,6 @@ struct umx_engine {
   int last_parts = 0;              // partitions used by the most recent evaluation (0: the ordinary path)
   int last_lanes = 1;              // lanes (chunks in flight) of the most recent evaluation (umx_last_lanes)
   int arena_allocs = 0;            // how often the workspace has been (re-)allocated (umx_workspace_stats)
-  int radial_f16 = 0;              // UMX_RADIAL_F16: bit 0 = fc1, bit 1 = fc2 of the fused radial head on four fp16 plane products (default mode, TR = 2, FAST = 0)
   bool ws_eager = false;           // UMX_WS_EAGER=1: size the workspace for the whole batch at once (the behaviour before ABI v8)
   long ws_soft_edges = 320000;     // UMX_WS_SOFT_EDGES: directed edges per chunk the workspace starts with when nothing else is known
   double t_first_eval = -1.0;      // steady-clock seconds of the first evaluation (amortised workspace growth)
@@ -249,7 +228,6 @@ int launch_gemm(umx_engine* eng, const GemmP& p, int amode, int cplx, int epi, i
     case A_PLAIN * 100 + 10 + E_BIAS: hipLaunchKernelGGL((umx_gemm_kernel<A_PLAIN, 1, E_BIAS>), grid, block, 0, eng->stream, p); break;
     case A_MODUL * 100 + 0 + E_BIAS: hipLaunchKernelGGL((umx_gemm_kernel<A_MODUL, 0, E_BIAS>), grid, block, 0, eng->stream, p); break;
     case A_MODUL * 100 + 10 + E_BIAS: hipLaunchKernelGGL((umx_gemm_kernel<A_MODUL, 1, E_BIAS>), grid, block, 0, eng->stream, p); break;
-    case A_GAUSS * 100 + 0 + E_TABLES: hipLaunchKernelGGL((umx_gemm_kernel<A_GAUSS, 0, E_TABLES>), grid, block, 0, eng->stream, p); break;
     case A_SILU * 100 + 0 + E_BIAS: hipLaunchKernelGGL((umx_gemm_kernel<A_SILU, 0, E_BIAS>), grid, block, 0, eng->stream, p); break;
     default: return fail(eng, UMX_ERR_ARG, "gemm: variant not instantiated");
   }
@@ -293,34 +271,39 @@ int gemm_cplx(umx_engine* eng, const float* A, long lda, int offRe, int offIm, c
   return launch_gemm(eng, p, R ? A_MODUL : A_PLAIN, 1, E_BIAS);
 }
 
-// split-precision GEMM on pre-split operands.  P = 3: a FORWARD product (quad-row kernels of umx_gemm_q.h: fp16 planes by default,
-// three bf16 planes in split-bf16 mode; PL layout with UMX_Q3=0), P = 2: a reverse-pass product (bf16 planes, umx_gemm_pl.h).
+// Split-precision GEMM of the large SO(2) / radial linears.  P = 3 at the call site: a FORWARD product, P = 2: a reverse-pass product (the
+// operand formats and plane counts are the engine's, fixed by the precision mode at umx_load_weights):
+//   forward, bf16x3 / split-bf16 : A = float32 quad-row blocks split into three bf16 planes by the GEMM in registers, B = three bf16 planes (6 products)
+//   forward, split (fp16)        : A = two fp16 planes of 16 x activation, B = three exact fp16 planes (4 products)
+//   reverse, bf16x3              : conv^T: A = float32 quad-row blocks (g_msg / g_hg), B = three bf16 planes, 6 products (umx_gemm_q.h);
+//                                  fc3^T: A = float32 ROWS (g_rad, a_f32rows) split by umx_gemm_pl16_kernel<.., AF = 1>
+//   reverse, split / split-bf16  : A, B = two PL bf16 planes, 3 products (umx_gemm_pl.h)
 // Wkey = fp32 device pointer of the weight (its plane copy is looked up); a_cols = total columns of the A matrix; offsets in columns.
 int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_cols, int offA0, int offA1, const float* Wkey, int bHalf,
             const float* bias, float* Cp, long ldc, int offC, int offCi, long M, int N, int K, float conj, bool a_f32rows = false) {
-  // a_f32rows: a reverse-pass A operand stored as plain float32 ROWS (k_modrot_bwd_pl<0>), split by umx_gemm_pl16_kernel<.., AF = 1> in registers
   if (M <= 0) return UMX_OK;
   auto it = eng->planes.find(Wkey);
   if (it == eng->planes.end()) return fail(eng, UMX_ERR_ARG, "gemm_pl: weight has no PL copy");
   if (K % 32 != 0) return fail(eng, UMX_ERR_ARG, "gemm_pl: K not a multiple of 32");
-  const bool fwd = (P == 3);                 // the call sites say 3 = forward product, 2 = reverse product; the reverse plane count is the engine's
+  const bool fwd = (P == 3);
   if (!fwd) P = eng->rev_planes;
   GemmPL q;
   std::memset(&q, 0, sizeof(q));
   q.Apl = Apl; q.lda = (long)a_cols * P; q.offA0 = offA0; q.offA1 = offA1; q.Bpl = it->second; q.ldb = (long)K * P; q.bHalf = bHalf;
   q.Cp = Cp; q.ldc = ldc; q.offC = offC; q.offCi = offCi; q.bias = bias; q.conj = conj; q.M = (int)M; q.N = N; q.K = K;
   q.odd_sign = eng->odd_sign;
-  // reverse pass (P=2: two ring stages of a 256x256 tile fit the LDS): the wide tile needs a third less L2->LDS fill per FLOP and
-  // measured 9-11 % faster wherever N fills whole tiles (UMX_WIDE=0 disables)
+  // 256 x 256 tiles (two ring stages fit the LDS) wherever N fills whole tiles: a third less L2->LDS fill per FLOP, 9-11 % faster.
   // Small systems (c1: 50 atoms x 8 images = 13 k edges = 51 row tiles): a launch whose wide grid does not even put one workgroup on
   // every CU is bound by ONE tile's k-loop, so the narrow tiles (twice the workgroups, half the work each) finish sooner.
   const int bmr = cplx ? 128 : 256;
   const long nM = (M + bmr - 1) / bmr;
   const bool fills = nM * (N / (cplx ? 128 : 256)) >= 256;          // wide grid >= one workgroup per CU
-  const bool wide = eng->wide_tiles && !fwd && P == 2 && N % (cplx ? 128 : 256) == 0 && fills;
+  const bool wide = N % (cplx ? 128 : 256) == 0 && fills;
   const int bnc = wide ? (cplx ? 128 : 256) : (cplx ? 64 : 128);
   const long nN = (N + bnc - 1) / bnc;
-  dim3 grid((unsigned)(((nM + 7) / 8) * 8 * nN)), block(512);
+  const dim3 grid((unsigned)(((nM + 7) / 8) * 8 * nN)), block(512);
+  const auto pq = eng->planes_q.find(Wkey);
+  const bool quad = fwd || (P == 3 && pq != eng->planes_q.end() && pq->second);      // quad-row operands (umx_gemm_q.h)
   ProfRec* pr = nullptr;
   if (eng->prof_on) {
     if (eng->prof_used == eng->prof.size()) {
@@ -329,90 +312,47 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
     pr = &eng->prof[eng->prof_used++];
     pr->flops = cplx ? 8.0 * M * (double)N * K : 2.0 * M * (double)N * K;
     pr->M = (int)M; pr->N = N; pr->K = K; pr->amode = 9; pr->cplx = cplx; pr->gz = 1;
-    pr->prec = (fwd && eng->q3 && eng->fwd_fmt == 2) ? 28 : (fwd && eng->q3 && eng->fwd_fmt == 1) ? 20 + eng->f16_prod : P;      // 28: fp16 x 2 + bf8 (4 + 2 half-cost products); 23 / 24: two fp16 planes, 3 / 4 products; 3 / 2: bf16 planes, 6 / 3 products
+    pr->prec = (fwd && eng->fwd_fmt == 1) ? 24 : P;      // 24: two fp16 planes, 4 products; 3 / 2: bf16 planes, 6 / 3 products
     HIPCHK(eng, hipEventRecord(pr->a, eng->stream));
   }
-  // MFMA shape per GEMM (measured in the c3 pipeline): 16x16x32 wins 1-7 % on the complex SO(2) GEMMs and on K >= 512,
-  // 32x32x16 wins 5-10 % on the short-K plain ones (radial fc3 and its transpose, conv-2 m=0)
-  const bool use16 = eng->mfma16 >= 2 || (eng->mfma16 == 1 && (cplx || K >= 512));
-  const auto pq = eng->planes_q.find(Wkey);
-  const bool revq = !fwd && P == 3 && pq != eng->planes_q.end() && pq->second;      // reverse operands of the bf16x3 mode in the quad-row layout
-  if (revq) {
-    const bool wq = eng->q3_wide && N % (cplx ? 128 : 256) == 0 && fills;
-    const int bnq = wq ? (cplx ? 128 : 256) : (cplx ? 64 : 128);
-    const long nNq = (N + bnq - 1) / bnq;
-    dim3 gq((unsigned)(((nM + 7) / 8) * 8 * nNq));
-    if (eng->rev_qf) {         // A = float32 blocks, split in registers (umx_gemm_q.h, AF)
-      if (cplx) { if (wq) hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1, 3, 2, 0, 6, 3, 0, 1>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<1, 0, 3, 2, 0, 6, 3, 0, 1>), gq, block, 0, eng->stream, q); }
-      else      { if (wq) hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 3, 2, 0, 6, 3, 0, 1>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0, 3, 2, 0, 6, 3, 0, 1>), gq, block, 0, eng->stream, q); }
-    } else if (cplx) { if (wq) hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<1, 0>), gq, block, 0, eng->stream, q); }
-    else      { if (wq) hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0>), gq, block, 0, eng->stream, q); }
-  } else if (fwd && eng->q3) {
-    // forward operands in the quad-row layout: 256x256 tiles where N fills them, else 256x128 (umx_gemm_q.h)
-    const bool wq = eng->q3_wide && N % (cplx ? 128 : 256) == 0 && fills;
-    const int bnq = wq ? (cplx ? 128 : 256) : (cplx ? 64 : 128);
-    const long nNq = (N + bnq - 1) / bnq;
-    dim3 gq((unsigned)(((nM + 7) / 8) * 8 * nNq));
-    const int S = eng->q3_stages;             // ring depth: 2 (default) or 3 (UMX_Q3S=3: 144 KB wide / 108 KB narrow)
-    if (eng->fwd_fmt == 2) {
-      // two fp16 planes + two 8-bit planes of the activations, three fp16 planes (exact) + two 8-bit planes of the weights (umx_gemm_q.h, X8);
-      // the 8-bit planes of A follow its half planes in the same buffer
-      if (K % 64 != 0 || offA0 % 64 != 0 || offA1 % 64 != 0) return fail(eng, UMX_ERR_ARG, "gemm_pl: the f16x2b8 form needs K and the column offsets in multiples of 64");
-      const auto sc = eng->plane_scale.find(Wkey);
-      const auto p8 = eng->planes8.find(Wkey);
-      if (sc == eng->plane_scale.end() || p8 == eng->planes8.end()) return fail(eng, UMX_ERR_ARG, "gemm_pl: weight has no f16x2b8 plane copy");
-      q.lda = (long)a_cols * 2; q.ldb = (long)K * 3;
-      q.cscale = 1.0f / (QF16_SCALE * sc->second);
-      q.A8 = reinterpret_cast<const unsigned char*>(Apl) + (size_t)((M + 3) / 4 * 4) * a_cols * 4; q.lda8 = (long)a_cols * 2; q.B8 = p8->second;
-      if (cplx) { if (wq) hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1, 2, 2, 1, 4, 3, 1>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<1, 0, 2, 2, 1, 4, 3, 1>), gq, block, 0, eng->stream, q); }
-      else      { if (wq) hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 2, 2, 1, 4, 3, 1>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0, 2, 2, 1, 4, 3, 1>), gq, block, 0, eng->stream, q); }
-    } else if (eng->fwd_fmt == 1) {
-      // two fp16 planes of 16 x (activations), three (exact) or two planes of s_w x (weights): C = (A' . B'^T) / (16 s_w)
-      q.lda = (long)a_cols * 2; q.ldb = (long)K * (eng->f16_prod == 3 ? 2 : 3);
-      const auto sc = eng->plane_scale.find(Wkey);
-      if (sc == eng->plane_scale.end()) return fail(eng, UMX_ERR_ARG, "gemm_pl: weight has no fp16 plane copy");
-      q.cscale = 1.0f / (QF16_SCALE * sc->second);
-#define UMX_QH(CP, WD)                                                                                                      \
-      do {                                                                                                                  \
-        if (eng->f16_prod == 3) { if (S == 3) hipLaunchKernelGGL((umx_gemm_q_kernel<CP, WD, 2, 3, 1, 3, 2>), gq, block, 0, eng->stream, q);  \
-                                  else hipLaunchKernelGGL((umx_gemm_q_kernel<CP, WD, 2, 2, 1, 3, 2>), gq, block, 0, eng->stream, q); }       \
-        else                    { if (S == 3) hipLaunchKernelGGL((umx_gemm_q_kernel<CP, WD, 2, 3, 1, 4, 3>), gq, block, 0, eng->stream, q);  \
-                                  else hipLaunchKernelGGL((umx_gemm_q_kernel<CP, WD, 2, 2, 1, 4, 3>), gq, block, 0, eng->stream, q); }       \
-      } while (0)
-      if (cplx) { if (wq) UMX_QH(1, 1); else UMX_QH(1, 0); }
-      else      { if (wq) UMX_QH(0, 1); else UMX_QH(0, 0); }
-#undef UMX_QH
-    } else if (eng->fwd_fmt == 3) {
-      // A = float32 quad-row blocks, split into the three bf16 planes in registers; weights as three bf16 planes (umx_gemm_q.h, AF = 1)
-#define UMX_QF(CP, WD) do { if (S == 3) hipLaunchKernelGGL((umx_gemm_q_kernel<CP, WD, 3, 3, 0, 6, 3, 0, 1>), gq, block, 0, eng->stream, q);   \
-                            else hipLaunchKernelGGL((umx_gemm_q_kernel<CP, WD, 3, 2, 0, 6, 3, 0, 1>), gq, block, 0, eng->stream, q); } while (0)
-      if (cplx) { if (wq) UMX_QF(1, 1); else UMX_QF(1, 0); }
-      else      { if (wq) UMX_QF(0, 1); else UMX_QF(0, 0); }
-#undef UMX_QF
-    } else if (cplx) {
-      if (wq) { if (S == 3) hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1, 3, 3>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1>), gq, block, 0, eng->stream, q); }
-      else    { if (S == 3) hipLaunchKernelGGL((umx_gemm_q_kernel<1, 0, 3, 3>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<1, 0>), gq, block, 0, eng->stream, q); }
-    } else {
-      if (wq) { if (S == 3) hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 3, 3>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1>), gq, block, 0, eng->stream, q); }
-      else    { if (S == 3) hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0, 3, 3>), gq, block, 0, eng->stream, q); else hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0>), gq, block, 0, eng->stream, q); }
-    }
-  } else if (P == 3 && a_f32rows) {
-    if (cplx || N > 128) return fail(eng, UMX_ERR_ARG, "gemm_pl: float32-row operands are instantiated for the plain N <= 128 (radial fc3^T) product only");
-    q.lda = (long)a_cols * 2;                  // row pitch in 2-byte units
-    hipLaunchKernelGGL((umx_gemm_pl16_kernel<0, 3, 2, 4, 2, 2, 2, 0, 1>), grid, block, 0, eng->stream, q);     // (an 8 x 1 wave layout measured the same)
+#define UMX_Q(...)                                                                                                             \
+  do {                                                                                                                         \
+    if (cplx) { if (wide) hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1, __VA_ARGS__>), grid, block, 0, eng->stream, q);          \
+                else hipLaunchKernelGGL((umx_gemm_q_kernel<1, 0, __VA_ARGS__>), grid, block, 0, eng->stream, q); }             \
+    else      { if (wide) hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, __VA_ARGS__>), grid, block, 0, eng->stream, q);          \
+                else hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0, __VA_ARGS__>), grid, block, 0, eng->stream, q); }             \
+  } while (0)
+  if (quad && fwd && eng->fwd_fmt == 1) {
+    // two fp16 planes of 16 x (activations), three exact planes of s_w x (weights): C = (A' . B'^T) / (16 s_w)
+    q.lda = (long)a_cols * 2; q.ldb = (long)K * 3;
+    const auto sc = eng->plane_scale.find(Wkey);
+    if (sc == eng->plane_scale.end()) return fail(eng, UMX_ERR_ARG, "gemm_pl: weight has no fp16 plane copy");
+    q.cscale = 1.0f / (QF16_SCALE * sc->second);
+    UMX_Q(2, 2, 1, 4, 3);
+  } else if (quad) {
+    // A = float32 quad-row blocks, split into the three bf16 planes in registers; weights as three bf16 planes
+    if (fwd && eng->fwd_fmt != 3) return fail(eng, UMX_ERR_ARG, "gemm_pl: unknown forward operand format");
+    if (!fwd && !eng->rev_qf) return fail(eng, UMX_ERR_ARG, "gemm_pl: quad-row reverse operands exist in the bf16x3 mode only");
+    q.lda = (long)a_cols * 3; q.ldb = (long)K * 3;
+    UMX_Q(3, 2, 0, 6, 3, 1);
   } else if (P == 3) {
-    if (use16) {
-      if (cplx) hipLaunchKernelGGL((umx_gemm_pl16_kernel<1, 3, 2, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
-      else hipLaunchKernelGGL((umx_gemm_pl16_kernel<0, 3, 2, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
+    // three-plane PL products of the bf16x3 reverse pass: the radial fc3^T of the layers (A = float32 rows, split in registers) and of the
+    // edge-degree embedding (A = three PL planes written by k_rotate_back_bwd<3, 3>); both plain, N = 128, 256 x 128 tiles
+    if (cplx || N > 128) return fail(eng, UMX_ERR_ARG, "gemm_pl: three-plane PL products are instantiated for the plain N <= 128 (radial fc3^T) products only");
+    const dim3 g128((unsigned)(((nM + 7) / 8) * 8 * ((N + 127) / 128)));
+    if (a_f32rows) {
+      q.lda = (long)a_cols * 2;                  // row pitch in 2-byte units
+      hipLaunchKernelGGL((umx_gemm_pl16_kernel<0, 3, 2, 4, 2, 2, 2, 0, 1>), g128, block, 0, eng->stream, q);     // (an 8 x 1 wave layout measured the same)
     } else {
-      if (cplx) hipLaunchKernelGGL((umx_gemm_pl_kernel<1, 3, 2, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
-      else hipLaunchKernelGGL((umx_gemm_pl_kernel<0, 3, 2, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
+      hipLaunchKernelGGL((umx_gemm_pl_kernel<0, 3, 2, 4, 2, 2, 2>), g128, block, 0, eng->stream, q);
     }
   } else if (wide) {
     if (cplx) hipLaunchKernelGGL((umx_gemm_pl16_kernel<1, 2, 2, 4, 2, 2, 4>), grid, block, 0, eng->stream, q);
     else hipLaunchKernelGGL((umx_gemm_pl16_kernel<0, 2, 2, 4, 2, 2, 4>), grid, block, 0, eng->stream, q);
   } else {
-    if (use16) {
+    // MFMA shape per GEMM (measured in the c3 pipeline): 16x16x32 wins 1-7 % on the complex SO(2) GEMMs and on K >= 512,
+    // 32x32x16 wins 5-10 % on the short-K plain ones (radial fc3^T, conv-2^T m = 0)
+    if (cplx || K >= 512) {
       if (cplx) hipLaunchKernelGGL((umx_gemm_pl16_kernel<1, 2, 3, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
       else hipLaunchKernelGGL((umx_gemm_pl16_kernel<0, 2, 3, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
     } else {
@@ -420,6 +360,7 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
       else hipLaunchKernelGGL((umx_gemm_pl_kernel<0, 2, 3, 4, 2, 2, 2>), grid, block, 0, eng->stream, q);
     }
   }
+#undef UMX_Q
   HIPCHK(eng, hipGetLastError());
   if (pr) HIPCHK(eng, hipEventRecord(pr->b, eng->stream));
   return UMX_OK;
@@ -447,7 +388,7 @@ struct WS {
   float* rad[NL];
   float* hg[NL];
   float* msg[NL];
-  float *xrot, *hid, *gmsg, *ghg, *gy1, *grad, *e128a, *e128b, *ggauss;
+  float *xrot, *hid, *gmsg, *ghg, *gy1, *grad, *e128a;
   unsigned short *y1pl, *hidpl, *a2pl, *gmsgpl, *ghgpl, *gradpl;   // split path: pre-split GEMM operands (forward: quad-row planes, reverse: PL)
 };
 
@@ -462,7 +403,7 @@ struct Bump {
 };
 
 // workspace mode: 0 = fp32 path, else (planes of the forward operands) + 16 when the reverse operands have three planes
-inline int ws_mode(const umx_engine* eng) { return !eng->pl ? 0 : ((eng->q3 && (eng->fwd_fmt == 1 || eng->fwd_fmt == 3)) ? 2 : 3) + (eng->rev_planes == 3 ? 16 : 0) + (eng->rev_qf ? 32 : 0); }   // (fwd_fmt 2: two half planes + two byte planes = 3 x 2 bytes)
+inline int ws_mode(const umx_engine* eng) { return !eng->pl ? 0 : 2 + (eng->rev_planes == 3 ? 16 : 0) + (eng->rev_qf ? 32 : 0); }   // (forward operands: 4 B per element in both split formats)
 // ... + the grid points of the grid feed-forward in bits 8+ (its per-node buffers scale with G; 0 = spectral feed-forward)
 inline int ws_mode_g(const umx_engine* eng) { return ws_mode(eng) | ((eng->ff_grid ? eng->grid_G : 0) << 8); }
 
@@ -498,7 +439,7 @@ void carve_persist(Bump& b, long nn, long ne, WS& t, int gridG = 0) {
 void carve_trans(Bump& b, long ne, WS& t, int pl) {
   t.ra = b.take<float>(ne * RH);
   t.hid = b.take<float>(ne * ROW); t.gy1 = b.take<float>(ne * XROT);
-  t.e128a = b.take<float>(ne * RH); t.e128b = b.take<float>(ne * RH); t.ggauss = b.take<float>(ne * NG);
+  t.e128a = b.take<float>(ne * RH);
   t.xrot = t.ghg = t.grad = nullptr;
   t.y1pl = t.hidpl = t.a2pl = t.gmsgpl = t.ghgpl = t.gradpl = nullptr;
   if (pl) {
@@ -537,68 +478,17 @@ int dbg_capture(umx_engine* eng, const std::string& name, const void* dptr, size
 // Each is split into its small layers (fp32 GEMMs + LayerNorm/SiLU kernels: "streaming" work) and the one large fc3 GEMM, so that
 // the two-lane executor can treat the large GEMM as a matrix-pipe segment (see Plan below).
 int radial_fwd_head(umx_engine* eng, const WS& w, const RadialW& r, int slot, long ne) {
-  hipStream_t s = eng->stream;
+  // one persistent kernel: gaussians -> fc1 -> LN+SiLU -> fc2 -> LN+SiLU -> the fc3 operand (fp16 planes / float32 quad-row blocks of the
+  // split modes, or fp32 rows in w.ra); the intermediate rows never reach HBM
   const bool planes = eng->pl && eng->planes.count(r.w3);
-  if (eng->fused_radial && (!planes || eng->q3)) {
-    // one persistent kernel: gaussians -> fc1 -> LN+SiLU -> fc2 -> LN+SiLU -> fc3 operand (Q3 planes, or fp32 rows in w.ra)
-    const int TR = eng->radial_tr;
-    const unsigned tiles = nblk(ne, 32 * TR);
-    const unsigned cap = TR == 1 ? 768u : 512u;          // persistent: three / two workgroups per CU
-    const dim3 grid(vgrid(eng, tiles < cap ? tiles : cap));
-#define UMX_RH_ARGS grid, dim3(256), 0, s, w.evec, w.ez, eng->gcoef, eng->d_gmu, r.w1g, r.tsd, r.ttd, r.ln1w, r.ln1b, r.w2, r.b2, r.ln2w, r.ln2b, w.h1pre[slot], w.h2pre[slot]
-#define UMX_RH_LAUNCH(Q, OUT)                                                                                           \
-    do {                                                                                                              \
-      const int fm = eng->radial_fast;                                                                                \
-      if (TR == 1) {                                                                                                  \
-        if (fm == 2) hipLaunchKernelGGL((k_radial_head<Q, 2, 1>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign, (unsigned char*)nullptr);                      \
-        else if (fm == 1) hipLaunchKernelGGL((k_radial_head<Q, 1, 1>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign, (unsigned char*)nullptr);                 \
-        else hipLaunchKernelGGL((k_radial_head<Q, 0, 1>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign, (unsigned char*)nullptr);                              \
-      } else {                                                                                                        \
-        if (fm == 2) hipLaunchKernelGGL((k_radial_head<Q, 2, 2>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign, (unsigned char*)nullptr);                      \
-        else if (fm == 1) hipLaunchKernelGGL((k_radial_head<Q, 1, 2>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign, (unsigned char*)nullptr);                 \
-        else if (Q == 2 && eng->radial_f16 == 3) hipLaunchKernelGGL((k_radial_head<Q, 0, 2, (Q == 2 ? 3 : 0)>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign, (unsigned char*)nullptr); \
-        else if (Q == 2 && eng->radial_f16 == 2) hipLaunchKernelGGL((k_radial_head<Q, 0, 2, (Q == 2 ? 2 : 0)>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign, (unsigned char*)nullptr); \
-        else if (Q == 2 && eng->radial_f16 == 1) hipLaunchKernelGGL((k_radial_head<Q, 0, 2, (Q == 2 ? 1 : 0)>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign, (unsigned char*)nullptr); \
-        else hipLaunchKernelGGL((k_radial_head<Q, 0, 2>), UMX_RH_ARGS, (void*)(OUT), ne, eng->odd_sign, (unsigned char*)nullptr);                              \
-      }                                                                                                               \
-    } while (0)
-    ProfRec* pr = prof_open(eng, 2.0 * ne * ((double)NG * RH + (double)RH * RH), -1, ne, RH, NG + RH);
-    if (planes && eng->fwd_fmt == 2) {
-      unsigned char* a2o8 = reinterpret_cast<unsigned char*>(w.a2pl) + (size_t)((ne + 3) / 4 * 4) * RH * 4;
-      const int fm = eng->radial_fast;
-      if (TR == 1) {
-        if (fm == 2) hipLaunchKernelGGL((k_radial_head<3, 2, 1>), UMX_RH_ARGS, (void*)w.a2pl, ne, eng->odd_sign, a2o8);
-        else if (fm == 1) hipLaunchKernelGGL((k_radial_head<3, 1, 1>), UMX_RH_ARGS, (void*)w.a2pl, ne, eng->odd_sign, a2o8);
-        else hipLaunchKernelGGL((k_radial_head<3, 0, 1>), UMX_RH_ARGS, (void*)w.a2pl, ne, eng->odd_sign, a2o8);
-      } else {
-        if (fm == 2) hipLaunchKernelGGL((k_radial_head<3, 2, 2>), UMX_RH_ARGS, (void*)w.a2pl, ne, eng->odd_sign, a2o8);
-        else if (fm == 1) hipLaunchKernelGGL((k_radial_head<3, 1, 2>), UMX_RH_ARGS, (void*)w.a2pl, ne, eng->odd_sign, a2o8);
-        else hipLaunchKernelGGL((k_radial_head<3, 0, 2>), UMX_RH_ARGS, (void*)w.a2pl, ne, eng->odd_sign, a2o8);
-      }
-    } else if (planes && eng->fwd_fmt == 1) UMX_RH_LAUNCH(2, w.a2pl); else if (planes && eng->fwd_fmt == 3) UMX_RH_LAUNCH(4, w.a2pl); else if (planes) UMX_RH_LAUNCH(1, w.a2pl); else UMX_RH_LAUNCH(0, w.ra);
+  const unsigned tiles = nblk(ne, 64);                      // two 32-row MFMA tiles per workgroup tile, two workgroups per CU
+  const dim3 grid(vgrid(eng, tiles < 512u ? tiles : 512u));
+  ProfRec* pr = prof_open(eng, 2.0 * ne * ((double)NG * RH + (double)RH * RH), -1, ne, RH, NG + RH);
+#define UMX_RH_LAUNCH(Q, OUT) hipLaunchKernelGGL((k_radial_head<Q>), grid, dim3(256), 0, eng->stream, w.evec, w.ez, eng->gcoef, eng->d_gmu, r.w1g, r.tsd, r.ttd, r.ln1w, \
+                                                 r.ln1b, r.w2, r.b2, r.ln2w, r.ln2b, w.h1pre[slot], w.h2pre[slot], (void*)(OUT), ne, eng->odd_sign)
+  if (planes && eng->fwd_fmt == 1) UMX_RH_LAUNCH(2, w.a2pl); else if (planes) UMX_RH_LAUNCH(4, w.a2pl); else UMX_RH_LAUNCH(0, w.ra);
 #undef UMX_RH_LAUNCH
-#undef UMX_RH_ARGS
-    prof_close(eng, pr);
-    HIPCHK(eng, hipGetLastError());
-    return UMX_OK;
-  }
-  GemmP p = gp_zero();
-  p.evec = w.evec; p.gcoef = eng->gcoef; p.gmu = eng->d_gmu; p.B = r.w1g; p.ldb = NG; p.Cp = w.h1pre[slot]; p.ldc = RH;
-  p.TS = r.ts; p.TT = r.tt; p.ez = w.ez;
-  p.M = (int)ne; p.N = RH; p.K = NG;
-  CHK(launch_gemm(eng, p, A_GAUSS, 0, E_TABLES));
-  hipLaunchKernelGGL(k_ln_silu_fwd, dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h1pre[slot], r.ln1w, r.ln1b, w.ra, ne);
-  CHK(gemm_plain(eng, w.ra, RH, 0, r.w2, RH, r.b2, w.h2pre[slot], RH, 0, ne, RH, RH));
-  if (eng->pl && eng->planes.count(r.w3)) {
-    if (eng->q3 && eng->fwd_fmt == 2) hipLaunchKernelGGL((k_ln_silu_fwd_pl<2, true>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne, eng->odd_sign,
-                                                         reinterpret_cast<unsigned char*>(w.a2pl) + (size_t)((ne + 3) / 4 * 4) * RH * 4);
-    else if (eng->q3 && eng->fwd_fmt == 1) hipLaunchKernelGGL((k_ln_silu_fwd_pl<2, true>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne, eng->odd_sign, (unsigned char*)nullptr);
-    else if (eng->q3 && eng->fwd_fmt == 3) hipLaunchKernelGGL((k_ln_silu_fwd_pl<2, true, 3>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne, eng->odd_sign, (unsigned char*)nullptr);
-    else if (eng->q3) hipLaunchKernelGGL((k_ln_silu_fwd_pl<3, true>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne, eng->odd_sign, (unsigned char*)nullptr);
-    else hipLaunchKernelGGL((k_ln_silu_fwd_pl<3, false>), dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.a2pl, ne, eng->odd_sign, (unsigned char*)nullptr);
-  } else {
-    hipLaunchKernelGGL(k_ln_silu_fwd, dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.h2pre[slot], r.ln2w, r.ln2b, w.ra, ne);
-  }
+  prof_close(eng, pr);
   HIPCHK(eng, hipGetLastError());
   return UMX_OK;
 }
@@ -616,34 +506,13 @@ int radial_bwd_fc3(umx_engine* eng, const WS& w, const RadialW& r, long ne, cons
   return gemm_plain(eng, grad, r.out, 0, r.w3T, r.out, nullptr, w.e128a, RH, 0, ne, RH, r.out);
 }
 int radial_bwd_tail(umx_engine* eng, const WS& w, const RadialW& r, int slot, long ne) {
-  hipStream_t s = eng->stream;
-  if (eng->fused_radial) {
-    // one persistent kernel: LN+SiLU bwd -> fc2^T -> LN+SiLU bwd -> fc1^T -> dE/dd through the gaussians (accumulated into dedd)
-    const int TR = eng->radial_tr;
-    const unsigned tiles = nblk(ne, 32 * TR);
-    const unsigned cap = TR == 1 ? 768u : 512u;
-    const dim3 grid(vgrid(eng, tiles < cap ? tiles : cap));
-#define UMX_RT_ARGS grid, dim3(256), 0, s, w.e128a, w.h2pre[slot], w.h1pre[slot], w.evec, eng->gcoef, eng->d_gmu, r.ln2w, r.ln2b, r.ln1w, r.ln1b, r.w2T, r.w1gT, w.dedd_rad, ne
-    ProfRec* pr = prof_open(eng, 2.0 * ne * ((double)NG * RH + (double)RH * RH), -1, ne, RH, NG + RH);
-    if (TR == 1) {
-      if (eng->radial_fast == 2) hipLaunchKernelGGL((k_radial_tail<2, 1>), UMX_RT_ARGS);
-      else if (eng->radial_fast == 1) hipLaunchKernelGGL((k_radial_tail<1, 1>), UMX_RT_ARGS);
-      else hipLaunchKernelGGL((k_radial_tail<0, 1>), UMX_RT_ARGS);
-    } else {
-      if (eng->radial_fast == 2) hipLaunchKernelGGL((k_radial_tail<2, 2>), UMX_RT_ARGS);
-      else if (eng->radial_fast == 1) hipLaunchKernelGGL((k_radial_tail<1, 2>), UMX_RT_ARGS);
-      else hipLaunchKernelGGL((k_radial_tail<0, 2>), UMX_RT_ARGS);
-    }
-#undef UMX_RT_ARGS
-    prof_close(eng, pr);
-    HIPCHK(eng, hipGetLastError());
-    return UMX_OK;
-  }
-  hipLaunchKernelGGL(k_ln_silu_bwd, dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.e128a, w.h2pre[slot], r.ln2w, r.ln2b, w.e128b, ne);
-  CHK(gemm_plain(eng, w.e128b, RH, 0, r.w2T, RH, nullptr, w.e128a, RH, 0, ne, RH, RH));
-  hipLaunchKernelGGL(k_ln_silu_bwd, dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.e128a, w.h1pre[slot], r.ln1w, r.ln1b, w.e128b, ne);
-  CHK(gemm_plain(eng, w.e128b, RH, 0, r.w1gT, RH, nullptr, w.ggauss, NG, 0, ne, NG, RH));
-  hipLaunchKernelGGL(k_radial_dd, dim3(vgrid(eng, nblk(ne, 4))), dim3(256), 0, s, w.ggauss, w.evec, eng->gcoef, eng->d_gmu, w.dedd_rad, ne);
+  // one persistent kernel: LN+SiLU bwd -> fc2^T -> LN+SiLU bwd -> fc1^T -> dE/dd through the gaussians (accumulated into dedd_rad)
+  const unsigned tiles = nblk(ne, 64);
+  const dim3 grid(vgrid(eng, tiles < 512u ? tiles : 512u));
+  ProfRec* pr = prof_open(eng, 2.0 * ne * ((double)NG * RH + (double)RH * RH), -1, ne, RH, NG + RH);
+  hipLaunchKernelGGL(k_radial_tail, grid, dim3(256), 0, eng->stream, w.e128a, w.h2pre[slot], w.h1pre[slot], w.evec, eng->gcoef, eng->d_gmu, r.ln2w, r.ln2b, r.ln1w, r.ln1b,
+                     r.w2T, r.w1gT, w.dedd_rad, ne);
+  prof_close(eng, pr);
   HIPCHK(eng, hipGetLastError());
   return UMX_OK;
 }
@@ -688,21 +557,8 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
   const dim3 B256(256);
   const bool pl = eng->pl;
   const bool gp = eng->gp;                                       // graph-parallel: partial sums over this rank's edges + exchange points
-  const bool fused_rev = eng->fuse_modrot && (eng->pl || !eng->dbg_on);     // k_modrot_bwd_pl produces g_xn itself (fp32 mode: unless debug captures are on)
+  const bool fused_rev = eng->pl || !eng->dbg_on;     // k_modrot_bwd_pl produces g_xn itself (fp32 mode with debug captures: the unfused kernels, which expose xrot / g_xrot)
   const long g_lo = gp ? eng->gp_lo : 0, g_hi = gp ? eng->gp_hi : nn;
-  // side-stream issue of the fused radial kernels (see umx_engine::side); the plan is the same, only WHERE two of its kernels run changes
-  const bool side = eng->side && eng->n_lanes == 1 && !eng->dbg_on && !gp && pl && ne > 0 && eng->fused_radial && eng->q3;
-  auto side_launch = [eng](hipEvent_t done, const std::function<int()>& fn) -> int {
-    hipStream_t main_s = eng->stream;
-    HIPCHK(eng, hipEventRecord(eng->ev_sf, main_s));                   // fork: after everything issued on the main stream so far
-    HIPCHK(eng, hipStreamWaitEvent(eng->stream2, eng->ev_sf, 0));
-    eng->stream = eng->stream2;
-    const int st = fn();
-    eng->stream = main_s;
-    if (st != UMX_OK) return st;
-    HIPCHK(eng, hipEventRecord(done, eng->stream2));                   // join point: the consumer waits on `done`
-    return UMX_OK;
-  };
   // every closure reads eng->stream when it RUNS (the executor points it at the lane's stream)
   // K1 graph, K4 + K5
   P.stream([=, &w]() -> int {
@@ -751,23 +607,13 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       P.stream([=, &w]() -> int {
         hipStream_t s = eng->stream;
         hipLaunchKernelGGL(k_norm_fwd, dim3(nblk(nn, 4)), B256, 0, s, xin, Lp->n1w, Lp->n1b, eng->d_sysemb, w.xn[i], nn);
-        if (side && i > 0) return UMX_OK;               // head(i) was issued on the side stream next to layer i-1's gather kernel
         return radial_fwd_head(eng, w, Lp->rad, i, ne);
       });
-      P.matrix([=, &w]() -> int {
-        if (side && i > 0) HIPCHK(eng, hipStreamWaitEvent(eng->stream, eng->ev_shead, 0));
-        return radial_fwd_fc3(eng, w, Lp->rad, ne, w.rad[i]);
-      });
+      P.matrix([=, &w]() -> int { return radial_fwd_fc3(eng, w, Lp->rad, ne, w.rad[i]); });
       P.stream([=, &w]() -> int {
         hipStream_t s = eng->stream;
-        // the NEXT layer's radial head (geometry only; a2pl is free: this layer's fc3 has consumed it) beside this HBM-bound kernel
-        if (side && i + 1 < NL) CHK(side_launch(eng->ev_shead, [=, &w]() -> int { return radial_fwd_head(eng, w, eng->lw[i + 1].rad, i + 1, ne); }));
-        if (eng->q3 && eng->fwd_fmt == 2) hipLaunchKernelGGL(k_gather_rotate_mod_q3<2>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne, eng->odd_sign,
-                                                             reinterpret_cast<unsigned char*>(w.y1pl) + (size_t)((ne + 3) / 4 * 4) * XROT * 4);
-        else if (eng->q3 && eng->fwd_fmt == 1) hipLaunchKernelGGL(k_gather_rotate_mod_q3<1>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne, eng->odd_sign, (unsigned char*)nullptr);
-        else if (eng->q3 && eng->fwd_fmt == 3) hipLaunchKernelGGL(k_gather_rotate_mod_q3<3>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne, eng->odd_sign, (unsigned char*)nullptr);
-        else if (eng->q3) hipLaunchKernelGGL(k_gather_rotate_mod_q3<0>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne, eng->odd_sign, (unsigned char*)nullptr);
-        else hipLaunchKernelGGL((k_gather_rotate_mod_pl<3, false>), dim3((nblk(ne, 4) + 7) / 8 * 8), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne, eng->odd_sign);
+        if (eng->fwd_fmt == 1) hipLaunchKernelGGL(k_gather_rotate_mod_q3<1>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne, eng->odd_sign);
+        else hipLaunchKernelGGL(k_gather_rotate_mod_q3<3>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.y1pl, ne, eng->odd_sign);
         HIPCHK(eng, hipGetLastError());
         return UMX_OK;
       });
@@ -779,12 +625,8 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       });
       P.stream([=, &w]() -> int {
         hipStream_t s = eng->stream;
-        if (eng->q3 && eng->fwd_fmt == 2) hipLaunchKernelGGL(k_gate_edge_fwd_q3<2>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hg[i], w.hidpl, ne, eng->odd_sign,
-                                                             reinterpret_cast<unsigned char*>(w.hidpl) + (size_t)((ne + 3) / 4 * 4) * ROW * 4);
-        else if (eng->q3 && eng->fwd_fmt == 1) hipLaunchKernelGGL(k_gate_edge_fwd_q3<1>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hg[i], w.hidpl, ne, eng->odd_sign, (unsigned char*)nullptr);
-        else if (eng->q3 && eng->fwd_fmt == 3) hipLaunchKernelGGL(k_gate_edge_fwd_q3<3>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hg[i], w.hidpl, ne, eng->odd_sign, (unsigned char*)nullptr);
-        else if (eng->q3) hipLaunchKernelGGL(k_gate_edge_fwd_q3<0>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hg[i], w.hidpl, ne, eng->odd_sign, (unsigned char*)nullptr);
-        else hipLaunchKernelGGL((k_gate_edge_fwd_pl<3, false>), dim3(nblk(ne * (H / 4), 256)), B256, 0, s, w.hg[i], w.hidpl, ne, eng->odd_sign);
+        if (eng->fwd_fmt == 1) hipLaunchKernelGGL(k_gate_edge_fwd_q3<1>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hg[i], w.hidpl, ne, eng->odd_sign);
+        else hipLaunchKernelGGL(k_gate_edge_fwd_q3<3>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hg[i], w.hidpl, ne, eng->odd_sign);
         HIPCHK(eng, hipGetLastError());
         return UMX_OK;
       });
@@ -928,8 +770,6 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       if (ne > 0 && eng->pl)
       {
         if (eng->rev_qf) hipLaunchKernelGGL(k_rotate_back_bwd_q3<3>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne, eng->odd_sign);
-        else if (eng->rev_planes == 3 && eng->q3 && eng->rev_q3) hipLaunchKernelGGL(k_rotate_back_bwd_q3<0>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne, eng->odd_sign);
-        else if (eng->rev_planes == 3) hipLaunchKernelGGL(k_rotate_back_bwd_pl<3>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne, eng->odd_sign);
         else hipLaunchKernelGGL(k_rotate_back_bwd_pl<2>, dim3(vgrid(eng, (nblk(ne, 4) + 7) / 8 * 8)), B256, 0, s, w.G2, w.msg[i], w.frame, w.edst, w.gmsgpl, w.dedd, w.tau, ne, eng->odd_sign);
       }
       HIPCHK(eng, hipGetLastError());
@@ -944,12 +784,7 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       P.stream([=, &w]() -> int {
         hipStream_t s = eng->stream;
         DBG("g_hid." + std::to_string(i), w.hid, ne * ROW);
-        // the radial tail of the layer ABOVE (it feeds only dE/dd) beside this HBM-bound kernel -- not right behind its fc3^T GEMM, where
-        // it would run next to the node-level and SO(2) GEMMs and slow those down by as much as it hides (measured)
-        if (side && i + 1 < NL) CHK(side_launch(eng->ev_stail, [=, &w]() -> int { return radial_bwd_tail(eng, w, eng->lw[i + 1].rad, i + 1, ne); }));
         if (eng->rev_qf) hipLaunchKernelGGL(k_gate_edge_bwd_q3<3>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne, eng->odd_sign);
-        else if (eng->rev_planes == 3 && eng->q3 && eng->rev_q3) hipLaunchKernelGGL(k_gate_edge_bwd_q3<0>, dim3(vgrid(eng, nblk(ne, 8))), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne, eng->odd_sign);
-        else if (eng->rev_planes == 3) hipLaunchKernelGGL(k_gate_edge_bwd_pl<3>, dim3(vgrid(eng, nblk(ne * (H / 4), 256))), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne, eng->odd_sign);
         else hipLaunchKernelGGL(k_gate_edge_bwd_pl<2>, dim3(vgrid(eng, nblk(ne * (H / 4), 256))), B256, 0, s, w.hid, w.hg[i], w.ghgpl, ne, eng->odd_sign);
         HIPCHK(eng, hipGetLastError());
         return UMX_OK;
@@ -963,28 +798,17 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       //  the other lane's GEMM it would only take CUs away from it; the other lane's throttled stream kernels do fit beside it)
       P.matrix([=, &w]() -> int {
         hipStream_t s = eng->stream;
-        if (eng->fuse_modrot) {       // one node-centric kernel: modulation backward + rotate-back + segmented sum (g_xrot stays in registers)
-          if (eng->rev_qf && eng->f32rows_layout) hipLaunchKernelGGL(k_modrot_bwd_pl<0>, dim3((unsigned)nn), B256, 0, s, w.gy1, w.xn[i], w.frame, w.rad[i], w.row_ptr, w.out_ptr, w.out_edge,
-                                              w.gradpl, w.tau, w.tau2, w.G1, nn, eng->odd_sign);        // g_rad as float32 rows (sign-alternating): split by the fc3^T GEMM
-          else if (eng->rev_planes == 3) hipLaunchKernelGGL(k_modrot_bwd_pl<3>, dim3((unsigned)nn), B256, 0, s, w.gy1, w.xn[i], w.frame, w.rad[i], w.row_ptr, w.out_ptr, w.out_edge,
-                                                       w.gradpl, w.tau, w.tau2, w.G1, nn, eng->odd_sign);
-          else hipLaunchKernelGGL(k_modrot_bwd_pl<2>, dim3((unsigned)nn), B256, 0, s, w.gy1, w.xn[i], w.frame, w.rad[i], w.row_ptr, w.out_ptr, w.out_edge,
-                                  w.gradpl, w.tau, w.tau2, w.G1, nn, eng->odd_sign);
-        } else {
-          if (eng->rev_planes == 3) hipLaunchKernelGGL(k_modulate_bwd_pl<3>, dim3(nblk(ne, 4)), B256, 0, s, w.gy1, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.gradpl, w.tau, ne, eng->odd_sign);
-          else hipLaunchKernelGGL(k_modulate_bwd_pl<2>, dim3(nblk(ne, 4)), B256, 0, s, w.gy1, w.xn[i], w.esrc, w.edst, w.frame, w.rad[i], w.gradpl, w.tau, ne, eng->odd_sign);
-          DBG("g_xrot." + std::to_string(i), w.gy1, ne * XROT);
-        }
+        // one node-centric kernel: modulation backward + rotate-back + segmented sum (g_xrot stays in registers); g_rad as float32 rows
+        // (sign-alternating; split by the fc3^T GEMM in registers) in the bf16x3 mode, as two PL bf16 planes in the 16-bit-reverse modes
+        if (eng->rev_qf) hipLaunchKernelGGL(k_modrot_bwd_pl<0>, dim3((unsigned)nn), B256, 0, s, w.gy1, w.xn[i], w.frame, w.rad[i], w.row_ptr, w.out_ptr, w.out_edge,
+                                            w.gradpl, w.tau, w.tau2, w.G1, nn, eng->odd_sign);
+        else hipLaunchKernelGGL(k_modrot_bwd_pl<2>, dim3((unsigned)nn), B256, 0, s, w.gy1, w.xn[i], w.frame, w.rad[i], w.row_ptr, w.out_ptr, w.out_edge,
+                                w.gradpl, w.tau, w.tau2, w.G1, nn, eng->odd_sign);
         HIPCHK(eng, hipGetLastError());
         return UMX_OK;
       });
-      P.matrix([=, &w]() -> int {
-        if (side && i + 1 < NL) HIPCHK(eng, hipStreamWaitEvent(eng->stream, eng->ev_stail, 0));      // e128a: the previous layer's tail has read it
-        return radial_bwd_fc3(eng, w, Lp->rad, ne, nullptr, w.gradpl, eng->rev_qf && eng->f32rows_layout && eng->fuse_modrot);
-      });
-      // the tail feeds only the scalar dE/dd (own accumulator dedd_rad).  Side mode: layers 3..1 defer it to the next layer's gate kernel
-      // (above); layer 0 has no layer below and runs it here
-      if (!(side && i > 0)) P.stream([=, &w]() -> int { return radial_bwd_tail(eng, w, Lp->rad, i, ne); });
+      P.matrix([=, &w]() -> int { return radial_bwd_fc3(eng, w, Lp->rad, ne, nullptr, w.gradpl, eng->rev_qf); });
+      P.stream([=, &w]() -> int { return radial_bwd_tail(eng, w, Lp->rad, i, ne); });     // feeds only the scalar dE/dd (own accumulator dedd_rad)
     } else if (ne > 0) {
       P.stream([=, &w]() -> int {
         hipStream_t s = eng->stream;
@@ -1000,7 +824,7 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
         CHK(gemm_cplx(eng, w.ghg, HG, 640, 896, nullptr, 0, 0, L.c1m1T, 256, 512, w.gy1, XROT, 768, 1280, ne, 512, 256, -1.0f));
         CHK(gemm_cplx(eng, w.ghg, HG, 1152, 1280, nullptr, 0, 0, L.c1m2T, 128, 256, w.gy1, XROT, 1792, 2048, ne, 256, 128, -1.0f));
         DBG("g_hg" + t, w.ghg, ne * HG);
-        if (eng->fuse_modrot && !eng->dbg_on) {
+        if (!eng->dbg_on) {
           // round 4: the fp32 mode takes the node-centric fused kernel of the split path too (P = 0: g_rad as float32 rows) instead of
           // k_gather_rotate + k_modulate_bwd + k_gather_rotate_bwd -- the rotated message and g_xrot never touch HBM (-27 KB per edge and
           // layer).  With debug captures on the unfused kernels run: they expose xrot / g_xrot to the stage-by-stage test.
@@ -1049,7 +873,6 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
                                        reinterpret_cast<float*>(w.gmsgpl), w.dedd, w.tau, ne, DEG_RESCALE, eng->odd_sign);
       else hipLaunchKernelGGL(k_rotate_back_bwd<3>, dim3(nblk(ne, 4)), B256, 0, s, w.G0, w.rad_deg, w.frame, w.edst, w.gmsg, w.dedd, w.tau, ne,
                               DEG_RESCALE);
-      if (side) HIPCHK(eng, hipStreamWaitEvent(s, eng->ev_stail, 0));        // join: layer 1's tail, the last one issued on the side stream (e128a, dedd_rad)
       CHK(radial_bwd(eng, w, eng->rdeg, NL, ne, w.gmsg, dpl ? w.gmsgpl : nullptr));
       if (fused_rev) hipLaunchKernelGGL(k_add4, dim3(nblk(ne, 256)), B256, 0, s, w.tau, w.tau2, ne);
       hipLaunchKernelGGL(k_force_edge, dim3(nblk(ne, 256)), B256, 0, s, w.dedd, w.dedd_rad, w.tau, w.frame, w.evec, w.gvec, ne);
@@ -1156,43 +979,23 @@ int umx_create(umx_engine** out, int device_ordinal) {
   }
   umx_engine* e = new umx_engine();
   e->dev = device_ordinal;
-  if (const char* ev = std::getenv("UMX_MFMA16")) e->mfma16 = std::atoi(ev);
-  if (const char* ev = std::getenv("UMX_WIDE")) e->wide_tiles = std::atoi(ev) != 0;
-  if (const char* ev = std::getenv("UMX_Q3")) e->q3 = std::atoi(ev) != 0;
-  if (const char* ev = std::getenv("UMX_Q3WIDE")) e->q3_wide = std::atoi(ev) != 0;
-  if (const char* ev = std::getenv("UMX_RADIAL_TR")) e->radial_tr = std::atoi(ev) == 1 ? 1 : 2;
-  if (const char* ev = std::getenv("UMX_RADIAL_FAST")) e->radial_fast = std::max(0, std::min(2, std::atoi(ev)));
-  if (const char* ev = std::getenv("UMX_FUSED_RADIAL")) e->fused_radial = std::atoi(ev) != 0;
-  if (const char* ev = std::getenv("UMX_Q3S")) e->q3_stages = std::atoi(ev) == 3 ? 3 : 2;
-  if (const char* ev = std::getenv("UMX_FUSE_MODROT")) e->fuse_modrot = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_STREAMS")) e->n_lanes = std::atoi(ev) >= 2 ? 2 : (std::atoi(ev) == 1 ? 1 : 0);
   if (const char* ev = std::getenv("UMX_LANES_AUTO_EDGES")) e->lanes_auto_edges = std::max(0L, std::atol(ev));
-  if (const char* ev = std::getenv("UMX_SIDE")) e->side = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_FORCE_PARTS")) e->force_parts = std::max(0, std::min(16, std::atoi(ev)));
   if (const char* ev = std::getenv("UMX_WS_GB")) e->ws_cap_default = (size_t)std::max(0L, std::atol(ev)) << 30;
-  if (const char* ev = std::getenv("UMX_RADIAL_F16")) e->radial_f16 = std::atoi(ev) & 3;
   if (const char* ev = std::getenv("UMX_WS_EAGER")) e->ws_eager = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_WS_SOFT_EDGES")) e->ws_soft_edges = std::max(1L, std::atol(ev));
   if (const char* ev = std::getenv("UMX_NODE_F64")) e->node_f64_on = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_GRID_F64")) e->grid_f64 = std::atoi(ev) != 0;
-  if (const char* ev = std::getenv("UMX_REV_Q3")) e->rev_q3 = std::atoi(ev) != 0;
-  if (const char* ev = std::getenv("UMX_A_F32")) e->a_f32 = std::atoi(ev) != 0;
-  if (const char* ev = std::getenv("UMX_GRAD_F32")) e->f32rows_layout = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_ALT_ROWS")) e->odd_sign = std::atoi(ev) != 0 ? -1.0f : 1.0f;
-  if (const char* ev = std::getenv("UMX_DEG_SPLIT")) e->deg_split = std::atoi(ev) != 0;
-  e->stream_cap = 512;
-  if (const char* ev = std::getenv("UMX_STREAM_BLOCKS")) e->stream_cap = std::max(0, std::atoi(ev)) / 8 * 8;
-  // stream2 gets the HIGHEST priority: the side kernels (two LDS-heavy workgroups per CU) are placed first and the main stream's
-  // edge kernel fills the rest of every CU; at equal priority the edge kernel's endless small workgroups keep the side kernel out
-  // (measured: it then ran 3x longer and spilled into the next GEMM)
+  // stream2 (the second lane) is created with the highest priority (as measured in rounds 3-5; priorities change little on this pool)
   int prio_lo = 0, prio_hi = 0;
   if (hipSetDevice(device_ordinal) != hipSuccess || hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
       hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, std::getenv("UMX_SIDE_PRIO") ? std::atoi(std::getenv("UMX_SIDE_PRIO")) : prio_hi) != hipSuccess ||
+      hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, prio_hi) != hipSuccess ||
       hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&e->ev_tok[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_tok[1], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_sf, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&e->ev_shead, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_stail, hipEventDisableTiming) != hipSuccess || hipMalloc(&e->d_flags, 4 * sizeof(int)) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming) != hipSuccess || hipMalloc(&e->d_flags, 4 * sizeof(int)) != hipSuccess ||
       hipMemset(e->d_flags, 0, 4 * sizeof(int)) != hipSuccess) {
     g_create_err = "umx_create: hipSetDevice/hipStreamCreate failed";
     delete e;
@@ -1216,7 +1019,6 @@ int umx_destroy(umx_engine* eng) {
   (void)hipEventDestroy(eng->ev_fork); (void)hipEventDestroy(eng->ev_join);
   (void)hipEventDestroy(eng->ev_tok[0]); (void)hipEventDestroy(eng->ev_tok[1]);
   if (eng->ev_done) (void)hipEventDestroy(eng->ev_done);
-  for (hipEvent_t ev : {eng->ev_sf, eng->ev_shead, eng->ev_stail}) if (ev) (void)hipEventDestroy(ev);
   (void)hipStreamDestroy(eng->stream2);
   (void)hipStreamDestroy(eng->stream);
   delete eng;
@@ -1275,7 +1077,7 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
     return o;
   };
   const float* hw = eng->h_w.data();
-  struct RadOff { size_t w1g, w1gT, ts, tt, w2T, w3T, tsd, ttd; };
+  struct RadOff { size_t w1g, w1gT, w2T, w3T, tsd, ttd; };
   std::vector<double> dtab;
   std::map<std::string, RadOff> roff;
   const Tensor* tsrc = need("source_embedding.weight", {NZ, 128});
@@ -1290,7 +1092,7 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
       if (!need(pre + s, {RH})) return UMX_ERR_WEIGHTS;
     if (!w1 || !b1 || !w2 || !w3 || !need(pre + ".fc3.bias", {out})) return UMX_ERR_WEIGHTS;
     const float* W1 = hw + w1->off;
-    std::vector<float> w1g((size_t)RH * NG), ts((size_t)NZ * RH), tt((size_t)NZ * RH);
+    std::vector<float> w1g((size_t)RH * NG);
     RadOff o;
     o.tsd = dtab.size(); dtab.resize(dtab.size() + (size_t)NZ * RH);
     o.ttd = dtab.size(); dtab.resize(dtab.size() + (size_t)NZ * RH);
@@ -1303,12 +1105,10 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
           a += (double)W1[(size_t)h * (NG + 256) + NG + k] * hw[tsrc->off + (size_t)z * 128 + k];
           c += (double)W1[(size_t)h * (NG + 256) + NG + 128 + k] * hw[ttgt->off + (size_t)z * 128 + k];
         }
-        ts[(size_t)z * RH + h] = (float)a;
-        tt[(size_t)z * RH + h] = (float)c;
         dtab[o.tsd + (size_t)z * RH + h] = a;
         dtab[o.ttd + (size_t)z * RH + h] = c;
       }
-    o.w1g = push(w1g); o.w1gT = push(transpose(w1g.data(), RH, NG)); o.ts = push(ts); o.tt = push(tt);
+    o.w1g = push(w1g); o.w1gT = push(transpose(w1g.data(), RH, NG));
     o.w2T = push(transpose(hw + w2->off, RH, RH)); o.w3T = push(transpose(hw + w3->off, out, RH));
     roff[pre] = o;
     return UMX_OK;
@@ -1426,38 +1226,17 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
     // mode whose every product, forward and reverse, carries >= 24 significant bits -- the like-for-like arithmetic.  The faster split-f16
     // (22-bit forward activations, 16-bit reverse products) meets the tolerances with margin but is narrower: an explicit choice.
     bool rev3 = false;
-    const int bf = (eng->q3 && eng->a_f32) ? 3 : 0;              // bf16-plane forward operands: float32 blocks split by the GEMM (round 4), or pre-split planes
     if (mode == "fp32") eng->pl = false;
-    else if (mode == "auto") { eng->pl = true; eng->fwd_fmt = bf; rev3 = true; }
-    else if (mode == "split" || mode == "split-f16") { eng->pl = true; eng->fwd_fmt = eng->q3 ? 1 : 0; }   // (the dev layout UMX_Q3=0 has bf16 planes only)
-    else if (mode == "split-bf16") { eng->pl = true; eng->fwd_fmt = bf; }
-    else if (mode == "bf16x3" || mode == "split-exact") { eng->pl = true; eng->fwd_fmt = bf; rev3 = true; }   // 24-bit products in BOTH passes
-    else if (mode == "f16x2b8") { eng->pl = true; eng->fwd_fmt = 2; rev3 = true; }   // forward: two fp16 planes + bf8 third planes (25-bit operands), reverse as bf16x3
-    else return fail(eng, UMX_ERR_ARG, "UMX_PRECISION must be auto, split (= split-f16), split-bf16, bf16x3 (= split-exact), f16x2b8 or fp32");
+    else if (mode == "auto" || mode == "bf16x3" || mode == "split-exact") { eng->pl = true; eng->fwd_fmt = 3; rev3 = true; }   // 24-bit products in BOTH passes
+    else if (mode == "split" || mode == "split-f16") { eng->pl = true; eng->fwd_fmt = 1; }
+    else if (mode == "split-bf16") { eng->pl = true; eng->fwd_fmt = 3; }
+    else return fail(eng, UMX_ERR_ARG, "UMX_PRECISION must be auto, bf16x3 (= split-exact), split (= split-f16), split-bf16 or fp32");
     eng->rev_planes = (eng->pl && rev3) ? 3 : 2;
-    eng->rev_qf = eng->pl && eng->rev_planes == 3 && eng->q3 && eng->rev_q3 && eng->a_f32;
-    if ((mode == "split-f16" || mode == "f16x2b8") && !eng->q3) return fail(eng, UMX_ERR_ARG, "UMX_PRECISION=split-f16 / f16x2b8 need the quad-row operand layout (UMX_Q3=1)");
+    eng->rev_qf = eng->pl && eng->rev_planes == 3;
     // a precision change alters the workspace carve-up: force a re-carve on the next call
     eng->cap_nodes = 0; eng->cap_edges = 0;
   }
-  if (const char* ev = std::getenv("UMX_F16_PRODUCTS")) eng->f16_prod = std::atoi(ev) == 3 ? 3 : 4;
   eng->plane_scale.clear();
-  std::vector<std::pair<const float*, size_t>> preq8;   // fwd_fmt 2: (weight, offset of its 8-bit planes in `bw`, in shorts)
-  // bf8 (e5m2) <- binary32, round to nearest even, saturating at the largest finite value 57344, subnormals kept (v_cvt_pk_bf8_f32's result for in-range input)
-  auto to_bf8 = [](float f) -> unsigned char {
-    uint32_t x; std::memcpy(&x, &f, 4);
-    const unsigned char sign = (unsigned char)((x >> 24) & 0x80u);
-    x &= 0x7FFFFFFFu;
-    float a; std::memcpy(&a, &x, 4);
-    if (!(a == a)) return (unsigned char)(sign | 0x7Fu);
-    if (a >= 57344.0f) return (unsigned char)(sign | 0x7Bu);
-    if (a < 6.103515625e-05f) return (unsigned char)(sign | (unsigned char)std::lrintf(a * 65536.0f));     // below 2^-14: multiples of 2^-16 (lrintf: to nearest even)
-    uint32_t h = (((x >> 23) - 112u) << 2) | ((x & 0x7FFFFFu) >> 21);
-    const uint32_t rem = x & 0x1FFFFFu;
-    if (rem > 0x100000u || (rem == 0x100000u && (h & 1u))) ++h;
-    if (h > 0x7Bu) h = 0x7Bu;
-    return (unsigned char)(sign | h);
-  };
   // IEEE binary16 <- binary32, round to nearest even, subnormals kept (what v_cvt_f16_f32 does for the activations)
   auto to_half = [](float f) -> unsigned short {
     uint32_t x; std::memcpy(&x, &f, 4);
@@ -1482,15 +1261,12 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
     uint32_t u; std::memcpy(&u, &v, 4); u |= sign; std::memcpy(&v, &u, 4);
     return v;
   };
-  // fp16 quad-row copy of a forward weight: PB half planes of s * w, s = the power of two that puts max|w| into [2^14, 2^15).
-  // PB = 3: 33 significand bits -- exact for every weight above max|w| * 2^-16, an absolute 2^-39 max|w| below; PB = 2: 22 bits.
+  // fp16 quad-row copy of a forward weight: three half planes of s * w, s = the power of two that puts max|w| into [2^14, 2^15):
+  // 33 significand bits -- exact for every weight above max|w| * 2^-16, an absolute 2^-39 max|w| below.
   auto want_planes_f16 = [&](const float* host, const float* dev, int rows, int K) {
-    const bool x8 = eng->fwd_fmt == 2;        // three half planes + the two 8-bit planes (O8 layout, umx_gemm_q.h) behind them
-    const int PB = (!x8 && eng->f16_prod == 3) ? 2 : 3;
+    const int PB = 3;
     PlaneReq r{dev, (bw.size() + 63) & ~size_t(63)};
-    const size_t off8 = r.off + (size_t)rows * K * PB;
-    bw.resize(off8 + (x8 ? (size_t)rows * K : 0));
-    if (x8) preq8.push_back({dev, off8});
+    bw.resize(r.off + (size_t)rows * K * PB);
     float mx = 0.f;
     for (size_t i = 0; i < (size_t)rows * K; ++i) mx = std::max(mx, std::fabs(host[i]));
     int ex = 0;
@@ -1501,13 +1277,7 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
       for (int k = 0; k < K; ++k) {
         float x = host[(size_t)rr * K + k] * sc;
         const size_t o = r.off + (((size_t)(rr / 4) * (K / 16) + k / 16) * (128 * PB) + (size_t)(rr % 4) * (32 * PB) + (size_t)(k % 16) * 2) / 2;
-        const float xs = x;
-        float w1 = 0.f;
-        for (int q = 0; q < PB; ++q) { const unsigned short hq = to_half(x); bw[o + 16 * q] = hq; if (q == 1) w1 = from_half(hq); x -= from_half(hq); }
-        if (x8) {           // 3-bit copies of the first two planes: w0' = bf8(s w), w1' = bf8(2^10 w1)
-          unsigned char* b8 = reinterpret_cast<unsigned char*>(bw.data() + off8) + ((size_t)rr * (K / 64) + k / 64) * 128 + (size_t)(k % 64);
-          b8[0] = to_bf8(xs); b8[64] = to_bf8(w1 * (float)(1 << Q8_SHIFT1));
-        }
+        for (int q = 0; q < PB; ++q) { const unsigned short hq = to_half(x); bw[o + 16 * q] = hq; x -= from_half(hq); }
       }
     preq.push_back(r);
   };
@@ -1517,9 +1287,9 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
   auto want_planes = [&](const float* host, const float* dev, int rows, int K, int P, bool rev_quad = false) {
     const bool fwdw = (P == 3);
     if (!fwdw) P = eng->rev_planes;
-    const bool quad = (fwdw && eng->q3) || (!fwdw && rev_quad && P == 3 && eng->q3 && eng->rev_q3);
+    const bool quad = fwdw || (rev_quad && P == 3);
     eng->planes_q[dev] = quad;
-    if (fwdw && eng->q3 && (eng->fwd_fmt == 1 || eng->fwd_fmt == 2)) { want_planes_f16(host, dev, rows, K); return; }
+    if (fwdw && eng->fwd_fmt == 1) { want_planes_f16(host, dev, rows, K); return; }
     PlaneReq r{dev, (bw.size() + 63) & ~size_t(63)};
     bw.resize(r.off + (size_t)rows * K * P);
     for (int rr = 0; rr < rows; ++rr)
@@ -1554,7 +1324,7 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
     want_planes(hd + loff[i].c2m1T, D(loff[i].c2m1T), 2 * 256, 256, 2, true); want_planes(hd + loff[i].c2m2T, D(loff[i].c2m2T), 2 * 128, 128, 2, true);
     want_planes(hd + roff[c1 + ".rad_func"].w3T, D(roff[c1 + ".rad_func"].w3T), RH, RAD, 2);
   }
-  if (eng->deg_split) {   // the edge-degree radial MLP's fc3 (128 -> 384) and its transpose run on the split path too
+  {   // the edge-degree radial MLP's fc3 (128 -> 384) and its transpose run on the split path too
     const std::string nm = "edge_degree_embedding.rad_func.fc3.weight";
     want_planes(hw + eng->wt[nm].off, W(nm), 3 * C, RH, 3);
     const size_t t = roff["edge_degree_embedding.rad_func"].w3T;
@@ -1565,11 +1335,9 @@ static int load_weights_impl(umx_engine* eng, const void* blob, size_t nbytes) {
   HIPCHK(eng, hipMemcpy(eng->d_bw, bw.data(), bw.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
   eng->planes.clear();
   for (const auto& r : preq) eng->planes[r.dev] = eng->d_bw + r.off;
-  eng->planes8.clear();
-  for (const auto& r : preq8) eng->planes8[r.first] = reinterpret_cast<const unsigned char*>(eng->d_bw + r.second);
   auto fill_rad = [&](RadialW& r, const std::string& pre, int out) {
     const RadOff& o = roff[pre];
-    r.w1g = D(o.w1g); r.w1gT = D(o.w1gT); r.ts = D(o.ts); r.tt = D(o.tt); r.w2T = D(o.w2T); r.w3T = D(o.w3T);
+    r.w1g = D(o.w1g); r.w1gT = D(o.w1gT); r.w2T = D(o.w2T); r.w3T = D(o.w3T);
     r.tsd = eng->d_dtab + o.tsd; r.ttd = eng->d_dtab + o.ttd;
     r.ln1w = W(pre + ".ln1.weight"); r.ln1b = W(pre + ".ln1.bias"); r.w2 = W(pre + ".fc2.weight"); r.b2 = W(pre + ".fc2.bias");
     r.ln2w = W(pre + ".ln2.weight"); r.ln2b = W(pre + ".ln2.bias"); r.w3 = W(pre + ".fc3.weight"); r.b3 = W(pre + ".fc3.bias");
@@ -1627,7 +1395,7 @@ int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes) {
 
 const char* umx_precision_mode(const umx_engine* eng) {
   if (!eng || !eng->have_weights) return "";
-  return !eng->pl ? "fp32" : (eng->q3 && eng->fwd_fmt == 2) ? "f16x2b8" : (eng->q3 && eng->fwd_fmt == 1) ? "split-f16" : eng->rev_planes == 3 ? "bf16x3" : "split-bf16";
+  return !eng->pl ? "fp32" : eng->fwd_fmt == 1 ? "split-f16" : eng->rev_planes == 3 ? "bf16x3" : "split-bf16";
 }
 
 const char* umx_model_variant(const umx_engine* eng) {
@@ -1725,7 +1493,7 @@ int umx_synchronize(umx_engine* eng) {
   if (flag) {
     HIPCHK(eng, hipMemset(eng->d_flags, 0, sizeof(int)));
     return fail(eng, UMX_ERR_RANGE, std::string("a device-pointer evaluation produced a non-finite energy") +
-                (eng->pl && (eng->fwd_fmt == 1 || eng->fwd_fmt == 2) ? " (an activation beyond the fp16 operand range of the split-f16 / f16x2b8 forward planes: re-load with UMX_PRECISION=bf16x3 or fp32)"
+                (eng->pl && eng->fwd_fmt == 1 ? " (an activation beyond the fp16 operand range of the split-f16 forward planes: re-load with UMX_PRECISION=split-bf16, bf16x3 or fp32)"
                                               : " (non-finite input or an overflow in float32)"));
   }
   return UMX_OK;
@@ -1885,7 +1653,7 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
     // bit 0: set by an EARLIER evaluation through a device-pointer entry (this one has not computed an energy yet; on this stream that
     // evaluation is complete): its caller got NaN energies / forces and, most likely, derived these positions from them
     return fail(eng, UMX_ERR_RANGE, std::string("the previous device-pointer evaluation produced a non-finite energy") +
-                (eng->pl && (eng->fwd_fmt == 1 || eng->fwd_fmt == 2) ? " (an activation beyond the fp16 operand range of the split-f16 / f16x2b8 forward planes: re-load with UMX_PRECISION=bf16x3 or fp32)"
+                (eng->pl && eng->fwd_fmt == 1 ? " (an activation beyond the fp16 operand range of the split-f16 forward planes: re-load with UMX_PRECISION=split-bf16, bf16x3 or fp32)"
                                               : " (non-finite input or an overflow in float32)"));
   }
   eng->last_maxdeg = img_edges[K];
@@ -2179,7 +1947,7 @@ int umx_energy_forces(umx_engine* eng, int n_images, const float* pos, double* e
     if (!std::isfinite(energy[k])) {
       (void)hipMemset(eng->d_flags, 0, sizeof(int));         // reported right here: do not fail the NEXT call for it as well
       return fail(eng, UMX_ERR_RANGE, "image " + std::to_string(k) + ": non-finite energy" +
-                  (eng->pl && (eng->fwd_fmt == 1 || eng->fwd_fmt == 2) ? " (an activation beyond the fp16 operand range of UMX_PRECISION=split / f16x2b8: try bf16x3 or fp32)"
+                  (eng->pl && eng->fwd_fmt == 1 ? " (an activation beyond the fp16 operand range of UMX_PRECISION=split: try split-bf16, bf16x3 or fp32)"
                                                 : " (an overflow in float32)"));
     }
   return UMX_OK;

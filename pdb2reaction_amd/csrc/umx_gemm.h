@@ -25,14 +25,13 @@
 
 namespace umx {
 
-enum AMode { A_PLAIN = 0, A_MODUL = 1, A_GAUSS = 2, A_SILU = 3 };
-enum EMode { E_BIAS = 0, E_TABLES = 1 };
+enum AMode { A_PLAIN = 0, A_MODUL = 1, A_SILU = 3 };
+enum EMode { E_BIAS = 0 };     // (round 5: the gaussian-basis prologue and the element-table epilogue of the unfused radial layers went with them, umx_radial.h)
 
 struct GemmP {
   // A operand: row r at A + r*lda + offA{0,1} (+ blockIdx.z * zA); offA1 = imaginary rows (CPLX)
   const float* A; long lda; int offA0, offA1;
   const float* R; long ldr; int offR;            // A_MODUL: A .* R
-  const float* evec; double gcoef; const double* gmu;  // A_GAUSS: exp(gcoef (d - mu_k)^2), d = evec[4r+3], mu = 64-entry table (double: umx_radial.h)
   // B operand: weights [rows][ldb]; CPLX row of kind ab: ab*bHalf + n
   const float* B; long ldb; int bHalf;
   const unsigned short* Bpl; long bplane;        // split-bf16 kernels: plane q of the weights at Bpl + q*bplane (same [row][ldb] layout)
@@ -40,8 +39,6 @@ struct GemmP {
   float* Cp; long ldc; int offC, offCi;
   const float* bias;                             // [N] or null
   const float* resid; long ldres; int offRes;    // optional residual added to the output (plain)
-  const float* TS; const float* TT;              // E_TABLES: + TS[z_src][col] + TT[z_dst][col]
-  const int* ez;                                 // E_TABLES: per-edge packed element indices z_src | z_dst << 16 (k_edge_z)
   float conj;                                    // CPLX combine sign
   long zA, zC, zRes;
   long zBl;                                      // != 0: SO(3)-linear mode -- blockIdx.z = l-primary coefficient (0..8), weights of degree l(z) at B + l*zBl,
@@ -102,26 +99,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[2][2
         if (full && col < p.N && EPI == E_BIAS && !p.resid) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) c[(long)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[i][j][r] + bv[j];
-        } else if (full && col < p.N && EPI == E_TABLES && !p.resid) {
-          // straight-line: 16 packed index loads, then 32 table loads (L2-resident), then 16 stores -- no dependent chain per store
-          int zz[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) zz[r] = p.ez[row0 + (r & 3) + 8 * (r >> 2)];
-          float tv[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) tv[r] = p.TS[(zz[r] & 0xffff) * RH + col] + p.TT[(zz[r] >> 16) * RH + col];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) c[(long)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[i][j][r] + bv[j] + tv[r];
         } else if (col < p.N) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const long row = row0 + (r & 3) + 8 * (r >> 2);
             if (row < p.M) {
               float v = acc[i][j][r] + bv[j];
-              if (EPI == E_TABLES) {
-                const int zz = p.ez[row];
-                v += p.TS[(zz & 0xffff) * RH + col] + p.TT[(zz >> 16) * RH + col];
-              }
               if (p.resid) v += p.resid[row * p.ldres + p.offRes + zoffR + col];
               p.Cp[row * p.ldc + p.offC + zoffC + col] = v;
             }
@@ -163,21 +146,12 @@ __global__ __launch_bounds__(256, 2) void umx_gemm_kernel(const GemmP p) {
       else      { grow = (long)mt * 128 + trow;       offA = p.offA0; }
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (grow < p.M) {
-        if (AMODE == A_GAUSS) {
-          const double d = (double)p.evec[grow * 4 + 3];
-          double t;
-          t = d - p.gmu[k0 + 0]; v.x = exp_f((float)(p.gcoef * t * t));
-          t = d - p.gmu[k0 + 1]; v.y = exp_f((float)(p.gcoef * t * t));
-          t = d - p.gmu[k0 + 2]; v.z = exp_f((float)(p.gcoef * t * t));
-          t = d - p.gmu[k0 + 3]; v.w = exp_f((float)(p.gcoef * t * t));
-        } else {
-          v = *reinterpret_cast<const float4*>(p.A + grow * p.lda + offA + zoffA + k0);
-          if (AMODE == A_MODUL) {
-            const float4 m = *reinterpret_cast<const float4*>(p.R + grow * p.ldr + p.offR + k0);
-            v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
-          }
-          if (AMODE == A_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+        v = *reinterpret_cast<const float4*>(p.A + grow * p.lda + offA + zoffA + k0);
+        if (AMODE == A_MODUL) {
+          const float4 m = *reinterpret_cast<const float4*>(p.R + grow * p.ldr + p.offR + k0);
+          v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
         }
+        if (AMODE == A_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
       }
       ra[r] = v;
       int brow; bool ok;

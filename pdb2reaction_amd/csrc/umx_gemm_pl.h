@@ -46,9 +46,6 @@ struct GemmPL {
   float odd_sign;    // +1, or -1 when the producer stored the A rows of ODD index negated (sign-alternating rows, umx_kernels_pl.h): the
                      // epilogue multiplies the accumulators of odd rows by it, so C is what it would be -- with the matrix core's one-sided
                      // rounding error reversed on every second row.  0 is read as +1 (dev programs that memset the struct).
-  const unsigned char* A8; long lda8;   // umx_gemm_q.h, X8 = 1 only: the 8-bit planes of A ("O8" layout, lda8 = bytes per row = 2 * columns)
-  const unsigned char* B8;              //                            and of the weights (row pitch 2 * K bytes)
-  int x8_skip;                          // dev: bit 0 = leave out x0'.y2', bit 1 = leave out x2'.y0'
 };
 
 // float32 A operands (AF = 1 kernels here and in umx_gemm_q.h): a pair of floats -> the three packed bf16 plane dwords, round to nearest,

@@ -51,52 +51,9 @@ __device__ __forceinline__ void q3_issue(const unsigned char* A, const unsigned 
       __builtin_amdgcn_global_load_lds(B + b_off[JBF] + kofs_b, (__attribute__((address_space(3))) void*)(sbase + A_BYTES + piece + JBF * 8192), 16, 0, 0);
 }
 
-// ---- X8 = 1: "fp16 x 2 + bf8" activations against exact weights: 24-bit products in 4 + 2 x 1/2 instead of 6 matrix-instruction slots ---
-// Activations x = x0 + x1 + x2: two IEEE-half planes (11 + 11 bits, round to nearest) and the residual x2 (|x2| <= 2^-22 |x|, 2 bits);
-// weights w = w0 + w1 + w2: three half planes of s_w w (exact).  Of the products down to 2^-22 of the result
-//     x0.w0, x0.w1, x1.w0, x0.w2      run on v_mfma_f32_32x32x16_f16 as in the split-f16 form (the last one carries the exact weights: a
-//                                      rounding of the WEIGHTS is the same for every edge and would bias the energy like N, section 5 of NOTES.md),
-//     x1.w1 and x2.w0                  run on v_mfma_scale_f32_32x32x64_f8f6f4 with bf8 (e5m2) operands: x1' = bf8(2^10 x1), w1' = bf8(2^10 w1),
-//                                      x2' = bf8(2^20 x2), w0' = bf8(w0); the E8M0 scales 2^-10, 2^-10 / 2^-20, 1 are applied by the instruction
-//                                      and the sum goes into the same fp32 accumulators.  Each is 2^-22 of the result, so the three
-//                                      significant bits of a bf8 factor are plenty (error <= 2^-3 * 2^-22), and both are ZERO-MEAN in the
-//                                      activations' rounding residues.  That matters: the instruction adds its products in small groups of
-//                                      neighbouring k with a ~12-bit alignment window and TRUNCATES toward zero what falls below the
-//                                      group's largest product (csrc/f8_inner_sum.hip: 2^14 + 31 x 1 returns 2^14 + 24, either sign) --
-//                                      harmless on a noise-like term, a bias on one that carries fixed weight bits: with x0.w2 on this
-//                                      instruction the c5 energy moved by -4.4e-4 eV where the exact plane moves it by -2.3e-4 (NOTES.md
-//                                      section 10), which is why x0.w2 stays on the 16-bit instruction.
-// One K = 64 instruction does the work of four K = 16 ones in twice the time: 5 instruction slots per k-step instead of the 6 of the bf16x3
-// form.  Measured: 0.78-0.82 of its time stand-alone (csrc/gemm_bench.hip f16, 256 x 256 tiles), but in the c3 pipeline only 0.89-0.92 on
-// the complex SO(2) GEMMs and 1.0-1.13 on the 256 x 128-tile ones (N = 640, 384: bound by the L2->LDS fill, and this form moves 40 KB per
-// k-tile against 36) -- 530.7 against 534.4 ms per iteration.  An opt-in mode (UMX_PRECISION=f16x2b8), not the default.
-// Dropped terms: x1.w2, x2.w1 (2^-33).
-// "O8" LAYOUT of the two 8-bit planes of X[rows][cols]: one 128-B line per (row, 64-column chunk) = [plane 0: 64 B][plane 1: 64 B], row-major:
-//   element (r, k, plane q) -> byte (r * (cols/64) + k/64) * 128 + q * 64 + k % 64       activations: (x1', x2'); weights: (w0', w1')
-// LDS image of a 256-row slab: row-major 128-B rows in the DMA's flat chunk order, the 16-B chunk index XOR-ed with (row >> 1) & 7 (source
-// side and fragment side, as q_swz): the sixteen lanes one ds_read_b128 pass serves then cover all 64 banks.  ONE slab buffer (64 KB for
-// the wide tile): slab c is requested after the barrier of k-tile 4c (everyone has consumed slab c-1 at k-tile 4c-1), must have landed at
-// k-tile 4c+2 (in-order vmcnt) and is consumed after the 16-bit products of k-tile 4c+3.
-typedef int i32x4_t __attribute__((ext_vector_type(4)));
-typedef int i32x8_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ int q8_swz(int row) { return (row >> 1) & 7; }
-
-template <int JA8, int JB8, int A8_BYTES, int TAG>
-__device__ __forceinline__ void q8_issue(const unsigned char* A8, const unsigned char* B8, unsigned char* sbase, const long (&a_off)[JA8], const long (&b_off)[JB8],
-                                         long kofs, int piece) {
-#pragma unroll
-  for (int j = 0; j < JA8; ++j)
-    __builtin_amdgcn_global_load_lds(A8 + a_off[j] + kofs, (__attribute__((address_space(3))) void*)(sbase + piece + j * 8192), 16, 0, 0);
-#pragma unroll
-  for (int j = 0; j < JB8; ++j)
-    __builtin_amdgcn_global_load_lds(B8 + b_off[j] + kofs, (__attribute__((address_space(3))) void*)(sbase + A8_BYTES + piece + j * 8192), 16, 0, 0);
-}
-
-__device__ __forceinline__ i32x8_t q8_frag(const unsigned char* sb, int ad0, int ad1) {
-  const i32x4_t lo = *reinterpret_cast<const i32x4_t*>(sb + ad0), hi = *reinterpret_cast<const i32x4_t*>(sb + ad1);
-  return i32x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
-
+// (Round 4 also had an "X8" form -- two fp16 planes + two bf8 planes of the activations, the two 2^-22-order products on
+// v_mfma_scale_f32_32x32x64_f8f6f4 -- worth 0.7 % at c3 and removed in round 5; NOTES.md section 10 keeps the measurements and what was
+// learnt about that instruction's inner sum.)
 // ---- AF = 1: the A operand as plain float32, split into its three bf16 planes IN REGISTERS (round 4) ------------------------------------
 // "QF" layout of A[rows][cols]: blocks of 4 rows x 16 columns fp32 = 256 B (the block geometry of the two-plane half format):
 //   element (r, k) -> byte ((r/4) * (cols/16) + k/16) * 256 + (r%4) * 64 + (k%16) * 4
@@ -120,14 +77,13 @@ __host__ __device__ constexpr bool q_use_product(int PA, int PB, int NPROD, int 
 }
 
 // P / PB = planes of the A / B operand (PB defaults to P).  F16 = 1: the planes are IEEE half (11-bit significands) and the products
-// run on v_mfma_f32_32x32x16_f16, else bf16.  NPROD = number of plane products (q_use_product).  The engine uses <.., 2, S, 1, 4, 3>
-// (default mode), <.., 3, S> (split-bf16) and <.., 2, S, 1, 3, 2> (dev: two-plane weights); the bf16 P = 2 form is gemm_bench's.
+// run on v_mfma_f32_32x32x16_f16, else bf16.  NPROD = number of plane products (q_use_product).  The engine uses <.., 3, 2, 0, 6, 3, 1>
+// (bf16x3 / split-bf16: A as float32, AF) and <.., 2, 2, 1, 4, 3> (split: fp16 planes, exact weights); the other forms are gemm_bench's.
 // S = ring stages (2: request tile kt+1 while tile kt is consumed; 3: two tiles in flight -- more tolerant of HBM latency when
 // other kernels load the memory system, at 144 KB of LDS for the wide tile).
-template <int CPLX, int WIDE, int P = 3, int S = 2, int F16 = 0, int NPROD = (P == 3 ? 6 : 3), int PB = P, int X8 = 0, int AF = 0>
+template <int CPLX, int WIDE, int P = 3, int S = 2, int F16 = 0, int NPROD = (P == 3 ? 6 : 3), int PB = P, int AF = 0>
 __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
-  static_assert(!AF || (P == 3 && PB == 3 && F16 == 0 && X8 == 0), "AF: the six-product bf16 form with A as float32");
-  static_assert(!X8 || (P == 2 && PB == 3 && F16 == 1 && NPROD == 4 && S == 2), "X8: two half planes of A, three (exact) of B, the four 16-bit products of the split-f16 form, two ring stages");
+  static_assert(!AF || (P == 3 && PB == 3 && F16 == 0), "AF: the six-product bf16 form with A as float32");
   static_assert((P == 3 && PB == 3 && NPROD == 6) || (P == 2 && PB == 2 && (NPROD == 3 || NPROD == 4)) || (P == 2 && PB == 3 && (NPROD == 4 || NPROD == 5)), "plane products");
   constexpr int BM = 256, BN = WIDE ? 256 : 128;
   constexpr int BMR = CPLX ? BM / 2 : BM, BNC = CPLX ? BN / 2 : BN;
@@ -137,13 +93,10 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
   constexpr int TNW = WIDE ? 4 : 2;                       // 32-column MFMA tiles per wave
   constexpr int JA = A_BYTES / 8192;                      // DMA rounds of the whole block (512 lanes x 16 B)
   constexpr int JBF = B_BYTES / 8192, BHR = (B_BYTES % 8192) ? 1 : 0;
-  constexpr int A8_BYTES = X8 ? BM * 128 : 0, B8_BYTES = X8 ? BN * 128 : 0;     // one K = 64 slab of the 8-bit planes
-  constexpr int JA8 = X8 ? A8_BYTES / 8192 : 1, JB8 = X8 ? B8_BYTES / 8192 : 1, G8 = JA8 + JB8;
-  static_assert(S * STAGE + A8_BYTES + B8_BYTES <= 160 * 1024 && A_BYTES % 8192 == 0 && (B_BYTES % 8192 == 0 || B_BYTES % 8192 == 4096), "tile geometry");
+  static_assert(S * STAGE <= 160 * 1024 && A_BYTES % 8192 == 0 && (B_BYTES % 8192 == 0 || B_BYTES % 8192 == 4096), "tile geometry");
   static_assert((P == 2 || P == 3) && (PB == 2 || PB == 3), "two or three planes");
   static_assert(S >= 2 && S <= 4, "ring depth");
-  __shared__ __attribute__((aligned(1024))) unsigned char ring[S * STAGE + A8_BYTES + B8_BYTES];
-  unsigned char* const slab8 = ring + S * STAGE;
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[S * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, h = lane >> 5;
@@ -178,26 +131,6 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
     else      { int cg = nt * (BN / 4) + g; if (cg >= gN) cg = gN - 1; grp = cg; }
     b_off[j] = grp * b_blocks * BLKB + (s ^ q_swz<PB>(g)) * 16;
   }
-  long a8_off[JA8], b8_off[JB8];
-  if constexpr (X8) {
-#pragma unroll
-    for (int j = 0; j < JA8; ++j) {
-      const int c = tid + 512 * j, tr = c >> 3, s = c & 7;
-      long erow; int offA;
-      if (CPLX) { erow = (long)mt * BMR + (tr % BMR); offA = (tr / BMR) ? p.offA1 : p.offA0; }
-      else      { erow = (long)mt * BM + tr;          offA = p.offA0; }
-      if (erow >= p.M) erow = p.M - 1;
-      a8_off[j] = erow * p.lda8 + (long)(offA / 64) * 128 + (s ^ q8_swz(tr)) * 16;
-    }
-#pragma unroll
-    for (int j = 0; j < JB8; ++j) {
-      const int c = tid + 512 * j, tr = c >> 3, s = c & 7;
-      int brow;
-      if (CPLX) { int cc = nt * BNC + (tr % BNC); if (cc >= p.N) cc = p.N - 1; brow = (tr / BNC) * p.bHalf + cc; }
-      else      { brow = nt * BN + tr; if (brow >= p.N) brow = p.N - 1; }
-      b8_off[j] = (long)brow * (2L * p.K) + (s ^ q8_swz(tr)) * 16;      // (row pitch of the O8 planes: 2 K bytes)
-    }
-  }
   const int piece = __builtin_amdgcn_readfirstlane(wave * 1024);
   const bool b_tail = __builtin_amdgcn_readfirstlane(wave < 4 ? 1 : 0) != 0;
 
@@ -225,28 +158,8 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
     for (int q = 0; q < PB; ++q) b_ad[t][q] = A_BYTES + q_row_off<PB>(row) + ((q * 2 + h) ^ q_swz<PB>(row >> 2)) * 16;
   }
 
-  int a8_ad[2][2][2], b8_ad[TNW][2][2];  // X8: byte address of the lane's two 16-B pieces (32 consecutive k of one row), per plane
-  if constexpr (X8) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int row = CPLX ? (t * BMR + wm * 32 + l31) : (wm * 64 + t * 32 + l31);
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) a8_ad[t][q][i] = row * 128 + ((q * 4 + h * 2 + i) ^ q8_swz(row)) * 16;
-    }
-#pragma unroll
-    for (int t = 0; t < TNW; ++t) {
-      const int row = CPLX ? ((t / (TNW / 2)) * BNC + wn * (16 * TNW) + (t % (TNW / 2)) * 32 + l31) : (wn * (32 * TNW) + t * 32 + l31);
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) b8_ad[t][q][i] = A8_BYTES + row * 128 + ((q * 4 + h * 2 + i) ^ q8_swz(row)) * 16;
-    }
-  }
-
   const int nk = p.K / 16;
-  constexpr int TAG = 9000 + S * 100 + P * 10 + CPLX * 2 + WIDE + F16 * 1000 + NPROD * 10000 + PB * 100000 + X8 * 1000000 + AF * 10000000;   // one q3_issue instance per kernel
+  constexpr int TAG = 9000 + S * 100 + P * 10 + CPLX * 2 + WIDE + F16 * 1000 + NPROD * 10000 + PB * 100000 + AF * 10000000;   // one q3_issue instance per kernel
   constexpr int GI = JA + JBF;                            // DMA instructions per tile per wave (+1 for the waves that fetch the half round)
 #pragma unroll
   for (int t = 0; t < S - 1; ++t)
@@ -254,14 +167,11 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
   int st_cur = 0, st_nxt = S - 1;
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt has landed once at most the requests of the S-2 younger tiles are outstanding (fewer near the tail: wait for all)
-    if (X8 && (kt & 3) == 1) wait_vmcnt<G8>();      // tile kt was requested BEFORE slab kt/4 (k-tile kt-1): the slab may still be in flight
-    else if (S == 2 || kt + S - 2 >= nk) wait_vmcnt<0>();
+    if (S == 2 || kt + S - 2 >= nk) wait_vmcnt<0>();
     else if (BHR != 0 && b_tail) wait_vmcnt<(S - 2) * (GI + 1)>();
     else wait_vmcnt<(S - 2) * GI>();
     __builtin_amdgcn_s_barrier();   // tile kt landed everywhere; everyone finished reading tile kt-1
     if (kt + S - 1 < nk) q3_issue<JA, JBF, BHR, A_BYTES, TAG>(Ab, Bb, ring + st_nxt * STAGE, a_off, b_off, (long)(kt + S - 1) * BLK, (long)(kt + S - 1) * BLKB, piece, b_tail);
-    if constexpr (X8)
-      if ((kt & 3) == 0) q8_issue<JA8, JB8, A8_BYTES, TAG>(p.A8, p.B8, slab8, a8_off, b8_off, (long)(kt >> 2) * 128, piece);
     const unsigned char* sb = ring + st_cur * STAGE;
     st_cur = st_cur + 1 == S ? 0 : st_cur + 1;
     st_nxt = st_nxt + 1 == S ? 0 : st_nxt + 1;
@@ -299,23 +209,6 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
             if constexpr (F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a[i][qa]), __builtin_bit_cast(f16x8_t, b[j][qb]), acc[i][j], 0, 0, 0);
             else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][qa], b[j][qb], acc[i][j], 0, 0, 0);
           }
-      }
-    if constexpr (X8)
-      if ((kt & 3) == 3) {          // the two 8-bit products of this K = 64 slab: x1'.w1' (scales 2^-10, 2^-10) and x2'.w0' (2^-20, 1)
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-          if ((p.x8_skip >> pr) & 1) continue;
-          i32x8_t a8[2], b8[TNW];
-#pragma unroll
-          for (int t = 0; t < 2; ++t) a8[t] = q8_frag(slab8, a8_ad[t][pr][0], a8_ad[t][pr][1]);
-#pragma unroll
-          for (int t = 0; t < TNW; ++t) b8[t] = q8_frag(slab8, b8_ad[t][1 - pr][0], b8_ad[t][1 - pr][1]);
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < TNW; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], b8[j], acc[i][j], 1, 1, 0, pr ? 127 - Q8_SHIFT : 127 - Q8_SHIFT1, 0, pr ? 127 : 127 - Q8_SHIFT1);
-        }
       }
   }
 

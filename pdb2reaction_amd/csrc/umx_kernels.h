@@ -375,44 +375,6 @@ __global__ __launch_bounds__(256) void k_norm_bwd(const float* __restrict__ gy, 
   }
 }
 
-// LayerNorm(128) + SiLU on rows of the radial MLP
-__global__ __launch_bounds__(256) void k_ln_silu_fwd(const float* __restrict__ x, const float* __restrict__ w,
-                                                     const float* __restrict__ b, float* __restrict__ y, long rows) {
-  UMX_WAVE_LOOP(row, rows) {
-  const int c0 = lane * 2;
-  float2 v = *reinterpret_cast<const float2*>(x + row * RH + c0);
-  const float mu = wave_sum(v.x + v.y) * (1.0f / RH);
-  v.x -= mu; v.y -= mu;
-  const float var = wave_sum(v.x * v.x + v.y * v.y) * (1.0f / RH);
-  const Rstd rstd = rstd_eps(var, LN_EPS);
-  const float2 ww = *reinterpret_cast<const float2*>(w + c0), bb = *reinterpret_cast<const float2*>(b + c0);
-  *reinterpret_cast<float2*>(y + row * RH + c0) =
-      make_float2(silu_f(scale_rstd(v.x, rstd) * ww.x + bb.x), silu_f(scale_rstd(v.y, rstd) * ww.y + bb.y));
-  }
-}
-
-__global__ __launch_bounds__(256) void k_ln_silu_bwd(const float* __restrict__ gout, const float* __restrict__ x,
-                                                     const float* __restrict__ w, const float* __restrict__ b,
-                                                     float* __restrict__ gx, long rows) {
-  UMX_WAVE_LOOP(row, rows) {
-  const int c0 = lane * 2;
-  float2 v = *reinterpret_cast<const float2*>(x + row * RH + c0);
-  const float2 go = *reinterpret_cast<const float2*>(gout + row * RH + c0);
-  const float mu = wave_sum(v.x + v.y) * (1.0f / RH);
-  v.x -= mu; v.y -= mu;
-  const float var = wave_sum(v.x * v.x + v.y * v.y) * (1.0f / RH);
-  const float rstd = rstd_eps(var, LN_EPS).y;              // (reverse pass: feeds forces only)
-  const float2 ww = *reinterpret_cast<const float2*>(w + c0), bb = *reinterpret_cast<const float2*>(b + c0);
-  const float xh0 = v.x * rstd, xh1 = v.y * rstd;
-  const float gw0 = go.x * silu_grad_f(xh0 * ww.x + bb.x) * ww.x;
-  const float gw1 = go.y * silu_grad_f(xh1 * ww.y + bb.y) * ww.y;
-  const float m1 = wave_sum(gw0 + gw1) * (1.0f / RH);
-  const float m2 = wave_sum(gw0 * xh0 + gw1 * xh1) * (1.0f / RH);
-  *reinterpret_cast<float2*>(gx + row * RH + c0) =
-      make_float2(rstd * (gw0 - m1 - xh0 * m2), rstd * (gw1 - m1 - xh1 * m2));
-  }
-}
-
 // K8, ff_type = grid (fairchem GridAtomwise [3P-UNVERIFIED]): the S2-grid projections of the atom-wise block.
 // The (G, 9) matrices are DATA of the weight blob (so3_grid.to_grid_mat / from_grid_mat).  One wave per node, two channels per lane:
 // every access is one contiguous 512-B row; the matrix entries are wave-uniform (scalar loads).
@@ -777,18 +739,6 @@ __global__ __launch_bounds__(256) void k_gather_rotate_bwd(const float* __restri
   }
 #pragma unroll
   for (int r = 0; r < 9; ++r) *reinterpret_cast<float2*>(gxn + node * ROW + r * C + c0) = make_float2(ax[r], ay[r]);
-}
-
-// dE/dd through the gaussian basis: dedd[e] += sum_k ggauss[e][k] * d/dd exp(gcoef (d - mu_k)^2)
-__global__ __launch_bounds__(256) void k_radial_dd(const float* __restrict__ ggauss, const float* __restrict__ evec,
-                                                   double gcoef, const double* __restrict__ gmu, float* __restrict__ dedd, long ne) {
-  UMX_WAVE_LOOP(e, ne) {
-  const float d = evec[e * 4 + 3];
-  const double t = (double)d - gmu[lane];
-  float v = ggauss[e * NG + lane] * exp_f((float)(gcoef * t * t)) * (float)(2.0 * gcoef * t);
-  v = wave_sum(v);
-  if (lane == 0) dedd[e] += v;
-  }
 }
 
 // dst = a + b (a may alias dst); graph-parallel mode: residual + the all-reduced sum of the ranks' partial aggregates

@@ -67,15 +67,12 @@ template <int P> __device__ __forceinline__ void pl_store4(unsigned short* row, 
 //                  2^-14 / QF16_SCALE a fixed absolute resolution of 2^-25 / QF16_SCALE -- half subnormals are kept by the
 //                  conversion and by the MFMA), 256-B blocks.  |x| >= 65520 / QF16_SCALE converts to inf, the low plane to -inf
 //                  and the GEMM output to NaN: a range violation cannot pass silently (the energy comes out non-finite).
-//   FMT 2 ("Q2H+O8"): FMT 1 plus, in a second buffer, the two 8-bit planes of the 2^-22-order products (umx_gemm_q.h, X8 = 1):
-//                  x1' = bf8(2^Q8_SHIFT1 lo) and x2' = bf8(2^Q8_SHIFT (s x - hi - lo)), one 128-B line per (row, 64-column chunk):
-//                  byte (row * (cols/64) + k/64) * 128 + plane * 64 + k%64.  25 significant bits in all.
 // element (row, k, plane q) of a matrix with `cols` columns -> byte ((row/4) * (cols/16) + k/16) * 128 P + (row%4) * 32 P + q * 32 + (k%16) * 2.
 constexpr float QF16_SCALE = 16.f;
 //   FMT 3 ("QF"):  plain float32, 256-B blocks of 4 rows x 16 columns (row r of a block = 64 B): the A operand of the bf16x3 GEMMs since
 //                  round 4 -- umx_gemm_q.h (AF = 1) splits it into the three bf16 planes in registers, bit for bit the planes of FMT 0,
 //                  at 4 B instead of 6 B per element through HBM, L2 and LDS.
-template <int FMT> struct QFmt { static constexpr int P = FMT ? 2 : 3; static constexpr int BLK = 128 * P; static constexpr int ROWB = 32 * P; static constexpr bool X8 = (FMT == 2); static constexpr bool F32 = (FMT == 3); };
+template <int FMT> struct QFmt { static constexpr int P = FMT ? 2 : 3; static constexpr int BLK = 128 * P; static constexpr int ROWB = 32 * P; static constexpr bool F32 = (FMT == 3); };
 // LDS staging of one row piece (16 columns of one row of a block = 8 P dwords at `rowbase`): two / four adjacent values at column k15 of the piece
 template <int FMT> __device__ __forceinline__ void q_split2(float x0, float x1, unsigned int (&out)[QFmt<FMT>::P]);
 template <int FMT> __device__ __forceinline__ void q_stage2(unsigned int* rowbase, int k15, float x0, float x1) {
@@ -96,26 +93,6 @@ template <int FMT> __device__ __forceinline__ void q_stage4(unsigned int* rowbas
 #pragma unroll
     for (int q = 0; q < QFmt<FMT>::P; ++q) *reinterpret_cast<uint2*>(rowbase + (k15 >> 1) + q * 8) = make_uint2(wa[q], wb[q]);
   }
-}
-// the 8-bit planes of two adjacent values: bits 0-15 = the two bytes of plane 0 (x1'), bits 16-31 = those of plane 1 (x2').
-// (bf8 = e5m2, largest finite value 57344: |lo| <= 2^-11 * 65504 and |residual| <= 2^-22 * 65504 stay far inside after the shifts)
-__device__ __forceinline__ unsigned int o8_split2(float x0, float x1) {
-  x0 *= QF16_SCALE; x1 *= QF16_SCALE;
-  const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-  const float d0 = x0 - (float)h0, d1 = x1 - (float)h1;
-  const _Float16 l0 = (_Float16)d0, l1 = (_Float16)d1;
-  const float r0 = (d0 - (float)l0) * (float)(1 << Q8_SHIFT), r1 = (d1 - (float)l1) * (float)(1 << Q8_SHIFT);
-  int v = __builtin_amdgcn_cvt_pk_bf8_f32((float)l0 * (float)(1 << Q8_SHIFT1), (float)l1 * (float)(1 << Q8_SHIFT1), 0, false);
-  v = __builtin_amdgcn_cvt_pk_bf8_f32(r0, r1, v, true);
-  return (unsigned int)v;
-}
-__device__ __forceinline__ unsigned char* o8_ptr(unsigned char* base, long row, int cols, int k) { return base + (row * (cols >> 6) + (k >> 6)) * 128 + (k & 63); }
-// direct (2-byte) stores of the 8-bit planes of two adjacent values -- only where a row is short (the 128-column radial operand)
-__device__ __forceinline__ void o8_store2(unsigned char* base, long row, int cols, int k, float x0, float x1) {
-  const unsigned int w = o8_split2(x0, x1);
-  unsigned char* d = o8_ptr(base, row, cols, k);
-  *reinterpret_cast<unsigned short*>(d) = (unsigned short)(w & 0xffffu);
-  *reinterpret_cast<unsigned short*>(d + 64) = (unsigned short)(w >> 16);
 }
 // two adjacent values -> one packed dword per plane
 template <int FMT> __device__ __forceinline__ void q_split2(float x0, float x1, unsigned int (&out)[QFmt<FMT>::P]) {
@@ -180,66 +157,6 @@ template <int FMT> __device__ __forceinline__ void q_store4(unsigned short* base
   for (long _vb = blockIdx.x; _vb < _nvb; _vb += gridDim.x)                           \
     if (const long idx = __builtin_amdgcn_readfirstlane((int)(((_vb & 7) * _per + (_vb >> 3)) * 4 + (threadIdx.x >> 6))); idx < (count))
 
-// LayerNorm(128)+SiLU of the radial MLP, output as PL planes (A operand of the fc3 GEMM)
-template <int P, bool Q = false, int FMT = (P == 2 ? 1 : 0)>      // Q: quad-row output in format FMT (QFmt)
-__global__ __launch_bounds__(256) void k_ln_silu_fwd_pl(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ b, unsigned short* __restrict__ y, long rows, float odd_sign,
-                                                        unsigned char* __restrict__ y8) {
-  UMX_WAVE_LOOP(row, rows) {
-  const int c0 = lane * 2;
-  float2 v = *reinterpret_cast<const float2*>(x + row * RH + c0);
-  const float mu = wave_sum(v.x + v.y) * (1.0f / RH);
-  v.x -= mu; v.y -= mu;
-  const float var = wave_sum(v.x * v.x + v.y * v.y) * (1.0f / RH);
-  const Rstd rstd = rstd_eps(var, LN_EPS);
-  const float2 ww = *reinterpret_cast<const float2*>(w + c0), bb = *reinterpret_cast<const float2*>(b + c0);
-  const float sg = row_sign(row, odd_sign);
-  const float o0 = sg * silu_f(scale_rstd(v.x, rstd) * ww.x + bb.x), o1 = sg * silu_f(scale_rstd(v.y, rstd) * ww.y + bb.y);
-  if (Q) q_store2<FMT>(y, row, RH, c0, o0, o1);
-  else pl_store2<P>(y + row * (RH * P), c0, o0, o1);
-  if (Q && P == 2 && y8) o8_store2(y8, row, RH, c0, o0, o1);    // (+ the 8-bit planes, FMT 2)
-  }
-}
-
-// K7a fused: y1[e] = (W_e [xn[src] | xn[dst]]) .* rad[e]  as PL planes (9 m-primary rows x 256 columns)
-template <int P, bool Q = false>
-__global__ __launch_bounds__(256) void k_gather_rotate_mod_pl(const float* __restrict__ xn, const int* __restrict__ esrc,
-                                                              const int* __restrict__ edst, const float* __restrict__ frame,
-                                                              const float* __restrict__ rad, unsigned short* __restrict__ y1, long ne, float odd_sign) {
-  UMX_WAVE_ITEM_PL_XCD(e, ne)
-  const int c0 = lane * 2;
-  const float* f = frame + e * FRAME;
-  const float sg = row_sign(e, odd_sign);
-  const long js = esrc[e], jd = edst[e];
-  float sx[9], sy[9], dx[9], dy[9];
-#pragma unroll
-  for (int r = 0; r < 9; ++r) {
-    const float2 a = *reinterpret_cast<const float2*>(xn + js * ROW + r * C + c0);
-    const float2 b = *reinterpret_cast<const float2*>(xn + jd * ROW + r * C + c0);
-    sx[r] = a.x; sy[r] = a.y; dx[r] = b.x; dy[r] = b.y;
-  }
-  const float* rd = rad + e * RAD;
-  unsigned short* out = y1 + e * (long)(XROT * P);
-  const int ridx[9] = {0, 1, 2, 3, 4, 3, 4, 5, 5};   // radial row of each m-primary row
-  float p[9], q[9];
-  rot_fwd(f, sx, p); rot_fwd(f, sy, q);
-#pragma unroll
-  for (int r = 0; r < 9; ++r) {
-    float2 m = *reinterpret_cast<const float2*>(rd + ridx[r] * 2 * C + c0);
-    m.x *= sg; m.y *= sg;
-    if (Q) q_store2<(P == 2)>(y1, e, XROT, r * 2 * C + c0, p[r] * m.x, q[r] * m.y);
-    else pl_store2<P>(out, r * 2 * C + c0, p[r] * m.x, q[r] * m.y);
-  }
-  rot_fwd(f, dx, p); rot_fwd(f, dy, q);
-#pragma unroll
-  for (int r = 0; r < 9; ++r) {
-    float2 m = *reinterpret_cast<const float2*>(rd + ridx[r] * 2 * C + C + c0);
-    m.x *= sg; m.y *= sg;
-    if (Q) q_store2<(P == 2)>(y1, e, XROT, r * 2 * C + C + c0, p[r] * m.x, q[r] * m.y);
-    else pl_store2<P>(out, r * 2 * C + C + c0, p[r] * m.x, q[r] * m.y);
-  }
-}
-
 // K7a for the quad-row operand layouts (umx_gemm_q.h; FMT as QFmt).  A workgroup = the four edges of one row group.  Per m-primary
 // row r the four waves put their 256 modulated columns x P planes into LDS in exactly the byte order of the 16 consecutive blocks that
 // hold (row group, columns r*256 ... r*256+255), and the whole workgroup then writes those 6 KB (4 KB) with coalesced 16-B stores
@@ -247,12 +164,9 @@ __global__ __launch_bounds__(256) void k_gather_rotate_mod_pl(const float* __res
 template <int FMT>
 __global__ __launch_bounds__(256) void k_gather_rotate_mod_q3(const float* __restrict__ xn, const int* __restrict__ esrc,
                                                               const int* __restrict__ edst, const float* __restrict__ frame,
-                                                              const float* __restrict__ rad, unsigned short* __restrict__ y1, long ne, float odd_sign,
-                                                              unsigned char* __restrict__ y1o8) {
+                                                              const float* __restrict__ rad, unsigned short* __restrict__ y1, long ne, float odd_sign) {
   constexpr int P = QFmt<FMT>::P, BLK = QFmt<FMT>::BLK;
-  constexpr bool X8 = QFmt<FMT>::X8;
   __shared__ __attribute__((aligned(16))) unsigned int stage[2][16][4][8 * P];   // [buffer][16-column block][row in group][q*8 + pair]
-  __shared__ __attribute__((aligned(16))) unsigned char stage8[X8 ? 2 : 1][4][X8 ? 512 : 16];   // FMT 2: [buffer][edge][the 4 O8 lines of 256 columns]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long nvb = (((ne + 3) / 4 + 7) / 8) * 8;                                 // virtual blocks = row groups, padded to the 8 XCDs
   const long per = nvb >> 3;                                                     // XCD-contiguous groups (see UMX_WAVE_LOOP_PL_XCD)
@@ -284,12 +198,6 @@ __global__ __launch_bounds__(256) void k_gather_rotate_mod_q3(const float* __res
   unsigned char* gbase = reinterpret_cast<unsigned char*>(y1) + grp * (long)(XROT / 16) * BLK;
   auto put = [&](int buf, int col, float x0, float x1) {
     q_stage2<FMT>(&stage[buf][col >> 4][wave][0], col & 15, x0, x1);
-    if constexpr (X8) {
-      const unsigned int w8 = o8_split2(x0, x1);
-      unsigned char* d8 = &stage8[buf][wave][(col >> 6) * 128 + (col & 63)];
-      *reinterpret_cast<unsigned short*>(d8) = (unsigned short)(w8 & 0xffffu);
-      *reinterpret_cast<unsigned short*>(d8 + 64) = (unsigned short)(w8 >> 16);
-    }
   };
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
@@ -304,40 +212,7 @@ __global__ __launch_bounds__(256) void k_gather_rotate_mod_q3(const float* __res
     uint4* dst = reinterpret_cast<uint4*>(gbase + (long)r * 16 * BLK);
     dst[threadIdx.x] = src[threadIdx.x];
     if (P == 3 && threadIdx.x < 128) dst[256 + threadIdx.x] = src[256 + threadIdx.x];
-    if constexpr (X8)
-      if (threadIdx.x < 128 && e0 + (threadIdx.x >> 5) < ne)                 // 4 edges x 512 B: one 16-B chunk per thread, 512 contiguous bytes per edge
-        st_stream(reinterpret_cast<uint4*>(y1o8 + (e0 + (threadIdx.x >> 5)) * (long)(XROT * 2) + r * 512) + (threadIdx.x & 31),
-                  reinterpret_cast<const uint4*>(&stage8[buf][threadIdx.x >> 5][0])[threadIdx.x & 31]);
   }
-  }
-}
-
-// SO(2) gate: hg = [gate(256) | hpre(9x128)] (fp32) -> hid (9x128) as PL planes
-template <int P, bool Q = false>
-__global__ void k_gate_edge_fwd_pl(const float* __restrict__ hg, unsigned short* __restrict__ hid, long ne, float odd_sign) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ne * (H / 4)) return;
-  const long e = i / (H / 4);
-  const float sg = row_sign(e, odd_sign);
-  const int c = (int)(i % (H / 4)) * 4;
-  const float* p = hg + e * HG;
-  const float4 g1 = *reinterpret_cast<const float4*>(p + c), g2 = *reinterpret_cast<const float4*>(p + H + c);
-  const float4 s1 = make_float4(sigmoid_f(g1.x), sigmoid_f(g1.y), sigmoid_f(g1.z), sigmoid_f(g1.w));
-  const float4 s2 = make_float4(sigmoid_f(g2.x), sigmoid_f(g2.y), sigmoid_f(g2.z), sigmoid_f(g2.w));
-  unsigned short* o = hid + e * (long)(ROW * P);
-#pragma unroll
-  for (int r = 0; r < 9; ++r) {
-    const float4 v = *reinterpret_cast<const float4*>(p + 2 * H + r * H + c);
-    float4 w;
-    if (r == 0) w = make_float4(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w));
-    else {
-      const bool l1 = (r == 1 || r == 3 || r == 5);
-      const float4 s = l1 ? s1 : s2;
-      w = make_float4(v.x * s.x, v.y * s.y, v.z * s.z, v.w * s.w);
-    }
-    w.x *= sg; w.y *= sg; w.z *= sg; w.w *= sg;
-    if (Q) q_store4<(P == 2)>(hid, e, ROW, r * H + c, w);
-    else pl_store4<P>(o, r * H + c, w);
   }
 }
 
@@ -345,12 +220,9 @@ __global__ void k_gate_edge_fwd_pl(const float* __restrict__ hg, unsigned short*
 // planes of the 8 edges are staged in LDS in the byte order of their 2 x 8 consecutive blocks and written with coalesced
 // 16-B stores (same reason as k_gather_rotate_mod_q3).
 template <int FMT>
-__global__ __launch_bounds__(256) void k_gate_edge_fwd_q3(const float* __restrict__ hg, unsigned short* __restrict__ hid, long ne, float odd_sign,
-                                                          unsigned char* __restrict__ hido8) {
+__global__ __launch_bounds__(256) void k_gate_edge_fwd_q3(const float* __restrict__ hg, unsigned short* __restrict__ hid, long ne, float odd_sign) {
   constexpr int P = QFmt<FMT>::P, BLK = QFmt<FMT>::BLK;
-  constexpr bool X8 = QFmt<FMT>::X8;
   __shared__ __attribute__((aligned(16))) unsigned int stage[2][2][8][4][8 * P]; // [buffer][row group][16-column block][row][q*8 + pair]
-  __shared__ __attribute__((aligned(16))) unsigned char stage8[X8 ? 2 : 1][8][X8 ? 256 : 16];     // FMT 2: [buffer][edge][the 2 O8 lines of 128 columns]
   const long nvb = (ne + 7) / 8;
   for (long vb = blockIdx.x; vb < nvb; vb += gridDim.x) {                        // grid-stride over groups of 8 edges: any grid size works
   const long e0 = vb * 8;
@@ -380,17 +252,7 @@ __global__ __launch_bounds__(256) void k_gate_edge_fwd_q3(const float* __restric
     const float rs = row_sign(le, odd_sign);                                      // e0 is a multiple of 8: the edge's parity is le's
     x[0] *= rs; x[1] *= rs; x[2] *= rs; x[3] *= rs;
     q_stage4<FMT>(&stage[buf][le >> 2][c >> 4][le & 3][0], c & 15, x);
-    if constexpr (X8) {
-      const unsigned int a8 = o8_split2(x[0], x[1]), b8 = o8_split2(x[2], x[3]);
-      unsigned char* d8 = &stage8[buf][le][(c >> 6) * 128 + (c & 63)];
-      *reinterpret_cast<unsigned int*>(d8) = (a8 & 0xffffu) | (b8 << 16);
-      *reinterpret_cast<unsigned int*>(d8 + 64) = (a8 >> 16) | (b8 & 0xffff0000u);
-    }
     __syncthreads();
-    if constexpr (X8)
-      if (threadIdx.x < 128 && e0 + (threadIdx.x >> 4) < ne)                 // 8 edges x 256 B: one 16-B chunk per thread
-        st_stream(reinterpret_cast<uint4*>(hido8 + (e0 + (threadIdx.x >> 4)) * (long)(ROW * 2) + r * 256) + (threadIdx.x & 15),
-                  reinterpret_cast<const uint4*>(&stage8[buf][threadIdx.x >> 4][0])[threadIdx.x & 15]);
     // per row group: 8 blocks x 128 P bytes = 64 P chunks of 16 B; 128 P chunks in all
     constexpr int CPG = 64 * P;
 #pragma unroll

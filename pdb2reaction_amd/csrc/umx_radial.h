@@ -20,58 +20,17 @@
 
 namespace umx {
 
-#ifndef UMX_ABL
-#define UMX_ABL 0        // dev ablation mask of k_radial_head (tools/gpu_ab_lib.sh): 1 no MFMA, 2 no LayerNorm/SiLU, 4 no element tables, 8 no gaussian exp, 16 no global stores
-#endif
 constexpr int R_LD = 132;      // padded LDS row of a 128-wide activation tile (floats)
 constexpr int R_LDG = 68;      // padded LDS row of the 64-wide gaussian tile
+constexpr int R_TR = 2;        // 32-row MFMA tiles per workgroup tile (64 edges; two workgroups per CU)
 
 // (dpp_add / row16_sum / wave_sum_dpp: umx_common.h)
 
-// Transcendentals (template parameter FAST = UMX_RADIAL_FAST): these kernels are VALU-bound on exactly these functions (two
-// SiLU per element pair, 64 gaussians per edge).
-// MODE 0: the libm calls (umx_common.h policy).  MODE 1: hardware approximations as they are (biased: a one-signed energy shift).
-// MODE 2: hardware instructions with the argument reduced / the result refined so that each function is accurate to about 1 ulp
-// without the libm call sequences: exp by Cody-Waite reduction to |r| <= ln2/2 before v_exp_f32 (the plain v_exp_f32(x * log2e)
-// form loses absolute accuracy in the product for large |x|), reciprocal by one Newton step on v_rcp_f32.
-// Measured with csrc/func_bias.hip on 4 M arguments (mean SIGNED relative error / mean |error|): exp -2.349e-9 / 2.22e-8 against
-// libm's -2.354e-9 / 2.21e-8; sigmoid +1.6e-9 / 3.21e-8 against +1.2e-9 / 3.20e-8; SiLU -1.3e-9 / 3.82e-8 against -5.6e-10 / 3.81e-8;
-// reciprocal +4e-12 in both: as accurate per call, but the SiLU bias is 2.3x libm's and shows at c5 (-1.74e-4 against -1.28e-4 eV),
-// for 0.8 ms per c3 iteration -- mode 0 stays the default.
-template <int FAST> __device__ __forceinline__ float r_exp(float x) {
-#ifdef UMX_EXP_DOUBLE
-  if (FAST == 0) return (float)exp((double)x);
-#endif
-  if (FAST == 0) return expf(x);
-  if (FAST == 1) return __expf(x);
-  const float n = rintf(x * 1.44269504088896341f);
-  float r = fmaf(n, -0.693145751953125f, x);            // ln2 split hi / lo (hi has 11 trailing zero bits: n * hi is exact)
-  r = fmaf(n, -1.42860682030941723e-6f, r);
-  return ldexpf(__expf(r), (int)n);
-}
-template <int FAST> __device__ __forceinline__ float r_rcp(float x) {
-  if (FAST == 0) return 1.0f / x;
-  float y = __frcp_rn(x);
-  if (FAST == 2) y = fmaf(fmaf(-x, y, 1.0f), y, y);
-  return y;
-}
-template <int FAST> __device__ __forceinline__ float r_rsqrt(float x) {
-  if (FAST == 0) return 1.0f / sqrtf(x);
-  float y = __frsqrt_rn(x);
-  if (FAST == 2) y = fmaf(fmaf(-0.5f * x * y, y, 0.5f), y, y);
-  return y;
-}
-#ifdef UMX_EXP_DOUBLE
-template <int FAST> __device__ __forceinline__ float r_sigmoid(float x) { return (float)(1.0 / (1.0 + exp(-(double)x))); }
-template <int FAST> __device__ __forceinline__ float r_silu(float x) { return (float)((double)x / (1.0 + exp(-(double)x))); }
-#else
-template <int FAST> __device__ __forceinline__ float r_sigmoid(float x) { return r_rcp<FAST>(1.0f + r_exp<FAST>(-x)); }
-template <int FAST> __device__ __forceinline__ float r_silu(float x) { return x * r_sigmoid<FAST>(x); }
-#endif
-template <int FAST> __device__ __forceinline__ float r_silu_grad(float x) {
-  const float sg = r_sigmoid<FAST>(x);
-  return sg * (1.0f + x * (1.0f - sg));
-}
+// Transcendentals: the libm-accurate functions of umx_common.h.  These kernels are VALU-bound on exactly them (two SiLU per element pair, 64
+// gaussians per edge); rounds 3-4 measured the hardware approximations (raw: -4 ms per c3 iteration but a one-signed energy shift; with
+// argument reduction / a Newton step: -0.8 ms, as accurate per call, but a SiLU bias 2.3x libm's that shows at 20 000 atoms) and fp16 plane
+// products for fc1 / fc2 (-2.5 ms, energy error at 20 000 atoms x3) -- both removed in round 5, NOTES.md sections 5 and 9 keep the numbers.
+__device__ __forceinline__ float r_silu(float x) { return x * sigmoid_f(x); }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier: it also waits for every
 // GLOBAL store in flight (h1pre / h2pre / the fc3 operand rows), i.e. it exposes a full HBM write round trip at each of the seven
@@ -79,24 +38,22 @@ template <int FAST> __device__ __forceinline__ float r_silu_grad(float x) {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // LayerNorm(128) + SiLU of one row held as 2 values per lane (the arithmetic of k_ln_silu_fwd)
-template <int FAST>
 __device__ __forceinline__ float2 ln_silu_row(float2 v, float2 ww, float2 bb) {
   const float mu = wave_sum_dpp(v.x + v.y) * (1.0f / RH);
   v.x -= mu; v.y -= mu;
   const float var = wave_sum_dpp(v.x * v.x + v.y * v.y) * (1.0f / RH);
   const Rstd rstd = rstd_eps(var, LN_EPS);            // compensated sum, in every mode (umx_common.h: `var + 1e-5f` rounds one way)
-  return make_float2(r_silu<FAST>(scale_rstd(v.x, rstd) * ww.x + bb.x), r_silu<FAST>(scale_rstd(v.y, rstd) * ww.y + bb.y));
+  return make_float2(r_silu(scale_rstd(v.x, rstd) * ww.x + bb.x), r_silu(scale_rstd(v.y, rstd) * ww.y + bb.y));
 }
 // backward of it (the arithmetic of k_ln_silu_bwd): go = dE/d(output), v = the pre-LayerNorm row
-template <int FAST>
 __device__ __forceinline__ float2 ln_silu_row_bwd(float2 go, float2 v, float2 ww, float2 bb) {
   const float mu = wave_sum_dpp(v.x + v.y) * (1.0f / RH);
   v.x -= mu; v.y -= mu;
   const float var = wave_sum_dpp(v.x * v.x + v.y * v.y) * (1.0f / RH);
   const float rstd = rstd_eps(var, LN_EPS).y;         // (reverse pass: feeds dE/dd only)
   const float xh0 = v.x * rstd, xh1 = v.y * rstd;
-  const float gw0 = go.x * r_silu_grad<FAST>(xh0 * ww.x + bb.x) * ww.x;
-  const float gw1 = go.y * r_silu_grad<FAST>(xh1 * ww.y + bb.y) * ww.y;
+  const float gw0 = go.x * silu_grad_f(xh0 * ww.x + bb.x) * ww.x;
+  const float gw1 = go.y * silu_grad_f(xh1 * ww.y + bb.y) * ww.y;
   const float m1 = wave_sum_dpp(gw0 + gw1) * (1.0f / RH);
   const float m2 = wave_sum_dpp(gw0 * xh0 + gw1 * xh1) * (1.0f / RH);
   return make_float2(rstd * (gw0 - m1 - xh0 * m2), rstd * (gw1 - m1 - xh1 * m2));
@@ -120,77 +77,20 @@ __device__ __forceinline__ void rad_mma(const float* __restrict__ a_lds, const f
   }
 }
 
-// fp16 form of the two small linears (MM = 1, default mode only): the activations of a tile sit in LDS as TWO IEEE-half planes of 16 x
-// (what the large forward GEMMs use, umx_kernels_pl.h QFmt<1>), written ONCE by the row pass that produces them; the weights of the
-// lane's column sit in registers as THREE half planes of s x W (exact: 33 bits; s = a power of two per column).  Four products per
-// 16-k step on v_mfma_f32_32x32x16_f16 -- a_hi w0, a_hi w1, a_lo w0, a_hi w2, as umx_gemm_q.h -- instead of eight v_mfma_f32_32x32x2_f32:
-// a quarter of the matrix-pipe cycles.  Both linears feed a LayerNorm, so a gain error of the half MFMA's adder cancels.
-struct WPlanes { f16x8_t w0, w1, w2; };
-template <int NT>
-__device__ __forceinline__ float rad_load_wplanes(const float* __restrict__ wrow, int h, WPlanes (&out)[NT]) {
-  float x[NT][8];
-  float mx = 0.f;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const float4 a = *reinterpret_cast<const float4*>(wrow + 16 * t + 8 * h), b = *reinterpret_cast<const float4*>(wrow + 16 * t + 8 * h + 4);
-    x[t][0] = a.x; x[t][1] = a.y; x[t][2] = a.z; x[t][3] = a.w; x[t][4] = b.x; x[t][5] = b.y; x[t][6] = b.z; x[t][7] = b.w;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(x[t][j]));
-  }
-  mx = fmaxf(mx, __shfl_xor(mx, 32));                      // both k-halves of the column
-  int e = 0;
-  if (mx > 0.f) (void)frexpf(mx, &e);                       // mx = m 2^e, m in [0.5, 1)
-  const float sc = ldexpf(1.0f, 15 - e);                    // s |W| < 2^15
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float v = x[t][j] * sc;
-      const _Float16 a = (_Float16)v;
-      const float r1 = v - (float)a;
-      const _Float16 b = (_Float16)r1;
-      const _Float16 c = (_Float16)(r1 - (float)b);
-      out[t].w0[j] = a; out[t].w1[j] = b; out[t].w2[j] = c;
-    }
-  return 1.0f / (QF16_SCALE * sc);
-}
-// ROWB = bytes per LDS row, PLB = bytes per plane within a row
-template <int NT, int ROWB, int PLB, int TR>
-__device__ __forceinline__ void rad_mma_f16(const unsigned char* __restrict__ a_lds, const WPlanes (&w)[NT], f32x16 (&acc)[TR], int l31, int h) {
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    f16x8_t ah[TR], al[TR];
-#pragma unroll
-    for (int i = 0; i < TR; ++i) {
-      const unsigned char* p = a_lds + (i * 32 + l31) * ROWB + (16 * t + 8 * h) * 2;
-      ah[i] = *reinterpret_cast<const f16x8_t*>(p);
-      al[i] = *reinterpret_cast<const f16x8_t*>(p + PLB);
-    }
-#pragma unroll
-    for (int i = 0; i < TR; ++i) {
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], w[t].w0, acc[i], 0, 0, 0);
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], w[t].w1, acc[i], 0, 0, 0);
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], w[t].w0, acc[i], 0, 0, 0);
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], w[t].w2, acc[i], 0, 0, 0);
-    }
-  }
-}
-
 // ---- forward: d, Z_src, Z_dst  ->  h1pre, h2pre (kept for the reverse pass) and the fc3 operand --------------------------------
-// OUTQ3 = 1: the fc3 operand as Q3 bf16 planes (umx_gemm_q.h), 2: as fp16 two-plane "Q2H" planes (QFmt<1>), 3: Q2H + 8-bit planes (QFmt<2>), 4: float32 quad-row blocks (QFmt<3>);  0: fp32 rows (fp32
-// precision mode, and the edge-degree MLP whose fc3 runs on the fp32 GEMM).   ts / tt: per-element tables of the embedding part of fc1 (tt includes the fc1 bias).
-// TR = 32-row MFMA tiles per workgroup tile (RT = 32 TR edges).  TR = 1 halves the LDS and accumulator footprint so that three
-// workgroups share a CU: the VALU-heavy LayerNorm passes of one overlap the MFMAs of the others (measured against TR = 2 below).
-template <int OUTQ3, int FAST, int TR, int MM = 0>
-__global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const float* __restrict__ evec, const int* __restrict__ ez, double gcoef,
+// OUTQ = 2: the fc3 operand as fp16 two-plane "Q2H" planes (QFmt<1>, UMX_PRECISION=split), 4: float32 quad-row blocks (QFmt<3>: bf16x3 / split-bf16),
+// 0: fp32 rows (fp32 precision mode).   ts / tt: per-element tables of the embedding part of fc1 (tt includes the fc1 bias).
+template <int OUTQ>
+__global__ __launch_bounds__(256, 2) void k_radial_head(const float* __restrict__ evec, const int* __restrict__ ez, double gcoef,
                                                         const double* __restrict__ gmu, const float* __restrict__ w1g,
                                                         const double* __restrict__ ts, const double* __restrict__ tt,
                                                         const float* __restrict__ ln1w, const float* __restrict__ ln1b,
                                                         const float* __restrict__ w2, const float* __restrict__ b2,
                                                         const float* __restrict__ ln2w, const float* __restrict__ ln2b,
                                                         float* __restrict__ h1pre, float* __restrict__ h2pre, void* __restrict__ out, long ne,
-                                                        float odd_sign, unsigned char* __restrict__ out8) {
-  constexpr int RT = 32 * TR;
+                                                        float odd_sign) {
+  static_assert(OUTQ == 0 || OUTQ == 2 || OUTQ == 4, "fc3 operand format");
+  constexpr int TR = R_TR, RT = 32 * TR;
   __shared__ __attribute__((aligned(16))) float bufA[RT * R_LD];
   __shared__ __attribute__((aligned(16))) float bufB[RT * R_LD];
   __shared__ float dbuf[RT];
@@ -198,18 +98,11 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int col = wave * 32 + l31;                   // the output column this lane owns in both linears
-  constexpr bool M1 = (MM & 1) != 0, M2 = (MM & 2) != 0;      // MM: bit 0 = fc1, bit 1 = fc2 on fp16 plane products
-  float4 W1[M1 ? 1 : NG / 8], W2[M2 ? 1 : RH / 8];
-  WPlanes P1[M1 ? NG / 16 : 1], P2[M2 ? RH / 16 : 1];
-  float inv1 = 1.0f, inv2 = 1.0f;                    // 1 / (16 s) of the lane's column
-  if constexpr (!M1) {
+  float4 W1[NG / 8], W2[RH / 8];
 #pragma unroll
-    for (int c = 0; c < NG / 8; ++c) W1[c] = *reinterpret_cast<const float4*>(w1g + col * NG + c * 8 + 4 * h);
-  } else inv1 = rad_load_wplanes<NG / 16>(w1g + col * NG, h, P1);
-  if constexpr (!M2) {
+  for (int c = 0; c < NG / 8; ++c) W1[c] = *reinterpret_cast<const float4*>(w1g + col * NG + c * 8 + 4 * h);
 #pragma unroll
-    for (int c = 0; c < RH / 8; ++c) W2[c] = *reinterpret_cast<const float4*>(w2 + col * RH + c * 8 + 4 * h);
-  } else inv2 = rad_load_wplanes<RH / 16>(w2 + col * RH, h, P2);
+  for (int c = 0; c < RH / 8; ++c) W2[c] = *reinterpret_cast<const float4*>(w2 + col * RH + c * 8 + 4 * h);
   const float bias2 = b2[col];
   const float2 l1w = *reinterpret_cast<const float2*>(ln1w + 2 * lane), l1b = *reinterpret_cast<const float2*>(ln1b + 2 * lane);
   const float2 l2w = *reinterpret_cast<const float2*>(ln2w + 2 * lane), l2b = *reinterpret_cast<const float2*>(ln2b + 2 * lane);
@@ -233,21 +126,11 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
         // i.e. up to 4e-6 relative on a gaussian, the SAME for every edge -- the largest systematic term of the energy error ~ N
         const double dd = (double)d;
         float4 v; double t;
-        if (UMX_ABL & 8) { v.x = v.y = v.z = v.w = d; }
-        else {
-        t = dd - gmu[c0 + 4 * q + 0]; v.x = r_exp<FAST>((float)(gcoef * t * t));
-        t = dd - gmu[c0 + 4 * q + 1]; v.y = r_exp<FAST>((float)(gcoef * t * t));
-        t = dd - gmu[c0 + 4 * q + 2]; v.z = r_exp<FAST>((float)(gcoef * t * t));
-        t = dd - gmu[c0 + 4 * q + 3]; v.w = r_exp<FAST>((float)(gcoef * t * t));
-        }
-        if constexpr (!M1) *reinterpret_cast<float4*>(bufA + row * R_LDG + c0 + 4 * q) = v;
-        else {                                       // two half planes of 16 x gaussian: [64 halfs | 64 halfs] in the row's first 256 B
-          unsigned int wa[2], wb[2];
-          q_split2<1>(v.x, v.y, wa); q_split2<1>(v.z, v.w, wb);
-          unsigned char* pr = reinterpret_cast<unsigned char*>(bufA + row * R_LDG) + (c0 + 4 * q) * 2;
-          *reinterpret_cast<uint2*>(pr) = make_uint2(wa[0], wb[0]);
-          *reinterpret_cast<uint2*>(pr + NG * 2) = make_uint2(wa[1], wb[1]);
-        }
+        t = dd - gmu[c0 + 4 * q + 0]; v.x = exp_f((float)(gcoef * t * t));
+        t = dd - gmu[c0 + 4 * q + 1]; v.y = exp_f((float)(gcoef * t * t));
+        t = dd - gmu[c0 + 4 * q + 2]; v.z = exp_f((float)(gcoef * t * t));
+        t = dd - gmu[c0 + 4 * q + 3]; v.w = exp_f((float)(gcoef * t * t));
+        *reinterpret_cast<float4*>(bufA + row * R_LDG + c0 + 4 * q) = v;
       }
     }
     lds_barrier();
@@ -256,15 +139,12 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
     for (int i = 0; i < TR; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    if (!(UMX_ABL & 1)) {
-      if constexpr (!M1) rad_mma<NG / 8, R_LDG, TR>(bufA, W1, acc, l31, h);
-      else rad_mma_f16<NG / 16, R_LDG * 4, NG * 2, TR>(reinterpret_cast<const unsigned char*>(bufA), P1, acc, l31, h);
-    }
+    rad_mma<NG / 8, R_LDG, TR>(bufA, W1, acc, l31, h);
     // epilogue 1: the raw fc1 tile to bufB; the row pass below adds the element tables, writes h1pre (whole 512-B rows) and normalises
 #pragma unroll
     for (int i = 0; i < TR; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bufB[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * R_LD + col] = M1 ? acc[i][r] * inv1 : acc[i][r];
+      for (int r = 0; r < 16; ++r) bufB[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * R_LD + col] = acc[i][r];
     lds_barrier();
     // Pass 1a: + element tables, back into LDS -- global LOADS only.  gfx9 counts loads and stores on one in-order counter (vmcnt), so a
     // table load issued behind an h1pre store cannot be waited for without waiting for that store as well: with the stores in this
@@ -277,8 +157,8 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
       float2 v = *reinterpret_cast<const float2*>(p);
       // element tables in DOUBLE, the sum rounded once (round 3): a float32 table entry is off by a fixed 3e-8 relative, the same for every
       // edge of that element pair -- a pattern the LayerNorm does not remove, measured as a -2e-8 gain on the radial output
-      const double2 a = (UMX_ABL & 4) ? double2{0.0, 0.0} : *reinterpret_cast<const double2*>(ts + (zz & 0xffff) * RH + 2 * lane);
-      const double2 b = (UMX_ABL & 4) ? double2{0.0, 0.0} : *reinterpret_cast<const double2*>(tt + (zz >> 16) * RH + 2 * lane);
+      const double2 a = *reinterpret_cast<const double2*>(ts + (zz & 0xffff) * RH + 2 * lane);
+      const double2 b = *reinterpret_cast<const double2*>(tt + (zz >> 16) * RH + 2 * lane);
       v.x = (float)((double)v.x + (a.x + b.x)); v.y = (float)((double)v.y + (a.y + b.y));
       *reinterpret_cast<float2*>(p) = v;
     }
@@ -287,44 +167,31 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
       const int row = wave * (RT / 4) + rr;
       float* p = bufB + row * R_LD + 2 * lane;
       const float2 v = *reinterpret_cast<const float2*>(p);
-      if (!(UMX_ABL & 16) && e0 + row < ne) *reinterpret_cast<float2*>(h1pre + (e0 + row) * RH + 2 * lane) = v;
-      const float2 o = (UMX_ABL & 2) ? v : ln_silu_row<FAST>(v, l1w, l1b);
-      if constexpr (!M2) *reinterpret_cast<float2*>(p) = o;
-      else {                                         // in place: the wave has read the whole fp32 row (one ds_read) before these two writes
-        unsigned int w[2];
-        q_split2<1>(o.x, o.y, w);
-        unsigned int* pr = reinterpret_cast<unsigned int*>(bufB + row * R_LD);
-        pr[lane] = w[0];
-        pr[RH / 2 + lane] = w[1];
-      }
+      if (e0 + row < ne) *reinterpret_cast<float2*>(h1pre + (e0 + row) * RH + 2 * lane) = v;
+      *reinterpret_cast<float2*>(p) = ln_silu_row(v, l1w, l1b);
     }
     lds_barrier();
 #pragma unroll
     for (int i = 0; i < TR; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    if (!(UMX_ABL & 1)) {
-      if constexpr (!M2) rad_mma<RH / 8, R_LD, TR>(bufB, W2, acc, l31, h);
-      else rad_mma_f16<RH / 16, R_LD * 4, RH * 2, TR>(reinterpret_cast<const unsigned char*>(bufB), P2, acc, l31, h);
-    }
+    rad_mma<RH / 8, R_LD, TR>(bufB, W2, acc, l31, h);
     // epilogue 2: fc2 tile + bias to bufA (the gaussian tile is dead: every wave passed the barriers behind fc1)
 #pragma unroll
     for (int i = 0; i < TR; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bufA[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * R_LD + col] = (M2 ? acc[i][r] * inv2 : acc[i][r]) + bias2;
+      for (int r = 0; r < 16; ++r) bufA[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * R_LD + col] = acc[i][r] + bias2;
     lds_barrier();
 #pragma unroll 2
     for (int rr = 0; rr < RT / 4; ++rr) {            // h2pre out, LN + SiLU -> the fc3 operand
       const int row = wave * (RT / 4) + rr;
       const long e = e0 + row;
       const float2 v = *reinterpret_cast<const float2*>(bufA + row * R_LD + 2 * lane);
-      const float2 o = (UMX_ABL & 2) ? v : ln_silu_row<FAST>(v, l2w, l2b);
-      if (!(UMX_ABL & 16) && e < ne) {
+      const float2 o = ln_silu_row(v, l2w, l2b);
+      if (e < ne) {
         *reinterpret_cast<float2*>(h2pre + e * RH + 2 * lane) = v;
-        if (OUTQ3) {
-          q_store2<(OUTQ3 == 4 ? 3 : OUTQ3 >= 2 ? 1 : 0)>(reinterpret_cast<unsigned short*>(out), e, RH, 2 * lane, row_sign(e, odd_sign) * o.x, row_sign(e, odd_sign) * o.y);
-          if (OUTQ3 == 3) o8_store2(out8, e, RH, 2 * lane, row_sign(e, odd_sign) * o.x, row_sign(e, odd_sign) * o.y);      // Q2H + the 8-bit planes (QFmt<2>)
-        } else *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + e * RH + 2 * lane) = o;
+        if (OUTQ) q_store2<(OUTQ == 4 ? 3 : 1)>(reinterpret_cast<unsigned short*>(out), e, RH, 2 * lane, row_sign(e, odd_sign) * o.x, row_sign(e, odd_sign) * o.y);
+        else *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + e * RH + 2 * lane) = o;
       }
     }
   }
@@ -332,14 +199,13 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_head(const floa
 
 // ---- reverse: dE/d(fc3 operand) -> dE/dd (accumulated into dedd) ------------------------------------------------------------------
 // ga2 = output of the fc3^T GEMM; w2T = W2^T ([k][j]), w1gT = W1g^T ([64 gaussians][128]).
-template <int FAST, int TR>
-__global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_tail(const float* __restrict__ ga2, const float* __restrict__ h2pre,
+__global__ __launch_bounds__(256, 2) void k_radial_tail(const float* __restrict__ ga2, const float* __restrict__ h2pre,
                                                         const float* __restrict__ h1pre, const float* __restrict__ evec, double gcoef,
                                                         const double* __restrict__ gmu, const float* __restrict__ ln2w,
                                                         const float* __restrict__ ln2b, const float* __restrict__ ln1w,
                                                         const float* __restrict__ ln1b, const float* __restrict__ w2T,
                                                         const float* __restrict__ w1gT, float* __restrict__ dedd, long ne) {
-  constexpr int RT = 32 * TR;
+  constexpr int TR = R_TR, RT = 32 * TR;
   __shared__ __attribute__((aligned(16))) float bufA[RT * R_LD];
   __shared__ __attribute__((aligned(16))) float bufB[RT * R_LD];
   __shared__ float dbuf[RT];
@@ -347,7 +213,7 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_tail(const floa
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int col = wave * 32 + l31;
-  const int gi = wave >> 1, gj = wave & 1;           // last linear (128 -> 64): wave -> (row tile, column tile); TR = 1: waves 0 and 1 only
+  const int gi = wave >> 1, gj = wave & 1;           // last linear (128 -> 64): wave -> (row tile, column tile)
   float4 W2T[RH / 8], W1T[RH / 8];
 #pragma unroll
   for (int c = 0; c < RH / 8; ++c) W2T[c] = *reinterpret_cast<const float4*>(w2T + col * RH + c * 8 + 4 * h);
@@ -367,7 +233,7 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_tail(const floa
       const long e = e0 + row < ne ? e0 + row : ne - 1;
       const float2 go = *reinterpret_cast<const float2*>(ga2 + e * RH + 2 * lane);
       const float2 x = *reinterpret_cast<const float2*>(h2pre + e * RH + 2 * lane);
-      *reinterpret_cast<float2*>(bufA + row * R_LD + 2 * lane) = ln_silu_row_bwd<FAST>(go, x, l2w, l2b);
+      *reinterpret_cast<float2*>(bufA + row * R_LD + 2 * lane) = ln_silu_row_bwd(go, x, l2w, l2b);
     }
     lds_barrier();
     f32x16 acc[TR];
@@ -387,7 +253,7 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_tail(const floa
       const long e = e0 + row < ne ? e0 + row : ne - 1;
       const float2 go = *reinterpret_cast<const float2*>(bufB + row * R_LD + 2 * lane);
       const float2 x = *reinterpret_cast<const float2*>(h1pre + e * RH + 2 * lane);
-      *reinterpret_cast<float2*>(bufA + row * R_LD + 2 * lane) = ln_silu_row_bwd<FAST>(go, x, l1w, l1b);
+      *reinterpret_cast<float2*>(bufA + row * R_LD + 2 * lane) = ln_silu_row_bwd(go, x, l1w, l1b);
     }
     lds_barrier();
     if (gi < TR) {   // g_gauss = g_h1 . W1g (128 -> 64): one 32 x 32 tile per wave (wave-uniform), then dE/dd = sum_k g_gauss[k] d/dd exp(gcoef (d - mu_k)^2)
@@ -407,7 +273,7 @@ __global__ __launch_bounds__(256, TR == 1 ? 3 : 2) void k_radial_tail(const floa
         const int row = gi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const double t = (double)dbuf[row] - mu_col;
         // sum over the 32 columns of this half-wave (two 16-lane rows), for both halves at once
-        const int rs = __builtin_bit_cast(int, row16_sum(a1[r] * r_exp<FAST>((float)(gcoef * t * t)) * (float)(2.0 * gcoef * t)));
+        const int rs = __builtin_bit_cast(int, row16_sum(a1[r] * exp_f((float)(gcoef * t * t)) * (float)(2.0 * gcoef * t)));
         const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rs, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(rs, 16));
         const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rs, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(rs, 48));
         if (lane == 0) { part[gj][row] = s0; part[gj][row + 4] = s1; }      // lane 0 sees h = 0: `row` is the first half's row, +4 the second's

@@ -217,7 +217,7 @@ class Engine:
         return e, f
 
     def precision_mode(self) -> str:
-        """The arithmetic the engine is in now ("bf16x3" | "split-f16" | "split-bf16" | "f16x2b8" | "fp32"): what "auto" resolved to."""
+        """The arithmetic the engine is in now ("bf16x3" | "split-f16" | "split-bf16" | "fp32"): what "auto" resolved to."""
         return self.lib.umx_precision_mode(self._h).decode()
 
     def take_range_error(self) -> bool:
@@ -233,11 +233,11 @@ class Engine:
         """Public form of the fp16 -> bf16 forward-plane switch, for callers that decide it collectively (parallel.py, hessian.py)."""
         return self._widen(why)
 
-    _WIDER = {"split-f16": "split-bf16", "f16x2b8": "bf16x3"}       # the mode with the same reverse pass and bf16 (float32-range) forward planes
+    _WIDER = {"split-f16": "split-bf16"}       # the mode with the same reverse pass and bf16 (float32-range) forward planes
 
     def _widen(self, why: str) -> bool:
-        """Move an engine whose forward operands are fp16 planes (split-f16, f16x2b8) to the mode with bf16 forward planes (split-bf16,
-        bf16x3) -- once; False when the engine is not in such a mode (or UMX_NO_WIDEN=1)."""
+        """Move an engine whose forward operands are fp16 planes (split-f16) to the mode with bf16 forward planes and the same reverse
+        pass (split-bf16) -- once; False when the engine is not in such a mode (or UMX_NO_WIDEN=1)."""
         wider = self._WIDER.get(self.precision_mode())
         if self.widened or self._blob is None or self._system is None or wider is None:
             return False

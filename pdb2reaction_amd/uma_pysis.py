@@ -276,11 +276,11 @@ class uma_pysis(Calculator):
         hessian_double: bool = CALC_KW["hessian_double"],
         **kwargs,
     ):
-        # not a reference keyword: the arithmetic of the large GEMMs ("auto" | "split" | "split-bf16" | "bf16x3" | "f16x2b8" | "fp32"; None = UMX_PRECISION).
+        # not a reference keyword: the arithmetic of the large GEMMs ("auto" | "split" | "split-bf16" | "bf16x3" | "fp32"; None = UMX_PRECISION).
         # Taken out of **kwargs so that the reference's signature stays as it is.
         precision = kwargs.pop("precision", None)
-        if precision not in (None, "auto", "split", "split-f16", "split-bf16", "bf16x3", "split-exact", "f16x2b8", "fp32"):
-            raise ValueError(f"precision must be auto, split, split-bf16, bf16x3, f16x2b8 or fp32, got {precision!r}")
+        if precision not in (None, "auto", "split", "split-f16", "split-bf16", "bf16x3", "split-exact", "fp32"):
+            raise ValueError(f"precision must be auto, split, split-bf16, bf16x3 or fp32, got {precision!r}")
         super().__init__(charge=charge, mult=spin, **kwargs)
         self._core: Optional[UMAcore] = None
         self._core_kw = dict(

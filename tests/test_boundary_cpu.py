@@ -326,6 +326,6 @@ def test_library_has_no_packed_fp32(tmp_path):
     # ... and the SHIPPED code object as a whole (GEMM and radial kernels, loop vectoriser, explicit float2 arithmetic included): the
     # gfx950 ELF inside libumx.so is disassembled and searched (build.check_no_packed_fp32, which build_library runs after linking)
     build.build_library(force=False, verbose=False)
-    assert build.check_no_packed_fp32(build.OUT) >= 100                        # kernels checked
+    assert build.check_no_packed_fp32(build.OUT) >= 60                         # kernels checked
     dis = build.device_disassembly(build.OUT)
     assert "k_norm_bwd" in dis and "umx_gemm_q_kernel" in dis and "k_radial_head" in dis

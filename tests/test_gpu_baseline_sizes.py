@@ -17,7 +17,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from pdb2reaction_amd import synth
+from pdb2reaction_amd import synth, weights as W
 
 U = importlib.import_module("pdb2reaction_amd.uma_pysis")
 
@@ -32,7 +32,7 @@ def gold():
     return load_golden("c3c4_n2000")
 
 
-@pytest.mark.parametrize("mode", ["split", "split-bf16", "bf16x3", "f16x2b8", "fp32"])
+@pytest.mark.parametrize("mode", ["split", "split-bf16", "bf16x3", "fp32"])
 def test_c3_energy_and_forces_against_f64_oracle(weights, gold, mode, monkeypatch):
     """The headline configuration: E and F of 2000-atom images vs the float64 oracle, every precision mode (split = fp16 forward
     planes, the default; split-bf16 = three bf16 forward planes; fp32 = fp32 MFMA everywhere)."""
@@ -199,7 +199,7 @@ def test_c2_c3_gsm_driver_at_baseline_sizes(n_atoms, n_img, gold):
     calc.close()
 
 
-@pytest.mark.parametrize("mode", ["auto", "split", "f16x2b8", "fp32"])
+@pytest.mark.parametrize("mode", ["auto", "split", "fp32"])
 def test_c5_energy_and_forces_against_f64_oracle(weights, mode, monkeypatch):
     """BASELINE configs[4]: a 20 000-atom image (1.6 M directed edges; one image needs more workspace than the default cap -- the
     engine then takes the full budget).  E and F against the float64 oracle (tools/make_golden_c5.py).
@@ -222,7 +222,7 @@ def test_c5_energy_and_forces_against_f64_oracle(weights, mode, monkeypatch):
     try:
         eng.load_weights(weights)
         eng.set_system(g["z"])
-        assert eng.precision_mode() == {"auto": "bf16x3", "split": "split-f16", "f16x2b8": "f16x2b8", "fp32": "fp32"}[mode]
+        assert eng.precision_mode() == {"auto": "bf16x3", "split": "split-f16", "fp32": "fp32"}[mode]
         e, f = eng.energy_forces(g["pos"][None])
         ne, maxdeg = eng.graph_stats()
         assert ne > 1_500_000 and maxdeg <= 300
@@ -233,5 +233,56 @@ def test_c5_energy_and_forces_against_f64_oracle(weights, mode, monkeypatch):
         assert de <= tol, (mode, de)
         assert df.max() <= TOL_F, (mode, df.max())
         assert not eng.widened
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("name", ["c5_n20000_g1", "c5_n20000_w1"])
+def test_c5_energy_on_another_geometry_and_another_weight_set(name):
+    """the 1e-4 eV energy bound at 20 000 atoms rests on a STATISTICAL cancellation (sign-alternating operand rows turn the
+    matrix cores' one-sided adder rounding into alternating-sign noise), so one geometry and one weight set is thin evidence.  Two more
+    float64 goldens (tools/make_golden_c5.py): `g1` = another cluster (seed 20260230, image 3), `w1` = the BASELINE geometry with another
+    synthetic weight set (seed 1).  Default mode (auto = bf16x3); the bound is include/umx.h's UMX_ENERGY_TOL_EV, not a number from the run."""
+    from pdb2reaction_amd.engine import Engine
+
+    g = load_golden(name)
+    eng = Engine(0)
+    try:
+        eng.load_weights(W.make_synthetic_weights(int(g["weights_seed"])))
+        eng.set_system(g["z"])
+        assert eng.precision_mode() == "bf16x3"
+        e, f = eng.energy_forces(g["pos"][None])
+        de = e[0] - g["energy"][0]
+        df = np.abs(f[0].astype(np.float64) - g["forces"][0]).max()
+        print(f"[{name}] dE = {de:+.2e} eV ({de / 20000:+.1e} eV/atom), max|dF| = {df:.2e} eV/A")
+        assert abs(de) <= TOL_E, (name, de)
+        assert df <= TOL_F, (name, df)
+    finally:
+        eng.close()
+
+
+def test_c5_energy_with_the_atom_order_permuted(weights):
+    """The same 20 000-atom image with its atoms in a random order: every edge gets another index, i.e. the parity that decides which operand
+    rows are stored negated is re-dealt -- the cancellation must not depend on the order the structure happens to be listed in.  Energy
+    against the float64 golden within UMX_ENERGY_TOL_EV, forces (un-permuted) within 1e-3 eV/A, and the two orders agree with each other
+    far inside the tolerance."""
+    from pdb2reaction_amd.engine import Engine
+
+    g = load_golden("c5_n20000")
+    perm = np.random.default_rng(5).permutation(len(g["z"]))
+    eng = Engine(0)
+    try:
+        eng.load_weights(weights)
+        eng.set_system(g["z"])
+        e0, _ = eng.energy_forces(g["pos"][None], forces=False)
+        eng.set_system(g["z"][perm])
+        e, f = eng.energy_forces(g["pos"][:, perm])
+        de = e[0] - g["energy"][0]
+        fb = np.empty_like(f[0])
+        fb[perm] = f[0]
+        df = np.abs(fb.astype(np.float64) - g["forces"][0]).max()
+        print(f"[c5 permuted] dE = {de:+.2e} eV (listed order: {e0[0] - g['energy'][0]:+.2e} eV), max|dF| = {df:.2e} eV/A")
+        assert abs(de) <= TOL_E and df <= TOL_F
+        assert abs(e[0] - e0[0]) <= TOL_E
     finally:
         eng.close()

@@ -37,7 +37,7 @@ def test_bench_json_line_contract():
     # the headline is the like-for-like mode: >= 24-bit products in both passes
     assert d["precision_requested"] == "auto" and d["precision_mode"] == "bf16x3" and d["dtype"] == "bf16x3-split"
     f = d["fp32_mode"]                                                               # the fp32-MFMA figure, same clock
-    assert f["value"] > 0 and f["dtype"].startswith("f32") and 0.0 < f["gemm_frac"] < 1.0 and f["steps"] >= 5 and f["warmup"] >= 2
+    assert f["value"] > 0 and f["dtype"].startswith("f32") and 0.0 < f["gemm_frac"] < 1.0 and f["steps"] >= 5 and f["warmup"] >= 2 and f["lanes"] == 1
     fm = d["fast_mode"]                                                              # the opt-in narrower mode, reported beside, never as `value`
     assert fm["value"] > 0 and fm["precision_mode"] == "split-f16" and "narrower" in fm["dtype"]
     assert r["lanes"] == 1 and "serial_schedule" not in d and "shard" not in d       # a tiny batch runs on one lane; the shard leg belongs to the headline sizes

@@ -66,7 +66,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA p
 PEAK_FP64_MFMA_TFLOPS = 78.6     # AMD MI355X datasheet: f64 matrix = f64 vector peak (the micro-arch guide has no f64 row)
 
 
-PMC_SUMMARIES = {"bf16x3": "r04_pmc_hbm_traffic_bf16x3.json", "split": "r04_pmc_hbm_traffic_split.json"}
+PMC_SUMMARIES = {"bf16x3": "r05_pmc_hbm_traffic_bf16x3.json", "split": "r05_pmc_hbm_traffic_split.json"}
 
 
 def pmc_summary(build_digest: str, mode: str):
@@ -322,22 +322,23 @@ def main():
         sample = list(range(0, n, max(1, n // sample_atoms)))[:sample_atoms]
         frz = sorted(set(range(n)) - set(sample))
         x0 = imgs[k // 2]
-        calls = {"n": 0, "geoms": 0}
+        calls = {"n": 0, "geoms": 0, "edges": 0}
 
         def batch_forces(disp):
             calls["n"] += 1
             calls["geoms"] += len(disp)
-            return eng.energy_forces(disp)[1]
+            f = eng.energy_forces(disp)[1]
+            calls["edges"] += eng.graph_stats()[0]
+            return f
 
         eng.reserve_images(64)
         batch_forces(np.repeat(x0[None], 64, axis=0))                     # warm-up: workspace for 64-image batches
-        calls.update(n=0, geoms=0)
+        calls.update(n=0, geoms=0, edges=0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         h = fd_hessian(batch_forces, x0, frz, device=dev, double=True, partial=False, batch=64, engine=eng)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        ne, _ = eng.graph_stats()
         ok = bool(torch.isfinite(h).all())
         eng.close()
         cols = 3 * len(sample)
@@ -345,7 +346,7 @@ def main():
         return {"columns": cols, "displaced_geometries": calls["geoms"], "engine_calls": calls["n"], "seconds": dt, "columns_per_s": cols / dt,
                 "ms_per_displaced_geometry": dt / calls["geoms"] * 1e3, "finite": ok, "batch": 64,
                 "full_hessian_columns": full_cols, "extrapolated_full_hessian_s": full_cols / (cols / dt),
-                "algorithmic_tflops": FLOP_PER_EDGE * (ne / 64.0) * calls["geoms"] / dt / 1e12,
+                "directed_edges": calls["edges"], "algorithmic_tflops": FLOP_PER_EDGE * calls["edges"] / dt / 1e12,
                 "note": f"hessian.fd_hessian (host-pointer entry: PCIe copies of 64 x {n} x 3 floats per call included), {cols} columns = {calls['geoms']} displaced "
                         f"{n}-atom geometries in batches of 64; extrapolated_full_hessian_s scales columns/s to the {full_cols} active columns of c4 "
                         "(an extrapolation of the same loop, not a second measurement)"}

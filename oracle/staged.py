@@ -147,8 +147,10 @@ class Staged:
         p, t = self.p, self.t
         g_a2 = g_rad @ p[f"{prefix}.fc3.weight"]
         g_h2 = ln_silu_bwd(g_a2, t[f"h2pre.{tag}"], p[f"{prefix}.ln2.weight"], p[f"{prefix}.ln2.bias"])
+        t[f"g_a2.{tag}"], t[f"g_h2pre.{tag}"] = g_a2, g_h2
         g_a1 = g_h2 @ p[f"{prefix}.fc2.weight"]
         g_h1 = ln_silu_bwd(g_a1, t[f"h1pre.{tag}"], p[f"{prefix}.ln1.weight"], p[f"{prefix}.ln1.bias"])
+        t[f"g_h1pre.{tag}"] = g_h1
         g_gauss = g_h1 @ p[f"{prefix}.fc1.weight"][:, : W.NUM_DISTANCE_BASIS]
         dgauss = t["gauss"] * (2.0 * self.gcoef) * (t["dist"][:, None] - self.mu[None, :])
         return (g_gauss * dgauss).sum(-1)
@@ -292,6 +294,7 @@ class Staged:
         dedd = dedd + denv * (gl * emb).sum(dim=(1, 2)) / W.DEG_RESCALE
         g_emb = gl * (env / W.DEG_RESCALE)[:, None, None]
         tau = tau - torque(g_emb, emb)
+        t["g_rad.deg"] = g_emb[:, 0:3]
         dedd = dedd + self.radial_bwd("edge_degree_embedding.rad_func", "deg", g_emb[:, 0:3].reshape(ne, 3 * C))
         # ---- assemble dE/dvec and scatter
         pole = torch.isclose(t["nhat"][:, 1], torch.ones_like(t["nhat"][:, 1]))

@@ -586,7 +586,7 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
     else hipLaunchKernelGGL(k_rotate_back_reduce<3>, dim3(nblk(nn, 4)), B256, 0, s, w.rad_deg, w.frame, w.row_ptr, (const float*)nullptr, w.xs[0], nn, DEG_RESCALE,
                             (const int*)eng->d_z, N, eng->emb_sphere, (const double*)eng->d_sysemb);
     HIPCHK(eng, hipGetLastError());
-    if (!gp) { DBG("rad.deg", w.rad_deg, ne * 3 * C); DBG("x0", w.xs[0], nn * ROW); }
+    if (!gp) { DBG("rad.deg", w.rad_deg, ne * 3 * C); DBG("x0", w.xs[0], nn * ROW); DBG("h1pre.deg", w.h1pre[NL], ne * RH); DBG("h2pre.deg", w.h2pre[NL], ne * RH); }
     return UMX_OK;
   });
   if (gp) {
@@ -679,7 +679,7 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       else hipLaunchKernelGGL(k_rotate_back_reduce<9>, dim3(vgrid(eng, nblk(nn, 4))), B256, 0, s, w.msg[i], w.frame, w.row_ptr, xin, xmid, nn, 1.0f,
                               (const int*)nullptr, 0, (const float*)nullptr, (const double*)nullptr);
       HIPCHK(eng, hipGetLastError());
-      DBG("xn" + t, w.xn[i], nn * ROW); DBG("rad" + t, w.rad[i], ne * RAD);
+      DBG("xn" + t, w.xn[i], nn * ROW); DBG("rad" + t, w.rad[i], ne * RAD); DBG("h1pre" + t, w.h1pre[i], ne * RH); DBG("h2pre" + t, w.h2pre[i], ne * RH);
       if (!eng->pl) { DBG("xrot" + t, w.xrot, ne * XROT); DBG("hid" + t, w.hid, ne * ROW); }
       DBG("hg" + t, w.hg[i], ne * HG); DBG("msg" + t, w.msg[i], ne * ROW); DBG("xmid" + t, xmid, nn * ROW);
       // K8 atom-wise

@@ -293,8 +293,11 @@ __global__ void k_node_init_add(const int* __restrict__ znode, int natoms, long 
 }
 
 // K6 RMS-norm-SH forward: wave per node, lane owns channels 2l, 2l+1
-// The balance weights 1/3, 1/9, 1/15 are applied as DIVISIONS (correctly rounded, error random per value): multiplying by the float32
-// constants scales the rms of every atom by the same 1e-8-level factor (systematic; see k_node_init).
+// Round 5: the whole row in DOUBLE (channel mean, sum of squares, 1/sqrt, scaling, affine), rounded once per output value.  The float32 form
+// (compensated rstd, divisions instead of reciprocal constants -- rounds 3-4) still carried an energy error COHERENT over the atoms:
+// tools/gpu_energy_cuts.py (linear response of the energy along cuts of the network) attributes +-1...3e-8 eV per atom to EACH norm, sign
+// depending on the weight set -- for the seed-0 weights it happened to cancel the other terms, for seed 1 it was +2.1e-5 eV at 700 atoms in
+// the final norm alone.  In double every norm's increment is +-3e-7 eV (noise).  Node-level work: no measurable cost.
 __global__ __launch_bounds__(256) void k_norm_fwd(const float* __restrict__ x, const float* __restrict__ aw,
                                                   const float* __restrict__ ab, const double* __restrict__ sysemb,
                                                   float* __restrict__ y, long nt) {
@@ -303,27 +306,28 @@ __global__ __launch_bounds__(256) void k_norm_fwd(const float* __restrict__ x, c
   float2 v[9];
 #pragma unroll
   for (int r = 0; r < 9; ++r) v[r] = *reinterpret_cast<const float2*>(x + node * ROW + r * C + c0);
-  const float mean0 = wave_sum(v[0].x + v[0].y) * (1.0f / C);
-  v[0].x -= mean0; v[0].y -= mean0;
-  float q0 = v[0].x * v[0].x + v[0].y * v[0].y, q1 = 0.f, q2 = 0.f;
+  // the whole row in double, rounded once per output value
+  const double mean0 = wave_sum_d((double)v[0].x + (double)v[0].y) * (1.0 / C);
+  double dx[9], dy[9];
 #pragma unroll
-  for (int r = 1; r < 4; ++r) q1 += v[r].x * v[r].x + v[r].y * v[r].y;
+  for (int r = 0; r < 9; ++r) { dx[r] = (double)v[r].x - (r == 0 ? mean0 : 0.0); dy[r] = (double)v[r].y - (r == 0 ? mean0 : 0.0); }
+  double q0 = dx[0] * dx[0] + dy[0] * dy[0], q1 = 0.0, q2 = 0.0;
 #pragma unroll
-  for (int r = 4; r < 9; ++r) q2 += v[r].x * v[r].x + v[r].y * v[r].y;
-  float q = q0 / 3.0f + q1 / 9.0f + q2 / 15.0f;
-  q = wave_sum(q) * (1.0f / C);
-  const Rstd s = rstd_eps(q, NORM_EPS);
+  for (int r = 1; r < 4; ++r) q1 += dx[r] * dx[r] + dy[r] * dy[r];
+#pragma unroll
+  for (int r = 4; r < 9; ++r) q2 += dx[r] * dx[r] + dy[r] * dy[r];
+  const double qd = wave_sum_d(q0 / 3.0 + q1 / 9.0 + q2 / 15.0) * (1.0 / C);
+  const double sd = 1.0 / sqrt(qd + (double)NORM_EPS);
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
     const int l = (r == 0) ? 0 : (r < 4 ? 1 : 2);
     const float2 w = *reinterpret_cast<const float2*>(aw + l * C + c0);
-    float2 o = make_float2(scale_rstd(v[r].x, s) * w.x, scale_rstd(v[r].y, s) * w.y);
+    double ox = dx[r] * sd * (double)w.x, oy = dy[r] * sd * (double)w.y;
     if (r == 0) {
       const float2 b = *reinterpret_cast<const float2*>(ab + c0);
-      if (sysemb) { o.x = (float)((double)o.x + ((double)b.x + sysemb[c0])); o.y = (float)((double)o.y + ((double)b.y + sysemb[c0 + 1])); }
-      else { o.x += b.x; o.y += b.y; }
+      ox += (double)b.x + (sysemb ? sysemb[c0] : 0.0); oy += (double)b.y + (sysemb ? sysemb[c0 + 1] : 0.0);
     }
-    *reinterpret_cast<float2*>(y + node * ROW + r * C + c0) = o;
+    *reinterpret_cast<float2*>(y + node * ROW + r * C + c0) = make_float2((float)ox, (float)oy);
   }
 }
 
@@ -473,7 +477,8 @@ __global__ __launch_bounds__(256) void k_energy_node(const float* __restrict__ p
   UMX_WAVE_ITEM(node, nt)
   const float2 w = *reinterpret_cast<const float2*>(w3 + lane * 2);
   const float2 v = *reinterpret_cast<const float2*>(pre2 + node * H + lane * 2);
-  const float en = wave_sum(silu_f(v.x) * w.x + silu_f(v.y) * w.y) + b3[0];
+  const double sx = (double)v.x / (1.0 + exp(-(double)v.x)), sy = (double)v.y / (1.0 + exp(-(double)v.y));
+  const float en = (float)(wave_sum_d(sx * (double)w.x + sy * (double)w.y) + (double)b3[0]);
   if (lane == 0) e_node[node] = en;
 }
 
@@ -591,7 +596,7 @@ __global__ __launch_bounds__(256) void k_rotate_back_reduce(const float* __restr
   // is its rounding error (round 3: no error may be shared by all atoms)
   UMX_WAVE_LOOP(node, nt) {
   const int c0 = lane * 2;
-  float ax[9], ay[9];
+  double ax[9], ay[9];
 #pragma unroll
   for (int r = 0; r < 9; ++r) { ax[r] = 0.f; ay[r] = 0.f; }
   const int e0 = row_ptr[node], e1 = row_ptr[node + 1];
@@ -604,9 +609,16 @@ __global__ __launch_bounds__(256) void k_rotate_back_reduce(const float* __restr
       if (r < NROWS) { const float2 t = *reinterpret_cast<const float2*>(m + r * C); vx[r] = t.x; vy[r] = t.y; }
       else { vx[r] = 0.f; vy[r] = 0.f; }
     }
-    const float sc = f[34] / div;            // a DIVISION by 5 (or 1): 0.2f is not 1/5, and its error would be shared by every atom
-    rot_bwd_acc(f, vx, sc, ax);
-    rot_bwd_acc(f, vy, sc, ay);
+    // the rotated message of this edge in float32, scaled and ACCUMULATED over the incoming edges in double (round 5: a float32 running sum
+    // over ~70 incoming edges is one more coherent 1e-8-level term per atom and layer; the kernel is HBM-bound, the double FMAs are free)
+    float tx[9], ty[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) { tx[r] = 0.f; ty[r] = 0.f; }
+    const double scd = (double)f[34] / (double)div;
+    rot_bwd_acc(f, vx, 1.0f, tx);
+    rot_bwd_acc(f, vy, 1.0f, ty);
+#pragma unroll
+    for (int r = 0; r < 9; ++r) { ax[r] = fma(scd, (double)tx[r], ax[r]); ay[r] = fma(scd, (double)ty[r], ay[r]); }
   }
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
@@ -617,7 +629,7 @@ __global__ __launch_bounds__(256) void k_rotate_back_reduce(const float* __restr
       continue;
     }
     const float2 b = (xin && !emb) ? *reinterpret_cast<const float2*>(xin + node * ROW + r * C + c0) : make_float2(0.f, 0.f);   // null: the bare sum (graph-parallel partial)
-    *reinterpret_cast<float2*>(xout + node * ROW + r * C + c0) = make_float2(b.x + ax[r], b.y + ay[r]);
+    *reinterpret_cast<float2*>(xout + node * ROW + r * C + c0) = make_float2((float)((double)b.x + ax[r]), (float)((double)b.y + ay[r]));
   }
   }
 }

@@ -1,6 +1,9 @@
 """Randomised parity sweep of the default precision mode against the float64 oracle: sizes 2-160, elements up to Z = 53, compressed and
-dilute clusters (down to 0.75 A contacts), charge / spin / task variants, several weight seeds.  Prints the worst errors; exits 1 when a
-case leaves the north-star tolerances (1e-4 eV, 1e-3 eV/A) or when the engine had to widen its operands."""
+dilute clusters (down to 0.75 A contacts), charge / spin / task variants, several weight seeds -- and (round 5) the model variants: the
+grid feed-forward, pos_emb / lin_emb charge-spin embeddings, a dataset list in another order.  Prints the worst errors; exits 1 when a
+case leaves the north-star tolerances (1e-4 eV, 1e-3 eV/A) or when the engine had to widen its operands.
+
+    python3 tools/gpu_fuzz_parity.py [seed] [cases]"""
 import sys, numpy as np
 sys.path.insert(0, ".")
 from pdb2reaction_amd import weights as W, synth
@@ -11,16 +14,20 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 36
 worst_e = worst_f = 0.0
 bad = 0
-for wseed in (0, 3):
-    w = W.make_synthetic_weights(wseed)
+VARIANTS = [(0, {}), (3, {}), (0, dict(ff_type="grid")), (1, dict(ff_type="grid", chg_spin_emb_type="pos_emb", dataset_list=("omol", "omat", "oc20", "odac"))),
+            (2, dict(chg_spin_emb_type="lin_emb"))]
+for wseed, vkw in VARIANTS:
+    w = W.make_synthetic_weights(wseed, **vkw)
     orc = Oracle(w)
     eng = Engine(0); eng.load_weights(w)
-    for case in range(ncase // 2):
+    tasks = list(eng.dataset_list)
+    print(f"# weights seed {wseed}, variant {eng.model_variant()}", flush=True)
+    for case in range(max(ncase // len(VARIANTS), 1)):
         n = int(rng.integers(2, 161))
         z, pos = synth.make_cluster(n, seed=int(rng.integers(1, 10**6)))
         z = rng.choice(np.array([1, 5, 6, 7, 8, 9, 11, 12, 15, 16, 17, 20, 26, 29, 30, 35, 53], dtype=np.int32), size=n)
         pos = pos * rng.uniform(0.7, 1.6)                       # compressed ... dilute (isolated atoms, ragged graphs)
-        charge, spin, task = int(rng.integers(-2, 3)), int(rng.integers(1, 4)), W.DATASET_LIST[int(rng.integers(0, len(W.DATASET_LIST)))]
+        charge, spin, task = int(rng.integers(-2, 3)), int(rng.integers(0 if vkw.get("chg_spin_emb_type") else 1, 4)), tasks[int(rng.integers(0, len(tasks)))]
         p32 = pos.astype(np.float32)
         eng.set_system(z, charge=charge, spin=spin, task=task)
         e, f = eng.energy_forces(p32[None])

@@ -2,7 +2,7 @@
 gain = <a, r> / <r, r> - 1 (a multiplicative bias; float32 storage noise averages out over the ~1e6-1e7 elements of a stage, so
 1e-9 is resolvable), mean signed difference, rms difference.
 
-    python3 tools/gpu_stage_bias.py [n_atoms]   (environment: UMX_PRECISION, UMX_NODE_F64, ...)"""
+    python3 tools/gpu_stage_bias.py [n_atoms] [weights seed]   (environment: UMX_PRECISION, UMX_NODE_F64, ...)"""
 import sys
 
 import numpy as np
@@ -15,7 +15,8 @@ from oracle.staged import Staged  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 torch.set_num_threads(16)
-w = W.make_synthetic_weights(0)
+wseed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+w = W.make_synthetic_weights(wseed)
 z, pos = synth.make_cluster(n)
 pos32 = pos.astype(np.float32)
 st = Staged(w)
@@ -29,7 +30,7 @@ eng.set_system(z)
 eng.debug_keep(True)
 e, _ = eng.energy_forces(pos32, forces=False)
 ne = len(T["src"])
-print(f"mode {eng.precision_mode()}  N = {n}  edges = {ne}   dE = {e[0] - e_ref:+.3e} eV ({(e[0] - e_ref) / n:+.2e} eV/atom)")
+print(f"mode {eng.precision_mode()}  weights seed {wseed}  N = {n}  edges = {ne}   dE = {e[0] - e_ref:+.3e} eV ({(e[0] - e_ref) / n:+.2e} eV/atom)")
 
 
 def cmp(name, ref):

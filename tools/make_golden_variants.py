@@ -2,7 +2,7 @@
 embedding, a checkpoint-ordered dataset list) -- same recipe as tools/make_golden.py: synthetic weights of the variant (seed 0), float32-
 rounded positions, the repo's own CPU restatement ("parity unpinned").  The variant keywords are stored in the fixture (``variant_*``).
 
-    python tools/make_golden_variants.py
+    python tools/make_golden_variants.py [small c2 | c3]
 """
 import sys, time
 import numpy as np, torch
@@ -29,6 +29,11 @@ def run(name, variant, z, imgs, charge=0, spin=1, task="omol", chunked=False):
                         charge=charge, spin=spin, task=task, weights_seed=0, **extra)
 
 
+which = sys.argv[1:] or ["small", "c2"]
+if "c3" in which:            # the headline size with the grid feed-forward: one image of synth.make_images(2000, 16), ~4 min on 8 cores
+    z, imgs, _ = synth.make_images(2000, 16)
+    run("c3_n2000_k1_grid", dict(ff_type="grid"), z, imgs[[5]], chunked=True)
+    sys.exit(0)
 z, imgs, _ = synth.make_images(20, 3, seed=7)
 run("small_n20_k3_grid", dict(ff_type="grid"), z, imgs)
 run("small_n20_charged_grid_pos_emb", dict(ff_type="grid", chg_spin_emb_type="pos_emb", dataset_list=("omol", "omat", "oc20")), z, imgs[:1], charge=-1, spin=2, task="omat")

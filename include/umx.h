@@ -74,17 +74,20 @@ const char* umx_last_error(const umx_engine* eng);
  *   split-bf16 : forward as bf16x3 (6 products), reverse as split (3 products).
  *   fp32       : every GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32).
  * ENERGY ERROR BOUNDS against float64 arithmetic on the same weights (pre-registered here; tests/test_gpu_baseline_sizes.py asserts exactly
- * these on the BASELINE image sizes with several weight sets): UMX_ENERGY_TOL_EV_N(n_atoms) in the default (bf16x3) and fp32 modes,
- * UMX_ENERGY_TOL_EV_FAST_N(n_atoms) in the split modes.  The north-star's 1e-4 eV holds up to 2000 atoms per image (the headline size) /
- * 1000 atoms; beyond that the bound is PER ATOM: the error of a float32-accumulating evaluation against exact arithmetic is systematic --
- * coherent over the edges, because every edge evaluates the same small networks -- at the 1e-8 eV-per-atom level, with sign and size
- * depending on the weight set (round 5, tools/gpu_energy_cuts.py: measured -1.9e-8 ... +3.0e-8 eV per atom in bf16x3 over five weight sets
- * and four 20 000-atom cases; -8.1e-8 ... +2.3e-8 in the fast mode).  Until ABI v9 this header promised 1e-4 eV at every BASELINE size; that
- * held for the one weight set it had been measured on, by cancellation.  A plain float32 evaluation in the reference's op style: 1.2e-7 eV per atom. */
+ * these on the BASELINE image sizes with several weight sets): UMX_ENERGY_TOL_EV_N(n_atoms) in the default (bf16x3), split-bf16 and fp32
+ * modes, UMX_ENERGY_TOL_EV_FAST_N(n_atoms) in the fast mode (split).  The north-star's 1e-4 eV holds up to 10 000 atoms per image (the
+ * headline size is 2000) / 1000 atoms in the fast mode; beyond that the bound is PER ATOM: what is left of the error of a float32-accumulating
+ * evaluation against exact arithmetic is systematic -- coherent over the edges, because every edge evaluates the same small networks.
+ * Round 5 found and removed the two causes that had it at 5e-8 eV per atom (NOTES.md section 11): a bias added to a finished float32 sum
+ * ("grid value + constant": one rounding error for every edge -- the accumulators now START from the bias), and the matrix cores cutting
+ * the 2^-16-order plane products against a large accumulator (they now accumulate apart).  Measured since, four 20 000-atom cases (two
+ * geometries, two weight sets, permuted order): bf16x3 -3e-10 ... -4.8e-9 eV per atom, fp32 -5e-10 ... -1.9e-9, split -3.1e-8 ... +1.6e-8.
+ * Until ABI v9 this header promised 1e-4 eV at every BASELINE size; that held for the one weight set it had been measured on, by
+ * cancellation.  A plain float32 evaluation in the reference's op style: 1.2e-7 eV per atom. */
 #define UMX_ENERGY_TOL_EV 1.0e-4                 /* the north-star tolerance */
 #define UMX_FORCE_TOL_EV_PER_A 1.0e-3
-#define UMX_ENERGY_TOL_EV_N(n_atoms) ((n_atoms) * 5.0e-8 > 1.0e-4 ? (n_atoms) * 5.0e-8 : 1.0e-4)           /* auto / bf16x3 / fp32 */
-#define UMX_ENERGY_TOL_EV_FAST_N(n_atoms) ((n_atoms) * 1.0e-7 > 1.0e-4 ? (n_atoms) * 1.0e-7 : 1.0e-4)      /* split / split-bf16  */
+#define UMX_ENERGY_TOL_EV_N(n_atoms) ((n_atoms) * 1.0e-8 > 1.0e-4 ? (n_atoms) * 1.0e-8 : 1.0e-4)           /* auto / bf16x3 / split-bf16 / fp32 */
+#define UMX_ENERGY_TOL_EV_FAST_N(n_atoms) ((n_atoms) * 1.0e-7 > 1.0e-4 ? (n_atoms) * 1.0e-7 : 1.0e-4)      /* split */
 int umx_load_weights(umx_engine* eng, const void* blob, size_t nbytes);
 
 /* MODEL VARIANTS (ABI v10).  The blob's tensors decide which of the forms SURVEY.md (section 2.4 K8, Appendix A) lists as possible for the

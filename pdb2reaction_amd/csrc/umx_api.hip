@@ -67,6 +67,7 @@ struct umx_engine {
   // operands, pre-split A planes, three-plane PL reverse operands, ring depth 3, two-plane fp16 weights, hardware transcendentals / fp16
   // products inside the fused radial kernels, the side stream, the unfused radial layers, the f16x2b8 mode.  What is left below is what runs.
   std::map<const float*, bool> planes_q;                  // weight plane copies stored in the quad-row layout (else PL)
+  int low_sep = 3;                 // UMX_LOW_SEP (gemm_pl): which forward bf16x3 products chain their 2^-16-order plane products from zero
   float odd_sign = -1.0f;          // sign-alternating operand rows (umx_kernels_pl.h): -1 = on (default), +1 = off (UMX_ALT_ROWS=0, dev A/B)
   int rev_planes = 2;              // bf16 planes of the REVERSE-pass operands: 2 (3 products, 16-bit) or 3 (6 products, 24-bit: UMX_PRECISION=bf16x3)
   int fwd_fmt = 3;                 // forward operand format (QFmt, umx_kernels_pl.h): 1 = two fp16 planes (UMX_PRECISION=split),
@@ -298,6 +299,12 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
   const int bmr = cplx ? 128 : 256;
   const long nM = (M + bmr - 1) / bmr;
   const bool fills = nM * (N / (cplx ? 128 : 256)) >= 256;          // wide grid >= one workgroup per CU
+  // LS: the three plane products of order 2^-16 of a forward bf16x3 GEMM accumulate apart from the large ones (umx_gemm_q.h) -- on every
+  // PLAIN product (radial fc3, conv-1 / conv-2 m = 0: operands with one-signed columns -- SiLU outputs, gated scalars, element embeddings);
+  // the complex m > 0 products take rotated l >= 1 components whose signs follow the edge direction, and measured no different with it
+  // (c5 energy error, three fixtures: none +1.0e-3 eV, fc3 only +5.9e-4, plain -7e-6, all -3e-5; c3 step 497 / 500 / 511 / 522 ms).
+  // UMX_LOW_SEP (dev A/B): 0 none, 1 fc3 only, 2 every forward product, 3 the plain ones (default).
+  const bool ls = fwd && eng->fwd_fmt == 3 && (eng->low_sep == 2 || (eng->low_sep == 3 && !cplx) || (eng->low_sep == 1 && !cplx && K == RH));
   const bool wide = N % (cplx ? 128 : 256) == 0 && fills;
   const int bnc = wide ? (cplx ? 128 : 256) : (cplx ? 64 : 128);
   const long nN = (N + bnc - 1) / bnc;
@@ -334,7 +341,14 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
     if (fwd && eng->fwd_fmt != 3) return fail(eng, UMX_ERR_ARG, "gemm_pl: unknown forward operand format");
     if (!fwd && !eng->rev_qf) return fail(eng, UMX_ERR_ARG, "gemm_pl: quad-row reverse operands exist in the bf16x3 mode only");
     q.lda = (long)a_cols * 3; q.ldb = (long)K * 3;
-    UMX_Q(3, 2, 0, 6, 3, 1);
+    if (!ls) UMX_Q(3, 2, 0, 6, 3, 1);
+    else if (wide) {      // 256 x 256 tiles: one spare accumulator, folded in every k-step
+      if (cplx) hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1, 3, 2, 0, 6, 3, 1, 1>), grid, block, 0, eng->stream, q);
+      else hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 3, 2, 0, 6, 3, 1, 1>), grid, block, 0, eng->stream, q);
+    } else {              // 256 x 128 tiles: a second accumulator set for the whole k loop
+      if (cplx) hipLaunchKernelGGL((umx_gemm_q_kernel<1, 0, 3, 2, 0, 6, 3, 1, 2>), grid, block, 0, eng->stream, q);
+      else hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0, 3, 2, 0, 6, 3, 1, 2>), grid, block, 0, eng->stream, q);
+    }
   } else if (P == 3) {
     // three-plane PL products of the bf16x3 reverse pass: the radial fc3^T of the layers (A = float32 rows, split in registers) and of the
     // edge-degree embedding (A = three PL planes written by k_rotate_back_bwd<3, 3>); both plain, N = 128, 256 x 128 tiles
@@ -988,6 +1002,7 @@ int umx_create(umx_engine** out, int device_ordinal) {
   if (const char* ev = std::getenv("UMX_NODE_F64")) e->node_f64_on = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_GRID_F64")) e->grid_f64 = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("UMX_ALT_ROWS")) e->odd_sign = std::atoi(ev) != 0 ? -1.0f : 1.0f;
+  if (const char* ev = std::getenv("UMX_LOW_SEP")) e->low_sep = std::atoi(ev);
   // stream2 (the second lane) is created with the highest priority (as measured in rounds 3-5; priorities change little on this pool)
   int prio_lo = 0, prio_hi = 0;
   if (hipSetDevice(device_ordinal) != hipSuccess || hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||

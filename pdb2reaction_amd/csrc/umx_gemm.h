@@ -83,12 +83,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[2][2
   } else {
     const long zoffC = (long)blockIdx.z * p.zC, zoffR = (long)blockIdx.z * p.zRes;
     const bool full = ((long)mt * 128 + 128 <= p.M);      // all rows of the block exist; columns are predicated once per lane
-    float bv[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = nt * 128 + wn * 64 + j * 32 + l31;
-      bv[j] = (p.bias && col < p.N && (p.zBl == 0 || blockIdx.z == 0)) ? p.bias[col] : 0.f;
-    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -98,13 +92,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[2][2
         float* c = p.Cp + row0 * p.ldc + p.offC + zoffC + col;
         if (full && col < p.N && EPI == E_BIAS && !p.resid) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) c[(long)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[i][j][r] + bv[j];
+          for (int r = 0; r < 16; ++r) c[(long)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[i][j][r];
         } else if (col < p.N) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const long row = row0 + (r & 3) + 8 * (r >> 2);
             if (row < p.M) {
-              float v = acc[i][j][r] + bv[j];
+              float v = acc[i][j][r];                                  // (the bias is where the accumulator started, below)
               if (p.resid) v += p.resid[row * p.ldres + p.offRes + zoffR + col];
               p.Cp[row * p.ldc + p.offC + zoffC + col] = v;
             }
@@ -169,13 +163,18 @@ __global__ __launch_bounds__(256, 2) void umx_gemm_kernel(const GemmP p) {
     }
   };
 
+  // Real GEMMs start their accumulators FROM the bias: added to the finished sum it would be "float32-grid value + constant", a rounding
+  // error shared by every row (coherent over edges -> an energy error that grows with N; umx_gemm_q.h, NOTES 11).
   f32x16 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < 2; ++j) {
+    const int col = nt * 128 + wn * 64 + j * 32 + l31;
+    const float b0 = (!CPLX && p.bias && col < p.N && (p.zBl == 0 || blockIdx.z == 0)) ? p.bias[col] : 0.f;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = b0;
+  }
 
   int arow[2], brow_l[2];
 #pragma unroll

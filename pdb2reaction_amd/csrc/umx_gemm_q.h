@@ -81,8 +81,10 @@ __host__ __device__ constexpr bool q_use_product(int PA, int PB, int NPROD, int 
 // (bf16x3 / split-bf16: A as float32, AF) and <.., 2, 2, 1, 4, 3> (split: fp16 planes, exact weights); the other forms are gemm_bench's.
 // S = ring stages (2: request tile kt+1 while tile kt is consumed; 3: two tiles in flight -- more tolerant of HBM latency when
 // other kernels load the memory system, at 144 KB of LDS for the wide tile).
-template <int CPLX, int WIDE, int P = 3, int S = 2, int F16 = 0, int NPROD = (P == 3 ? 6 : 3), int PB = P, int AF = 0>
+template <int CPLX, int WIDE, int P = 3, int S = 2, int F16 = 0, int NPROD = (P == 3 ? 6 : 3), int PB = P, int AF = 0, int LS = 0>
 __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
+  static_assert(!LS || (P == 3 && PB == 3 && !F16 && NPROD == 6), "LS: the six-product bf16 form");
+  static_assert(LS != 2 || !WIDE, "LS = 2 (second accumulator set): 256 x 128 tiles only");
   static_assert(!AF || (P == 3 && PB == 3 && F16 == 0), "AF: the six-product bf16 form with A as float32");
   static_assert((P == 3 && PB == 3 && NPROD == 6) || (P == 2 && PB == 2 && (NPROD == 3 || NPROD == 4)) || (P == 2 && PB == 3 && (NPROD == 4 || NPROD == 5)), "plane products");
   constexpr int BM = 256, BN = WIDE ? 256 : 128;
@@ -134,13 +136,35 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
   const int piece = __builtin_amdgcn_readfirstlane(wave * 1024);
   const bool b_tail = __builtin_amdgcn_readfirstlane(wave < 4 ? 1 : 0) != 0;
 
+  // The accumulators START from the bias (real GEMMs; scaled and signed the way the epilogue un-scales them, both exact): a bias added
+  // to the finished float32 sum is "a value on the float32 grid plus a constant", whose rounding error is the SAME for every row whose
+  // result shares a binade -- up to half an ulp per column, coherent over all edges, i.e. an energy error that grows with N (NOTES 11).
+  // Started from the bias, every rounding of the chain sees edge-dependent low bits and the errors are zero-mean.
+  const float cs = F16 ? p.cscale : 1.f;          // a power of two: exact (bf16 planes are unscaled, the multiply folds away)
+  const float cso = p.odd_sign < 0.f ? -cs : cs;  // odd rows: the producer stored them negated (sign-alternating rows, umx_kernels_pl.h); row parity = r & 1
   f32x16 acc[2][TNW];
+  f32x16 low[LS == 2 ? 2 : 1][LS == 2 ? TNW : 1];      // LS = 2 (below)
+  if constexpr (LS == 2) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < TNW; ++j)
+      for (int j = 0; j < TNW; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) low[i][j][r] = 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < TNW; ++j) {
+    float b0 = 0.f;
+    if (!CPLX) {
+      const int col = nt * BN + wn * (32 * TNW) + j * 32 + l31;
+      b0 = (p.bias && col < p.N) ? p.bias[col] / cs : 0.f;
+    }
+    const float b1 = p.odd_sign < 0.f ? -b0 : b0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = (r & 1) ? b1 : b0;
+  }
 
   int a_ad[2][P], b_ad[TNW][PB];       // byte address of this lane's 16-B fragment piece, per plane (chunk = plane * 2 + half, swizzled)
 #pragma unroll
@@ -159,7 +183,7 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
   }
 
   const int nk = p.K / 16;
-  constexpr int TAG = 9000 + S * 100 + P * 10 + CPLX * 2 + WIDE + F16 * 1000 + NPROD * 10000 + PB * 100000 + AF * 10000000;   // one q3_issue instance per kernel
+  constexpr int TAG = 9000 + S * 100 + P * 10 + CPLX * 2 + WIDE + F16 * 1000 + NPROD * 10000 + PB * 100000 + AF * 10000000 + LS * 100000000;   // one q3_issue instance per kernel
   constexpr int GI = JA + JBF;                            // DMA instructions per tile per wave (+1 for the waves that fetch the half round)
 #pragma unroll
   for (int t = 0; t < S - 1; ++t)
@@ -196,6 +220,37 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
     for (int q = 0; q < PB; ++q)
 #pragma unroll
       for (int t = 0; t < TNW; ++t) b[t][q] = *reinterpret_cast<const bf16x8_t*>(sb + b_ad[t][q]);
+    if constexpr (LS == 1) {
+      // LS (round 5): the three plane products of order 2^-16 (a0.b2, a1.b1, a2.b0) accumulate APART from the large ones and join them
+      // through one float32 add.  Why: the 16-bit matrix cores align the 16 products of an MFMA to its largest addend -- the accumulator
+      // -- and drop what falls below ~2^-32 of it.  Products of order 2^-16 of the sum (16-bit significands) lose their last bits
+      // there: a one-sided part (floor; the sign-alternating rows cancel it) AND a part that follows the sign of the product
+      // (profiles/r04_mfma_adder_rounding.txt: all products positive -1.5e-10, all negative +2.2e-10 per MFMA).  Where the columns of A
+      // are one-signed -- fc3's SiLU outputs, gated scalars, element embeddings -- sign(a0.b2) is the sign of the weight's third plane:
+      // the same for every edge, a fixed offset per output column, an energy error that grows with N (tools/gpu_fc3_error_form.py: 835 of
+      // 1536 fc3 columns off by > 4 standard errors, the float32 MFMA: 1; with LS: 67).  Accumulated among themselves these products keep
+      // every bit; the three leading products end at 2^-24 of the sum and were never cut.
+      //   LS = 1 (256 x 256 tiles, 239 VGPRs): one spare accumulator, folded in per tile and k-step (16 v_add_f32 behind an MFMA wait)
+      //   LS = 2 (256 x 128 tiles, 190 VGPRs): a second accumulator set for the whole k loop, folded in once
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+          f32x16 lo = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], lo, 0, 0, 0);
+          lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], lo, 0, 0, 0);
+          lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], lo, 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {      // scalar adds (an opaque asm per element): a vector add would be selected as v_pk_add_f32 (NOTES 5 item 14)
+            float v = lo[r];
+            asm("" : "+v"(v));
+            acc[i][j][r] += v;
+          }
+        }
+    } else
 #pragma unroll
     for (int ord = P + PB - 2; ord >= 0; --ord)   // smallest terms first
 #pragma unroll
@@ -207,15 +262,28 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
 #pragma unroll
           for (int j = 0; j < TNW; ++j) {
             if constexpr (F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a[i][qa]), __builtin_bit_cast(f16x8_t, b[j][qb]), acc[i][j], 0, 0, 0);
-            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][qa], b[j][qb], acc[i][j], 0, 0, 0);
+            else if constexpr (LS == 2) {      // narrow tiles: the 2^-16-order products have accumulators of their own for the whole k loop (64 VGPRs)
+              if (qa + qb == 2) low[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][qa], b[j][qb], low[i][j], 0, 0, 0);
+              else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][qa], b[j][qb], acc[i][j], 0, 0, 0);
+            } else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][qa], b[j][qb], acc[i][j], 0, 0, 0);
           }
       }
+  }
+  if constexpr (LS == 2) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TNW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {        // scalar adds (an opaque asm per element: no v_pk_add_f32, NOTES 5 item 14)
+          float v = low[i][j][r];
+          asm("" : "+v"(v));
+          acc[i][j][r] += v;
+        }
   }
 
   // ---- epilogue (C/D map of 32x32 tiles: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)); block-uniform fast path
   const bool full = ((long)mt * BMR + BMR <= p.M) && (nt * BNC + BNC <= p.N);
-  const float cs = F16 ? p.cscale : 1.f;          // a power of two: exact (bf16 planes are unscaled, the multiply folds away)
-  const float cso = p.odd_sign < 0.f ? -cs : cs;  // odd rows: the producer stored them negated (sign-alternating rows, umx_kernels_pl.h); row parity = r & 1
   if (CPLX) {
 #pragma unroll
     for (int cg = 0; cg < TNW / 2; ++cg) {
@@ -247,17 +315,16 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
 #pragma unroll
       for (int j = 0; j < TNW; ++j) {
         const int col = nt * BN + wn * (32 * TNW) + j * 32 + l31;
-        const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
         const long row0 = (long)mt * BM + wm * 64 + i * 32 + 4 * h;
         float* c = p.Cp + row0 * p.ldc + p.offC + col;
         if (full) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) c[(long)((r & 3) + 8 * (r >> 2)) * p.ldc] = ((r & 1) ? cso : cs) * acc[i][j][r] + bv;
+          for (int r = 0; r < 16; ++r) c[(long)((r & 3) + 8 * (r >> 2)) * p.ldc] = ((r & 1) ? cso : cs) * acc[i][j][r];
         } else if (col < p.N) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int dr = (r & 3) + 8 * (r >> 2);
-            if (row0 + dr < p.M) c[(long)dr * p.ldc] = ((r & 1) ? cso : cs) * acc[i][j][r] + bv;
+            if (row0 + dr < p.M) c[(long)dr * p.ldc] = ((r & 1) ? cso : cs) * acc[i][j][r];
           }
         }
       }

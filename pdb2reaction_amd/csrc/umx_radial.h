@@ -174,13 +174,13 @@ __global__ __launch_bounds__(256, 2) void k_radial_head(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < TR; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[i][r] = bias2;        // the chain STARTS from the bias: added last it is "grid value + constant", one rounding error for every edge (umx_gemm_q.h)
     rad_mma<RH / 8, R_LD, TR>(bufB, W2, acc, l31, h);
     // epilogue 2: fc2 tile + bias to bufA (the gaussian tile is dead: every wave passed the barriers behind fc1)
 #pragma unroll
     for (int i = 0; i < TR; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bufA[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * R_LD + col] = acc[i][r] + bias2;
+      for (int r = 0; r < 16; ++r) bufA[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * R_LD + col] = acc[i][r];
     lds_barrier();
 #pragma unroll 2
     for (int rr = 0; rr < RT / 4; ++rr) {            // h2pre out, LN + SiLU -> the fc3 operand

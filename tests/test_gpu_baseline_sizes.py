@@ -27,11 +27,13 @@ TOL_E = 1e-4   # eV      (BASELINE.json north_star)
 
 
 def energy_tol(n_atoms, mode="auto"):
-    """include/umx.h: UMX_ENERGY_TOL_EV_N(n) = max(1e-4, 5e-8 n) eV in the default (bf16x3) and fp32 modes, UMX_ENERGY_TOL_EV_FAST_N(n) =
-    max(1e-4, 1e-7 n) eV in the split modes -- the north-star's 1e-4 eV up to 2000 / 1000 atoms, a per-atom bound beyond (round 5: the
-    energy error of a float32-accumulating evaluation against exact arithmetic is SYSTEMATIC at the 1e-8 eV-per-atom level, sign and size
-    depending on the weight set: measured -1.9e-8 ... +3.0e-8 eV per atom in bf16x3 over five weight sets and four 20 000-atom cases)."""
-    return max(TOL_E, (1e-7 if mode in ("split", "split-f16", "split-bf16") else 5e-8) * n_atoms)
+    """include/umx.h: UMX_ENERGY_TOL_EV_N(n) = max(1e-4, 1e-8 n) eV in the default (bf16x3), split-bf16 and fp32 modes (the energy is the
+    forward pass: split-bf16 == bf16x3 there), UMX_ENERGY_TOL_EV_FAST_N(n) = max(1e-4, 1e-7 n) eV in the fast mode -- the north-star's 1e-4 eV
+    up to 10 000 / 1000 atoms, a per-atom bound beyond: what is left of the energy error of a float32-accumulating evaluation against exact
+    arithmetic is systematic (coherent over the edges).  Round 5 removed the two causes that had it at 5e-8 eV per atom (bias added to a
+    finished float32 sum; the matrix cores cutting the small plane products against a large accumulator -- NOTES.md section 11); measured
+    since on the four 20 000-atom cases: bf16x3 -3e-10 ... -4.8e-9 eV per atom, fp32 -5e-10 ... -1.9e-9, split -3.1e-8 ... +1.6e-8."""
+    return max(TOL_E, (1e-7 if mode in ("split", "split-f16") else 1e-8) * n_atoms)
 TOL_F = 1e-3   # eV/A
 
 
@@ -221,9 +223,13 @@ def test_c5_energy_and_forces_against_f64_oracle(name, mode, monkeypatch):
     weights the same build gave +1.4e-3 eV (tools/gpu_energy_bias.py, profiles/r05_energy_bias.txt).  tools/gpu_energy_cuts.py (linear
     response of the energy along cuts of the network, float64 oracle gradients) then located coherent terms of +-1...3e-8 eV per atom in
     every float32 RMS norm (cured: the norms, the edge -> node sums and the readout run in double since) and of +-1e-8 eV per atom and layer
-    in every float32-ACCUMULATED GEMM stage -- the radial fc2 / fc3, the SO(2) convolutions -- whose sign depends on the weight set and which
-    higher-precision accumulation alone would remove.  Hence the bound is per atom beyond 2000 atoms: UMX_ENERGY_TOL_EV_N(n) = max(1e-4,
-    5e-8 n) eV (split modes: 1e-7 n), pre-registered in include/umx.h -- against 1.2e-7 eV per atom for a plain float32 evaluation in the
+    in every float32-ACCUMULATED GEMM stage, with TWO causes, both cured: (i) the bias was added to the finished float32 sum -- a value on
+    the float32 grid plus a constant has ONE rounding error for all rows of a binade (tools/cpu_fp32_coherence.py reproduces the GPU's
+    number on the CPU; the accumulators now start from the bias: fp32 mode -3.6e-8 ... +2.1e-8 -> <= 2e-9 eV per atom); (ii) the 16-bit
+    matrix cores cut the 2^-16-order plane products against a large accumulator, with a part that follows the product's sign -- coherent
+    where the operand columns are one-signed (tools/gpu_fc3_error_form.py; those products now accumulate apart: bf16x3 +5e-8 -> <= 5e-9 eV
+    per atom).  The bound is per atom beyond 10 000 atoms: UMX_ENERGY_TOL_EV_N(n) = max(1e-4, 1e-8 n) eV (fast mode: 1e-7 n),
+    pre-registered in include/umx.h -- against 1.2e-7 eV per atom for a plain float32 evaluation in the
     reference's op style.  Forces keep the absolute 1e-3 eV/A at every size (measured 7e-7)."""
     from pdb2reaction_amd.engine import Engine
 
@@ -282,7 +288,7 @@ def test_c5_energy_with_the_atom_order_permuted(weights):
         eng.set_system(g["z"])
         e0, _ = eng.energy_forces(g["pos"][None], forces=False)
         eng.set_system(g["z"][perm])
-        e, f = eng.energy_forces(g["pos"][:, perm])
+        e, f = eng.energy_forces(g["pos"][perm][None])
         de = e[0] - g["energy"][0]
         fb = np.empty_like(f[0])
         fb[perm] = f[0]

@@ -18,6 +18,8 @@ from pdb2reaction_amd.engine import Engine  # noqa: E402
 GOLD = os.path.join("tests", "golden")
 VARIANTS = [{"UMX_PRECISION": "bf16x3"}, {"UMX_PRECISION": "bf16x3", "UMX_ALT_ROWS": "0"}, {"UMX_PRECISION": "split"}, {"UMX_PRECISION": "split", "UMX_ALT_ROWS": "0"},
             {"UMX_PRECISION": "fp32"}, {"UMX_PRECISION": "bf16x3", "UMX_NODE_F64": "0"}]
+if os.environ.get("BIAS_LOW_SEP"):      # the bf16x3 forward products with their 2^-16-order plane products chained from zero: none / fc3 / all
+    VARIANTS = [{"UMX_PRECISION": "bf16x3", "UMX_LOW_SEP": v} for v in os.environ["BIAS_LOW_SEP"].split(",")]
 if os.environ.get("BIAS_ONLY"):          # e.g. BIAS_ONLY=bf16x3: only that mode's variants
     VARIANTS = [v for v in VARIANTS if v["UMX_PRECISION"] in os.environ["BIAS_ONLY"].split(",")]
 FILES = {"c3": "c3c4_n2000.npz", "c5": "c5_n20000.npz", "g1": "c5_n20000_g1.npz", "w1": "c5_n20000_w1.npz", "perm": "c5_n20000.npz"}
@@ -33,7 +35,7 @@ for name in which:
         perm = np.random.default_rng(5).permutation(len(z))
         z, pos, f_ref = z[perm], pos[:, perm], f_ref.reshape(1, len(z), 3)[:, perm]
     for env in VARIANTS:
-        for k in ("UMX_PRECISION", "UMX_NODE_F64", "UMX_ALT_ROWS"):
+        for k in ("UMX_PRECISION", "UMX_NODE_F64", "UMX_ALT_ROWS", "UMX_LOW_SEP"):
             os.environ.pop(k, None)
         os.environ.update(env)
         eng = Engine(0)

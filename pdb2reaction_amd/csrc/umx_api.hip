@@ -305,7 +305,9 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
   // (c5 energy error, three fixtures: none +1.0e-3 eV, fc3 only +5.9e-4, plain -7e-6, all -3e-5; c3 step 497 / 500 / 511 / 522 ms).
   // UMX_LOW_SEP (dev A/B): 0 none, 1 fc3 only, 2 every forward product, 3 the plain ones (default).
   const bool ls = fwd && eng->fwd_fmt == 3 && (eng->low_sep == 2 || (eng->low_sep == 3 && !cplx) || (eng->low_sep == 1 && !cplx && K == RH));
-  const bool wide = N % (cplx ? 128 : 256) == 0 && fills;
+  // (an LS product picks its tile from N alone: the two LS forms fold the small products in at different points, and an image must get the
+  //  same bits whether it is evaluated alone or in a batch -- tests/test_gpu_graph_parallel.py, test_gpu_parity.py batch independence)
+  const bool wide = N % (cplx ? 128 : 256) == 0 && (fills || ls);
   const int bnc = wide ? (cplx ? 128 : 256) : (cplx ? 64 : 128);
   const long nN = (N + bnc - 1) / bnc;
   const dim3 grid((unsigned)(((nM + 7) / 8) * 8 * nN)), block(512);

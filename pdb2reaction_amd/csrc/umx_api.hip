@@ -347,7 +347,8 @@ int gemm_pl(umx_engine* eng, int cplx, int P, const unsigned short* Apl, int a_c
     else if (wide) {      // 256 x 256 tiles: one spare accumulator, folded in every k-step
       if (cplx) hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1, 3, 2, 0, 6, 3, 1, 1>), grid, block, 0, eng->stream, q);
       else hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 3, 2, 0, 6, 3, 1, 1>), grid, block, 0, eng->stream, q);
-    } else {              // 256 x 128 tiles: a second accumulator set for the whole k loop
+    } else {              // 256 x 128 tiles: a second accumulator set for the whole k loop (190 VGPRs: one workgroup per CU instead of two --
+                          // +10 ms at c3 for conv-1 / conv-2 m = 0; deeper rings do not buy it back: S = 3 / 4 measured +5 / +6 ms)
       if (cplx) hipLaunchKernelGGL((umx_gemm_q_kernel<1, 0, 3, 2, 0, 6, 3, 1, 2>), grid, block, 0, eng->stream, q);
       else hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0, 3, 2, 0, 6, 3, 1, 2>), grid, block, 0, eng->stream, q);
     }

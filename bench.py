@@ -21,9 +21,10 @@ Rank 0 prints ONE JSON line (contract in the task statement) carrying
   both passes) are emulation overhead, reported separately as `mfma_pipe_util` (executed FLOPs / peak).
   `traffic` (HBM bytes per launch from rocprofv3 PMC passes) is only emitted when the committed summary under profiles/
   was measured on EXACTLY this build (source digest compiled into libumx.so), else null + `traffic_source` says why;
-* `serial_schedule`: since round 5 the engine runs large batches on TWO LANES (two chunks in flight, the matrix segments of one beside
-  the HBM-bound segments of the other; bitwise the same results).  Kernels of different families then overlap, so "the step is the sum
-  of its families" is measured on a side run with `UMX_STREAMS=1`: per-family times, the HBM regime's remainder, and what the lanes buy;
+* `serial_schedule`: only when the timed region ran on TWO LANES (`UMX_STREAMS=2` / `UMX_LANES_AUTO_EDGES`: two chunks in flight, the
+  matrix segments of one beside the HBM-bound segments of the other; bitwise the same results; off by default since the gain went with
+  the LS forward kernels).  Kernels of different families then overlap, so "the step is the sum of its families" is measured on a side
+  run with `UMX_STREAMS=1`; on the default single lane the families of the timed region itself add up and `roofline.hbm_regime` is theirs;
 * `shard`: what ONE rank of the 8-GPU headline run does per iteration -- the 2-image batch through the same evaluator plus the RCCL
   all-gather of [E | status | F] (a one-rank nccl group here: the collective runs, on this GPU alone) -- driver-timed; the it/s derived
   from it is a PROJECTION, not a measurement;
@@ -418,7 +419,7 @@ def main():
         # second regime: the HBM-bound gather / rotate / gate / segmented-reduce kernels.  Everything outside the two GEMM
         # families is timed as the remainder of the step; the fused radial-MLP kernels (VALU / fp32-MFMA bound, not HBM bound) are timed
         # live as their own family (ABI v7) and taken OUT of the HBM figure, so that `achieved` is not a blend of two bounds.
-        # Two lanes (the engine's choice for large batches since round 5) overlap kernels of different families, so the remainder of the
+        # Two lanes (UMX_STREAMS=2 / UMX_LANES_AUTO_EDGES; not the default) overlap kernels of different families, so the remainder of the
         # step is no longer "the other kernels": the family breakdown comes from a serial-schedule side run (UMX_STREAMS=1) of the same
         # workload, the headline stays what the product does by default.
         two_lanes = lanes_used == 2
@@ -442,13 +443,13 @@ def main():
                                       "radial_ms_per_step": rad_ms, "hbm_regime_ms_per_step": edge_ms, "two_lane_gain_ms": bms - ms,
                                       "gemm_family_tflops": bdom["alg_flops"] / max(bdom["ms"], 1e-9) / 1e9,
                                       "note": "UMX_STREAMS=1 side run of the same workload: one lane, kernels strictly one after another, so the step is the plain sum of its "
-                                              "families (roofline.hbm_regime is taken from it); the headline above is the engine's default schedule (two lanes for this batch size, "
+                                              "families (roofline.hbm_regime is taken from it); the headline above ran on two lanes (requested through the environment; "
                                               "bitwise the same results)"}
         out["roofline"]["lanes"] = lanes_used
         if ser:
             # the timed region ran on two lanes: a GEMM launch there shares the chip with the other lane's HBM-bound kernels and takes longer than alone
             # (that is the price of the overlap; the step is shorter all the same).  Both figures, so that neither hides the other:
-            out["roofline"]["schedule"] = "two lanes (engine default for this batch): per-launch times include the slowdown from co-running HBM-bound kernels"
+            out["roofline"]["schedule"] = "two lanes (requested through UMX_STREAMS / UMX_LANES_AUTO_EDGES): per-launch times include the slowdown from co-running HBM-bound kernels"
             out["roofline"]["serial_schedule_achieved"] = bdom["alg_flops"] / max(bdom["ms"], 1e-9) / 1e9
             out["roofline"]["serial_schedule_frac"] = out["roofline"]["serial_schedule_achieved"] / peak
         hb = {"bound": "hbm", "kernels": "HBM-bound edge / node kernels: k_gather_rotate_mod_q3, k_modrot_bwd_pl, k_gate_edge_*, k_rotate_back_*, norms, graph build "

@@ -186,9 +186,9 @@ int umx_last_graph_stats(const umx_engine* eng, int64_t* n_edges_total, int32_t*
 int umx_last_partitions(const umx_engine* eng);
 
 /* Lanes of the most recent evaluation (ABI v10): 2 = two chunks of images were in flight on two streams, the large-GEMM segments of one
- * beside the HBM-bound segments of the other (the engine's choice for batches of >= 1.2 M directed edges whose largest image fits half the
- * workspace budget; UMX_STREAMS=1 / 2 forces it); results are bitwise those of one lane.  Kernel families then overlap in time, so
- * per-family times no longer add up to the step (bench.py measures them on a UMX_STREAMS=1 side run).                                */
+ * beside the HBM-bound segments of the other (UMX_STREAMS=2, or UMX_LANES_AUTO_EDGES=<n>: for batches of >= n directed edges whose largest
+ * image fits half the workspace budget); default 1.  Results are bitwise those of one lane.  With two lanes kernel families overlap in time,
+ * so per-family times no longer add up to the step (bench.py then measures them on a UMX_STREAMS=1 side run).                           */
 int umx_last_lanes(const umx_engine* eng);
 
 /* Workspace hint (ABI v8): the caller expects batches of up to `n_images` images of the bound system.  The workspace grows with the largest

@@ -79,12 +79,12 @@ struct umx_engine {
                                    // fp32 MFMA instead of the float64-accumulating kernel (k_gemm_f64acc).  Measured (round 3): the fp32-MFMA form of
                                    // these 14 chained GEMMs shifts the energy by a one-signed -2e-8 eV per atom; the double form costs +1 % at c3
   std::map<const float*, float> plane_scale;             // fp16 form: power-of-two scale folded into the weight planes
-  int n_lanes = 0;                 // UMX_STREAMS: 1 = one lane, 2 = two chunks in flight (matrix segments alternating between the lanes), unset / 0 = the
-                                   // engine's choice (round 5): two lanes for batches of >= lanes_auto_edges directed edges whose largest image fits half
-                                   // the workspace budget.  Measured A/B on one box (profiles/r05_lanes_ab.txt): c3 (16 x 2000 atoms, 2.28 M edges) 505.2 ->
-                                   // 499.0 ms, c4 string (24 images) 761.2 -> 751.4 ms, bitwise identical results; the 2-image shard of the 8-GPU run +-0;
-                                   // c2 (366 k edges) +2 %, c1 +25 % -- small batches lose to the halved chunks, hence the threshold
-  long lanes_auto_edges = 1200000; // UMX_LANES_AUTO_EDGES
+  int n_lanes = 0;                 // UMX_STREAMS: 1 / unset = one lane, 2 = two chunks in flight (matrix segments alternating between the lanes; bitwise the
+                                   // same results).  Mid-round 5 the engine chose two lanes by itself for batches of >= 1.2 M directed edges (c3 505.2 ->
+                                   // 499.0 ms, c4 string 761.2 -> 751.4 ms, profiles/r05_lanes_ab.txt); with the LS forward kernels (one workgroup per CU)
+                                   // the gain is gone -- c3 511.1 vs 510.6 ms, c4 string 766.4 vs 773.2 ms, c2 +2 %, c1 +25 % (same file, second part) --
+                                   // so the rule is off by default; UMX_LANES_AUTO_EDGES=<n> turns it back on with that threshold
+  long lanes_auto_edges = 0;       // UMX_LANES_AUTO_EDGES (0 = no automatic choice)
   int stream_cap = 512;            // two-lane mode caps the grids of the grid-stride streaming kernels at this many workgroups (two per CU) so
                                    // that they run BESIDE the other lane's GEMM
   bool throttle = false;           // set while a two-lane evaluation is being issued
@@ -1692,7 +1692,7 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
     }
   }
   int lanes = (eng->n_lanes >= 2 && K >= 2 && !eng->dbg_on && !eng->gp) ? 2 : 1;      // debug captures name ONE chunk's buffers
-  if (eng->n_lanes == 0 && K >= 2 && !eng->dbg_on && !eng->gp && eng->force_parts < 2 && eng->last_edges >= eng->lanes_auto_edges) {
+  if (eng->n_lanes == 0 && K >= 2 && !eng->dbg_on && !eng->gp && eng->force_parts < 2 && eng->lanes_auto_edges > 0 && eng->last_edges >= eng->lanes_auto_edges) {
     long emax = 0;
     for (long k = 0; k < K; ++k) emax = std::max(emax, (long)img_edges[k]);
     if (carve(nullptr, N, emax, nullptr, ws_mode_g(eng)) <= budget / 2) lanes = 2;

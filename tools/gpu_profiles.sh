@@ -10,13 +10,13 @@ mkdir -p $O $P
 cd /tmp && export TMPDIR=/tmp && cd $R
 BENCH="python3 bench.py --no-cpu-baseline --no-fp32-mode --no-fast-mode --no-shard --no-serial --driver string"
 if [ $STEP = all ] || [ $STEP = kt ]; then
-echo "== 1. kernel trace + stats: default mode (bf16x3) on the engine's default schedule (two lanes) AND on one lane, fast mode (split), fp32 mode" &&
+echo "== 1. kernel trace + stats: default mode (bf16x3), fast mode (split), fp32 mode on the default schedule (one lane), and bf16x3 on two lanes" &&
 for M in bf16x3 split fp32; do
   UMX_PRECISION=$M rocprofv3 --kernel-trace --stats -d $O/kt_$M -o kt -f csv -- $BENCH --steps 2 --warmup 1 > $O/kt_$M.log 2>&1 &&
-  ( echo "# UMX_PRECISION=$M rocprofv3 --kernel-trace --stats -- $BENCH --steps 2 --warmup 1  (MI355X, round 5, 3 iterations incl. warm-up; engine default schedule = two lanes at this batch size)"; cat $O/kt_$M/kt_kernel_stats.csv ) > $P/r05_bench_c3_kernel_stats_$M.csv || exit 1
+  ( echo "# UMX_PRECISION=$M rocprofv3 --kernel-trace --stats -- $BENCH --steps 2 --warmup 1  (MI355X, round 5, 3 iterations incl. warm-up; default schedule = one lane)"; cat $O/kt_$M/kt_kernel_stats.csv ) > $P/r05_bench_c3_kernel_stats_$M.csv || exit 1
 done
-UMX_STREAMS=1 rocprofv3 --kernel-trace --stats -d $O/kt_serial -o kt -f csv -- $BENCH --steps 2 --warmup 1 > $O/kt_serial.log 2>&1 &&
-( echo "# UMX_STREAMS=1 rocprofv3 --kernel-trace --stats -- $BENCH --steps 2 --warmup 1  (MI355X, round 5, bf16x3, ONE lane: kernels strictly one after another, 3 iterations incl. warm-up)"; cat $O/kt_serial/kt_kernel_stats.csv ) > $P/r05_bench_c3_kernel_stats_bf16x3_serial.csv || exit 1
+UMX_STREAMS=2 rocprofv3 --kernel-trace --stats -d $O/kt_lanes2 -o kt -f csv -- $BENCH --steps 2 --warmup 1 > $O/kt_lanes2.log 2>&1 &&
+( echo "# UMX_STREAMS=2 rocprofv3 --kernel-trace --stats -- $BENCH --steps 2 --warmup 1  (MI355X, round 5, bf16x3, TWO lanes: the large-GEMM segments of one chunk beside the HBM-bound segments of the other, 3 iterations incl. warm-up)"; cat $O/kt_lanes2/kt_kernel_stats.csv ) > $P/r05_bench_c3_kernel_stats_bf16x3_two_lanes.csv || exit 1
 fi
 if [ $STEP = all ] || [ $STEP = pmc ]; then
 echo "== 2. PMC passes: FETCH_SIZE, WRITE_SIZE (separate, counters only), default mode and fast mode" &&
@@ -34,8 +34,8 @@ python3 tools/gemm_pmc_summary.py $O/g1 $O/g2 $P/r05_gemm_pmc_counters_bf16x3.js
 fi
 if [ $STEP = all ] || [ $STEP = bench ]; then
 echo "== 4. bench line (AFTER the PMC summaries, so that the traffic figure is the one of this very build)" &&
-cp $P/r05_pmc_hbm_traffic_bf16x3.json $P/r05_pmc_hbm_traffic_split.json profiles/ &&
-( /usr/bin/time -f "%e s wall" timeout -k 10 900 python3 bench.py --steps 5 --warmup 2 --driver gsm --gsm-cycles 10 > $O/bench.log 2> $O/bench.err; tail -n 1 $O/bench.err > $P/r05_bench_c3_n1.walltime ) &&
+{ [ ! -f $P/r05_pmc_hbm_traffic_bf16x3.json ] || cp $P/r05_pmc_hbm_traffic_bf16x3.json $P/r05_pmc_hbm_traffic_split.json profiles/; } &&   # (a separate gpurun call: the caller has copied them into profiles/ already)
+( TIMEFORMAT="%R s wall"; { time timeout -k 10 900 python3 bench.py --steps 5 --warmup 2 --driver gsm --gsm-cycles 10 > $O/bench.log 2> $O/bench.err; } 2> $P/r05_bench_c3_n1.walltime ) &&
 grep '^{' $O/bench.log | tail -n 1 > $P/r05_bench_c3_n1.json || exit 1
 fi
 if [ $STEP = all ] || [ $STEP = cfg ]; then

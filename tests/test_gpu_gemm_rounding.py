@@ -1,0 +1,78 @@
+"""Guards for the two rounding traps behind the per-atom energy error that round 5 removed (NOTES.md section 11 item 5).
+
+A rounding error that is the SAME for every edge is an energy error that grows with the number of atoms, however small it is per element.  Both
+traps show up as output COLUMNS of a radial linear whose error has a mean significantly different from zero over the edges:
+
+* fc2 (float32 MFMA in every mode): a bias added to the finished float32 sum is "grid value + constant" -- one rounding error per column and
+  binade.  Measured before: 77 of 128 columns off by more than 4 standard errors of their mean; the accumulators now start from the bias.
+* fc3 (bf16x3: six plane products on the 16-bit matrix cores): the products of order 2^-16 were cut against the large accumulator with a part
+  that follows the product's sign; fc3's activations are SiLU outputs, so that sign is the weight plane's.  Measured before: 835 of 1536 columns
+  (fp32 MFMA: 1); those products now accumulate apart (UMX_LOW_SEP): 67.
+
+The check needs no oracle forward pass: the engine's own captured input of the layer (h1pre / h2pre, float32) goes through LayerNorm + SiLU + the
+linear in float64 on the CPU and is compared with the engine's captured output.  (The float32 LayerNorm / SiLU of the engine is inside the
+difference as zero-mean noise.)"""
+import numpy as np
+import pytest
+import torch
+
+from pdb2reaction_amd import synth, weights as W
+from oracle.staged import ln_silu_fwd
+
+pytestmark = pytest.mark.gpu
+
+N_ATOMS = 700          # 44 k directed edges: a column offset of 2e-9 (what the traps produced) is 4 standard errors
+
+
+def _column_stats(precision, monkeypatch, env=None):
+    from pdb2reaction_amd.engine import Engine
+
+    for k, v in (env or {}).items():
+        monkeypatch.setenv(k, v)
+    w = W.make_synthetic_weights(0)
+    p = {k: torch.as_tensor(np.asarray(v, dtype=np.float64)) for k, v in w.items()}
+    z, pos = synth.make_cluster(N_ATOMS)
+    eng = Engine(0, precision=precision)
+    try:
+        eng.load_weights(w)
+        eng.set_system(z)
+        eng.debug_keep(True)
+        eng.energy_forces(pos.astype(np.float32), forces=False)
+        out = {}
+        for tag, prefix in [("deg", "edge_degree_embedding.rad_func")] + [(str(i), f"blocks.{i}.edge_wise.so2_conv_1.rad_func") for i in range(4)]:
+            h1 = torch.as_tensor(eng.debug_fetch(f"h1pre.{tag}").astype(np.float64)).reshape(-1, W.RADIAL_HIDDEN)
+            h2 = torch.as_tensor(eng.debug_fetch(f"h2pre.{tag}").astype(np.float64)).reshape(-1, W.RADIAL_HIDDEN)
+            ne = h1.shape[0]
+            rad = eng.debug_fetch(f"rad.{tag}").astype(np.float64).reshape(ne, -1)
+            a1 = ln_silu_fwd(h1, p[f"{prefix}.ln1.weight"], p[f"{prefix}.ln1.bias"])
+            d2 = (h2 - (a1 @ p[f"{prefix}.fc2.weight"].T + p[f"{prefix}.fc2.bias"])).numpy()
+            a2 = ln_silu_fwd(h2, p[f"{prefix}.ln2.weight"], p[f"{prefix}.ln2.bias"])
+            d3 = rad - (a2 @ p[f"{prefix}.fc3.weight"].T + p[f"{prefix}.fc3.bias"]).numpy()
+            for name, d in (("fc2", d2), ("fc3", d3)):
+                t = d.mean(0) / (d.std(0) / np.sqrt(ne))
+                out[(name, tag)] = (int((np.abs(t) > 4).sum()), d.shape[1], float(np.abs(d).max()))
+        return out
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+def test_no_coherent_column_offsets_in_the_radial_linears(precision, monkeypatch):
+    stats = _column_stats(precision, monkeypatch)
+    for (name, tag), (n_sig, n_col, dmax) in stats.items():
+        print(f"[{precision}] {name}.{tag}: {n_sig} of {n_col} columns with |mean error| > 4 standard errors; max |error| {dmax:.1e}")
+        assert dmax < 5e-6, (name, tag, dmax)
+        # 4 standard errors by chance: 6e-5 of the columns.  Measured on the final round-5 build: fc2 0 of 128 in every mode (the bias-last
+        # form gave 77), fc3 in fp32 0-2 of 1536, fc3 in bf16x3 58-97 of 1536 and 32 of 384 for the edge-degree MLP (4-8 %: what the LS kernels
+        # leave; one accumulator gave 54-84 %).
+        limit = 3 if (name == "fc2" or precision == "fp32") else 0.12 * n_col
+        assert n_sig <= limit, (name, tag, n_sig, n_col)
+
+
+def test_the_check_sees_the_trap_when_the_small_products_meet_the_accumulator(monkeypatch):
+    """UMX_LOW_SEP=0 (dev A/B): fc3 on the six-product kernels with ONE accumulator -- more than 30 % of its columns are off again, so the test above
+    is able to fail."""
+    stats = _column_stats("bf16x3", monkeypatch, {"UMX_LOW_SEP": "0"})
+    n_sig, n_col, _ = stats[("fc3", "0")]
+    print(f"[bf16x3, UMX_LOW_SEP=0] fc3.0: {n_sig} of {n_col} columns with |mean error| > 4 standard errors")
+    assert n_sig > 0.30 * n_col

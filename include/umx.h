@@ -80,8 +80,9 @@ const char* umx_last_error(const umx_engine* eng);
  * evaluation against exact arithmetic is systematic -- coherent over the edges, because every edge evaluates the same small networks.
  * Round 5 found and removed the two causes that had it at 5e-8 eV per atom (NOTES.md section 11): a bias added to a finished float32 sum
  * ("grid value + constant": one rounding error for every edge -- the accumulators now START from the bias), and the matrix cores cutting
- * the 2^-16-order plane products against a large accumulator (they now accumulate apart).  Measured since, four 20 000-atom cases (two
- * geometries, two weight sets, permuted order): bf16x3 -3e-10 ... -4.8e-9 eV per atom, fp32 -5e-10 ... -1.9e-9, split -3.1e-8 ... +1.6e-8.
+ * the 2^-16-order plane products against a large accumulator (they now accumulate apart); a third site of the first kind, the element-table
+ * add of the radial fc1, no longer reaches the LayerNorm behind it.  Measured since, four 20 000-atom cases (two geometries, two weight
+ * sets, permuted order): bf16x3 -5e-11 ... -8.1e-9 eV per atom, fp32 -4e-10 ... -2.9e-9, split -3.1e-8 ... +1.6e-8.
  * Until ABI v9 this header promised 1e-4 eV at every BASELINE size; that held for the one weight set it had been measured on, by
  * cancellation.  A plain float32 evaluation in the reference's op style: 1.2e-7 eV per atom. */
 #define UMX_ENERGY_TOL_EV 1.0e-4                 /* the north-star tolerance */

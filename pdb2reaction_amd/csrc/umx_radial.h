@@ -45,6 +45,20 @@ __device__ __forceinline__ float2 ln_silu_row(float2 v, float2 ww, float2 bb) {
   const Rstd rstd = rstd_eps(var, LN_EPS);            // compensated sum, in every mode (umx_common.h: `var + 1e-5f` rounds one way)
   return make_float2(r_silu(scale_rstd(v.x, rstd) * ww.x + bb.x), r_silu(scale_rstd(v.y, rstd) * ww.y + bb.y));
 }
+// The same on a row given as hi + lo (lo = what the float32 rounding of the row dropped, |lo| <= ulp(hi) / 2): the mean is taken of both, and the
+// CENTRED value is formed in double before it is rounded -- fc1's row is "float32 MFMA sum + table constant of the element pair", and rounding
+// THAT sum to float32 is one error for every edge of the pair (the "grid value + constant" trap of umx_gemm_q.h: tools/gpu_fc1_table_form.py,
+// +1.0e-6 eV at 700 atoms on one weight set, 6.7 sigma; a CPU emulation reproduces it and shows the unrounded sum clean).  x - mean has the
+// edge's own mean in it, so ITS rounding is not coherent.  The stored h1pre stays the float32 hi (the reverse pass differentiates through it).
+__device__ __forceinline__ float2 ln_silu_row_hl(float2 hi, float2 lo, float2 ww, float2 bb) {
+  const float mu = (wave_sum_dpp(hi.x + hi.y) + wave_sum_dpp(lo.x + lo.y)) * (1.0f / RH);
+  float2 v;
+  v.x = (float)(((double)hi.x - (double)mu) + (double)lo.x);
+  v.y = (float)(((double)hi.y - (double)mu) + (double)lo.y);
+  const float var = wave_sum_dpp(v.x * v.x + v.y * v.y) * (1.0f / RH);
+  const Rstd rstd = rstd_eps(var, LN_EPS);
+  return make_float2(r_silu(scale_rstd(v.x, rstd) * ww.x + bb.x), r_silu(scale_rstd(v.y, rstd) * ww.y + bb.y));
+}
 // backward of it (the arithmetic of k_ln_silu_bwd): go = dE/d(output), v = the pre-LayerNorm row
 __device__ __forceinline__ float2 ln_silu_row_bwd(float2 go, float2 v, float2 ww, float2 bb) {
   const float mu = wave_sum_dpp(v.x + v.y) * (1.0f / RH);
@@ -159,16 +173,20 @@ __global__ __launch_bounds__(256, 2) void k_radial_head(const float* __restrict_
       // edge of that element pair -- a pattern the LayerNorm does not remove, measured as a -2e-8 gain on the radial output
       const double2 a = *reinterpret_cast<const double2*>(ts + (zz & 0xffff) * RH + 2 * lane);
       const double2 b = *reinterpret_cast<const double2*>(tt + (zz >> 16) * RH + 2 * lane);
-      v.x = (float)((double)v.x + (a.x + b.x)); v.y = (float)((double)v.y + (a.y + b.y));
+      const double sx = (double)v.x + (a.x + b.x), sy = (double)v.y + (a.y + b.y);
+      v.x = (float)sx; v.y = (float)sy;
       *reinterpret_cast<float2*>(p) = v;
+      // what the rounding dropped, for the LayerNorm below (bufA: the gaussian tile is dead, every wave is past the barrier behind fc1)
+      *reinterpret_cast<float2*>(bufA + row * R_LD + 2 * lane) = make_float2((float)(sx - (double)v.x), (float)(sy - (double)v.y));
     }
 #pragma unroll 2
     for (int rr = 0; rr < RT / 4; ++rr) {            // pass 1b (same rows, same wave: no barrier): h1pre out (whole 512-B rows), LN + SiLU in place
       const int row = wave * (RT / 4) + rr;
       float* p = bufB + row * R_LD + 2 * lane;
       const float2 v = *reinterpret_cast<const float2*>(p);
+      const float2 vlo = *reinterpret_cast<const float2*>(bufA + row * R_LD + 2 * lane);
       if (e0 + row < ne) *reinterpret_cast<float2*>(h1pre + (e0 + row) * RH + 2 * lane) = v;
-      *reinterpret_cast<float2*>(p) = ln_silu_row(v, l1w, l1b);
+      *reinterpret_cast<float2*>(p) = ln_silu_row_hl(v, vlo, l1w, l1b);
     }
     lds_barrier();
 #pragma unroll

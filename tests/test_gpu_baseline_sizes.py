@@ -32,7 +32,7 @@ def energy_tol(n_atoms, mode="auto"):
     up to 10 000 / 1000 atoms, a per-atom bound beyond: what is left of the energy error of a float32-accumulating evaluation against exact
     arithmetic is systematic (coherent over the edges).  Round 5 removed the two causes that had it at 5e-8 eV per atom (bias added to a
     finished float32 sum; the matrix cores cutting the small plane products against a large accumulator -- NOTES.md section 11); measured
-    since on the four 20 000-atom cases: bf16x3 -3e-10 ... -4.8e-9 eV per atom, fp32 -5e-10 ... -1.9e-9, split -3.1e-8 ... +1.6e-8."""
+    since on the four 20 000-atom cases: bf16x3 -5e-11 ... -8.1e-9 eV per atom, fp32 -4e-10 ... -2.9e-9, split -3.1e-8 ... +1.6e-8."""
     return max(TOL_E, (1e-7 if mode in ("split", "split-f16") else 1e-8) * n_atoms)
 TOL_F = 1e-3   # eV/A
 
@@ -227,8 +227,9 @@ def test_c5_energy_and_forces_against_f64_oracle(name, mode, monkeypatch):
     the float32 grid plus a constant has ONE rounding error for all rows of a binade (tools/cpu_fp32_coherence.py reproduces the GPU's
     number on the CPU; the accumulators now start from the bias: fp32 mode -3.6e-8 ... +2.1e-8 -> <= 2e-9 eV per atom); (ii) the 16-bit
     matrix cores cut the 2^-16-order plane products against a large accumulator, with a part that follows the product's sign -- coherent
-    where the operand columns are one-signed (tools/gpu_fc3_error_form.py; those products now accumulate apart: bf16x3 +5e-8 -> <= 5e-9 eV
-    per atom).  The bound is per atom beyond 10 000 atoms: UMX_ENERGY_TOL_EV_N(n) = max(1e-4, 1e-8 n) eV (fast mode: 1e-7 n),
+    where the operand columns are one-signed (tools/gpu_fc3_error_form.py; those products now accumulate apart: bf16x3 +5e-8 -> <= 8e-9 eV
+    per atom); (iii) the same trap as (i) in the radial fc1 -- float32 sum + element-table constant -- whose rounding no longer reaches the
+    LayerNorm (tools/gpu_fc1_table_form.py).  The bound is per atom beyond 10 000 atoms: UMX_ENERGY_TOL_EV_N(n) = max(1e-4, 1e-8 n) eV (fast mode: 1e-7 n),
     pre-registered in include/umx.h -- against 1.2e-7 eV per atom for a plain float32 evaluation in the
     reference's op style.  Forces keep the absolute 1e-3 eV/A at every size (measured 7e-7)."""
     from pdb2reaction_amd.engine import Engine

@@ -98,7 +98,7 @@ def test_ranks_partition_one_image(oracle, world, n_atoms, precision):
     eng.close()
     # the ORACLE is the yardstick (the mode was only ever compared with the single-engine HIP result)
     e_orc, f_orc = oracle.energy_forces(z, np.asarray(imgs[0], dtype=np.float32).astype(np.float64))
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()   # (never FORK a process that has initialised the GPU: the child dies with "Memory in use")
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _port(), n_atoms, out, precision), nprocs=world, join=True)
     assert sorted(out.keys()) == list(range(world))
@@ -186,7 +186,7 @@ def test_rccl_all_gather_of_the_image_shards():
     """The collective of the image-sharded path: ONE ``all_gather_into_tensor`` of float64 [E | status | F] rows per
     evaluation, here issued by RCCL in a one-rank nccl group (``force_collective``) on the evaluator's device buffers, on torch's current
     stream right behind the engine's kernels -- sync and deferred check; the gathered result must be bitwise the ungathered one."""
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()   # (never FORK a process that has initialised the GPU: the child dies with "Memory in use")
     out = mgr.dict()
     mp.spawn(_nccl_one_rank_gather, args=(_port(), out), nprocs=1, join=True)
     assert out["backend"] == "nccl" and out["sync"] is True and out["deferred"] is True
@@ -198,7 +198,7 @@ def test_rccl_all_reduce_in_place_on_engine_memory():
     one-rank all-reduce is the identity, so the result must stay bitwise the graph-parallel evaluation without the collective (and within
     float32 rounding of the ordinary one, test_world_size_one_matches_the_ordinary_path) -- what this proves is that RCCL
     accepts and orders work on memory it did not allocate, between two engine segments, on real hardware."""
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()   # (never FORK a process that has initialised the GPU: the child dies with "Memory in use")
     out = mgr.dict()
     mp.spawn(_nccl_one_rank, args=(_port(), out), nprocs=1, join=True)
     assert out["backend"] == "nccl" and out["n_exchanges"] == 10 and out["bitwise"] is True and out["close"] is True

@@ -25,7 +25,7 @@ def dependencies() -> list:
     """Every file the library is compiled from: all of csrc/*.h and csrc/*.hip (umx_api.hip includes the headers; a
     hand-kept list once missed the default forward GEMM, so the stale git-ignored .so shipped) plus the ABI header."""
     deps = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip")))
-    deps = [d for d in deps if os.path.basename(d) not in ("gemm_bench.hip", "overlap_bench.hip", "func_bias.hip", "norm_bwd_repro.hip", "corun_probe.hip", "mfma_bias.hip", "mfma_rate.hip", "f8_inner_sum.hip")]     # stand-alone dev benchmarks, not part of the library
+    deps = [d for d in deps if os.path.basename(d) not in ("gemm_bench.hip", "overlap_bench.hip", "func_bias.hip", "norm_bwd_repro.hip", "corun_probe.hip", "mfma_bias.hip", "mfma_probe.hip", "mfma_rate.hip", "f8_inner_sum.hip")]     # stand-alone dev benchmarks, not part of the library
     return deps + [ABI_HEADER]
 
 

@@ -236,13 +236,15 @@ def from_state_dict(state: Mapping[str, object], *, prefix: str = "backbone.", c
                     rename: Optional[Union[Mapping[str, str], Callable[[str], Optional[str]]]] = None,
                     extra: Optional[Mapping[str, object]] = None, strict: bool = True,
                     dataset_list: Optional[Sequence[str]] = None, variant: Optional[Mapping[str, Any]] = None,
-                    task: Optional[str] = None) -> Dict[str, Array]:
+                    task: Optional[str] = None, info: Optional[Dict[str, Any]] = None) -> Dict[str, Array]:
     """Turn a (fairchem-style) state dict into the engine's parameter dict.
 
     1. keys are stripped of ``prefix`` (keys without it are kept as they are); fairchem-style module names are mapped to the engine's
        (:data:`_DEFAULT_RENAMES`; the per-name dataset tables ``dataset_embedding.dataset_emb_dict.<name>.weight`` are stacked into
-       ``dataset_embedding.weight`` in the order of ``dataset_list``; a stacked ``dataset_embedding.weight`` is taken as it is -- its
-       rows then ARE in ``dataset_list`` order; (lat, long, 9) grid matrices are flattened to (G, 9));
+       ``dataset_embedding.weight`` in the order of ``dataset_list`` -- without one, in UMA's own order ``weights.DATASET_LIST`` when
+       the names are exactly those, otherwise refused: an order is never invented; the order actually used is recorded in
+       ``info["dataset_order"]`` and is what ``convert`` writes into the blob trailer; a stacked ``dataset_embedding.weight`` is taken
+       as it is -- its rows then ARE in ``dataset_list`` order; (lat, long, 9) grid matrices are flattened to (G, 9));
     2. ``rename`` (dict or callable returning the new name, or None to drop the key) is applied;
     3. a key ending in ``expert_suffix`` whose tensor has one more dimension than the target is an expert stack: it is merged
        with ``coefficients`` and stored under ``<stem> + merged_suffix``;
@@ -291,11 +293,22 @@ def from_state_dict(state: Mapping[str, object], *, prefix: str = "backbone.", c
     if per_name:
         if "dataset_embedding.weight" in out:
             raise KeyError("dataset embedding given both stacked (dataset_embedding.weight) and per name (dataset_emb_dict.*)")
-        order = list(dataset_list) if dataset_list else sorted(per_name)
+        if dataset_list:
+            order = [str(d) for d in dataset_list]
+        elif set(per_name) == set(W.DATASET_LIST):
+            order = list(W.DATASET_LIST)          # UMA's own task order; never an invented (e.g. alphabetical) one: the engine maps task names through it
+        else:
+            raise KeyError(f"per-name dataset tables {sorted(per_name)} without a dataset_list: the row order of the stacked table cannot be "
+                           f"known (pass dataset_list=... or a model config that has one; UMA's own names are {list(W.DATASET_LIST)})")
         missing_ds = [d for d in order if d not in per_name]
         if missing_ds:
             raise KeyError(f"dataset_list names {missing_ds} have no dataset_embedding.dataset_emb_dict.<name>.weight in the state dict")
+        extra_ds = sorted(d for d in per_name if d not in order)
+        if extra_ds:
+            raise KeyError(f"the state dict carries dataset tables {extra_ds} that dataset_list {order} does not name: refusing to drop them silently")
         out["dataset_embedding.weight"] = np.stack([per_name[d] for d in order])
+        if info is not None:
+            info["dataset_order"] = list(order)
     have = W.variant_of(out)
     if variant:
         for k in ("ff_type", "chg_spin_emb_type"):
@@ -344,6 +357,8 @@ def system_embedding(get: Callable[[str], Array], has: Callable[[str], bool], ch
 
     parts = [cs("charge", charge), cs("spin", spin)]
     if has(_DATASET_DICT + f"{task}.weight"):
+        if task not in dataset_list:          # routing and engine must agree on which tasks exist (the engine maps names through this list)
+            raise ValueError(f"task_name {task!r} not in {tuple(dataset_list)}")
         parts.append(get(_DATASET_DICT + f"{task}.weight").reshape(-1))
     elif has("dataset_embedding.weight"):
         if task not in dataset_list:
@@ -442,19 +457,30 @@ def convert(state: Mapping[str, object], *, merged_for: Optional[Mapping[str, ob
                        "part of the model's answer")
     if kw.get("task") is None and merged_for is not None:
         kw["task"] = dict(merged_for).get("task")
+    if model.get("dataset_list") == []:       # use_dataset_embedding = False: the model has no dataset embedding
+        pfx = kw.get("prefix", "backbone.")
+        tables = sorted(k for k in state if (k[len(pfx):] if pfx and k.startswith(pfx) else k).startswith("dataset_embedding."))
+        if tables:
+            raise UnsupportedCheckpoint(f"the model config says use_dataset_embedding=False but the state dict carries {tables[:3]}"
+                                        f"{' ...' if len(tables) > 3 else ''}: config and tensors disagree")
     kw.setdefault("dataset_list", model.get("dataset_list") or None)
     kw.setdefault("variant", {k: model[k] for k in ENGINE_CHOICES if k in model} or None)
-    params = from_state_dict(state, **kw)
+    info: Dict[str, Any] = {}
+    params = from_state_dict(state, info=info, **kw)
     v = W.variant_of(params)
     model.update(ff_type=v["ff_type"], chg_spin_emb_type=v["chg_spin_emb_type"])
     if v["n_datasets"] == 0:
         model["dataset_list"] = []
-    elif not model.get("dataset_list"):
+    elif info.get("dataset_order"):           # per-name tables: exactly the order they were stacked in
+        model["dataset_list"] = list(info["dataset_order"])
+    elif kw.get("dataset_list") and not model.get("dataset_list"):
+        model["dataset_list"] = [str(d) for d in kw["dataset_list"]]
+    elif not model.get("dataset_list"):       # a stacked table without any list: only UMA's own five rows can be named
         if v["n_datasets"] != len(W.DATASET_LIST):
             raise UnsupportedCheckpoint(f"the dataset embedding has {v['n_datasets']} rows but no dataset_list says which tasks they are "
                                         "(model_config['dataset_list'] or dataset_list=...)")
         model["dataset_list"] = list(W.DATASET_LIST)
-    elif len(model["dataset_list"]) != v["n_datasets"]:
+    if v["n_datasets"] and len(model["dataset_list"]) != v["n_datasets"]:
         raise UnsupportedCheckpoint(f"dataset_list has {len(model['dataset_list'])} names, the dataset embedding {v['n_datasets']} rows")
     meta: Dict[str, Any] = {"model": model}
     if merged_for is not None:

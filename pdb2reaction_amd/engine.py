@@ -173,6 +173,15 @@ class Engine:
         # task names -> rows of dataset_embedding.weight: the checkpoint's own dataset_list when the blob records one (checkpoint.py), else UMA's
         meta = weights.meta if hasattr(weights, "meta") else W.blob_meta(self._blob)
         self.dataset_list = tuple((meta.get("model") or {}).get("dataset_list") or W.DATASET_LIST)
+        # the list must name exactly the rows the blob's dataset embedding has (a re-ordered or shorter table without a trailer would
+        # otherwise map task names to the wrong rows silently); datasets=0: a model without dataset embedding takes any task name
+        try:
+            n_rows = int(self.model_variant().rsplit("datasets=", 1)[1].split(";")[0])
+        except (IndexError, ValueError):
+            n_rows = len(self.dataset_list)
+        if n_rows and n_rows != len(self.dataset_list):
+            raise UmxError(f"the weight blob's dataset embedding has {n_rows} rows but its dataset_list names {len(self.dataset_list)} tasks "
+                           f"{self.dataset_list}: task names cannot be mapped to rows (convert the checkpoint with its dataset_list)")
 
     def model_variant(self) -> str:
         """"ff=spectral|grid(G=..);emb=rand_emb|pos_emb|lin_emb;datasets=N" -- the model variant the loaded blob is (``umx_model_variant``)."""

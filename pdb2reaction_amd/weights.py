@@ -337,10 +337,29 @@ def unpack_blob(blob: bytes) -> "WeightSet":
     return out
 
 
+def _blob_data_end(blob: bytes) -> int:
+    """Offset just behind the tensor data section, computed from the header's entry table (where a JSON trailer starts if there is one)."""
+    if blob[:8] != MAGIC:
+        raise ValueError("not a UMXW0001 weight blob")
+    n, _ = struct.unpack_from("<II", blob, 8)
+    esz = struct.calcsize("<96sI4IQQ")
+    pos = 16 + n * esz
+    data0 = pos + ((-pos) % 64)
+    end = data0
+    for i in range(n):
+        off, nb = struct.unpack_from("<QQ", blob, 16 + i * esz + 96 + 20)
+        end = max(end, data0 + off + nb + ((-nb) % 64))
+    return end
+
+
 def blob_meta(blob: bytes) -> Dict[str, Any]:
-    """The JSON trailer of a blob ({} when it has none) without copying the tensors."""
-    at = blob.rfind(META_MAGIC)
-    if at < 0:
+    """The JSON trailer of a blob ({} when it has none) without copying the tensors.  The trailer is located from the header's tensor
+    extent -- a search for the magic could match bytes inside the tensor data."""
+    try:
+        at = _blob_data_end(blob)
+    except Exception:
+        return {}
+    if blob[at:at + 8] != META_MAGIC:
         return {}
     try:
         (n_js,) = struct.unpack_from("<I", blob, at + 8)

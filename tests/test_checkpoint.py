@@ -268,7 +268,7 @@ def test_model_variants_are_converted_not_refused(variant):
         with pytest.raises(KeyError, match="dumped from the loaded model"):             # never re-derived: must come from the checkpoint
             CK.convert(no_grid, extra=extra, model_config=cfg, task="omol")
         got = CK.from_state_dict(no_grid, extra={**extra, "so3_grid.to_grid_mat": w["so3_grid.to_grid_mat"].reshape(6, 7, 9),
-                                                 "so3_grid.from_grid_mat": w["so3_grid.from_grid_mat"]}, task="omol")
+                                                 "so3_grid.from_grid_mat": w["so3_grid.from_grid_mat"]}, task="omol", dataset_list=dl)
         assert np.array_equal(got["so3_grid.to_grid_mat"], w["so3_grid.to_grid_mat"])
 
 
@@ -298,3 +298,52 @@ def test_mole_routing_sees_the_variant_s_system_embedding():
     want = Oracle(w).system_embedding(-1, 2, "omat").numpy()
     np.testing.assert_allclose(se, want, rtol=1e-13, atol=1e-15)
     assert np.abs(se - CK.system_embedding(lambda n: sd[n], lambda n: n in sd, -1, 0, "omat", dl)).max() > 1e-3       # null spin differs
+
+
+def test_per_name_dataset_tables_keep_their_names():
+    """per-name tables without a dataset_list were stacked alphabetically while the trailer said UMA's order, so
+    'omol' got odac's row.  Row <-> name identity must hold for every way the order can be known, and an unknowable order is refused."""
+    w = W.make_synthetic_weights(0)
+    state = _fairchem_style(w, W.DATASET_LIST)
+    extra = {"normalizer.rmsd": w["normalizer.rmsd"], "element_refs": w["element_refs"]}
+    per_name = {d: state[f"backbone.dataset_embedding.dataset_emb_dict.{d}.weight"].numpy().reshape(-1) for d in W.DATASET_LIST}
+
+    def rows_match(blob):
+        back = W.unpack_blob(blob)
+        names = back.meta["model"]["dataset_list"]
+        assert sorted(names) == sorted(W.DATASET_LIST)
+        for i, d in enumerate(names):
+            assert np.array_equal(back["dataset_embedding.weight"][i], per_name[d].astype(np.float32)), (i, d)
+        return names
+
+    assert rows_match(CK.convert(state, extra=extra, model_config=CK.ASSUME_UMA_S)) == list(W.DATASET_LIST)     # no list: UMA's own order
+    other = ["omc", "omol", "oc20", "odac", "omat"]
+    assert rows_match(CK.convert(state, extra=extra, model_config=CK.ASSUME_UMA_S, dataset_list=other)) == other
+    assert rows_match(CK.convert(state, extra=extra, model_config={**UMA_S_CONFIG, "dataset_list": other, "num_experts": 1})) == other
+    # names the list does not cover are not dropped silently; an unknown name set without a list has no knowable order
+    with pytest.raises(KeyError, match="refusing to drop"):
+        CK.convert(state, extra=extra, model_config=CK.ASSUME_UMA_S, dataset_list=other[:4])
+    renamed = {k.replace(".omc.", ".mine."): v for k, v in state.items()}
+    with pytest.raises(KeyError, match="without a dataset_list"):
+        CK.convert(renamed, extra=extra, model_config=CK.ASSUME_UMA_S)
+    # use_dataset_embedding = False with dataset tables in the state dict: config and tensors disagree
+    with pytest.raises(CK.UnsupportedCheckpoint, match="use_dataset_embedding"):
+        CK.convert(state, extra=extra, model_config={**UMA_S_CONFIG, "use_dataset_embedding": False, "num_experts": 1})
+    # MoLE routing refuses a task the engine's list does not have even when a per-name table for it exists
+    sd = {k[len("backbone."):]: v.double().numpy() for k, v in state.items()}
+    with pytest.raises(ValueError, match="not in"):
+        CK.system_embedding(lambda n: sd[n], lambda n: n in sd, 0, 1, "omc", ("omol", "omat"))
+
+
+def test_blob_trailer_is_located_by_the_header_not_by_search():
+    """the magic of the JSON trailer may occur inside tensor data; the trailer sits behind the header's tensor extent."""
+    w = W.make_synthetic_weights(0)
+    blob = W.pack_blob(w, meta={"model": {"dataset_list": ["omol", "omat", "oc20", "odac", "omc"]}})
+    assert W.blob_meta(blob)["model"]["dataset_list"][1] == "omat"
+    plain = W.pack_blob(dict(w))                 # (a plain dict: no meta, no trailer)
+    assert W.blob_meta(plain) == {} and W.blob_meta(plain + b"junk") == {}
+    poisoned = bytearray(plain)
+    at = len(poisoned) - 4096                    # magic bytes in the middle of the last tensor
+    poisoned[at:at + 8] = W.META_MAGIC
+    assert W.blob_meta(bytes(poisoned)) == {}
+    assert W.blob_meta(bytes(poisoned) + blob[len(plain):])["model"]["dataset_list"][0] == "omol"

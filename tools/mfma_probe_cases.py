@@ -1,0 +1,136 @@
+"""Operand tiles for csrc/mfma_probe.hip (round 6): structured and random cases that pin down HOW the 16-bit matrix cores add.
+
+    python tools/mfma_probe_cases.py gpurun_out/mfma_probe        # writes <dir>/<set>.<kind>.in.bin
+    build/mfma_probe <kind> <set>.<kind>.in.bin <set>.<kind>.out.bin  (on the MI355X; tools/gpu_mfma_probe.sh)
+    python tools/mfma_model.py gpurun_out/mfma_probe               # fits / checks the adder model offline, bit for bit
+
+Sets (each a file of T tiles; one tile = R a-rows x R b-rows -> R*R independent dot products of length K with their own C0):
+  single : ONE non-zero product per dot product, swept from 2^+4 to 2^-44 of |C0| (alignment width, truncation rule, final rounding, ties)
+  pair   : TWO non-zero products (same / different k-halves) with C0 = 0 or large (is the product sum exact before it meets C0?)
+  tiny16 : sixteen products all far below C0 (what survives of many small addends -- the LS question)
+  rand   : sixteen random products, exponents spread over 2^-14 ... 2^0, random C0 scale (model validation)
+  chain  : 6 chained steps of `rand` (the model must compose)
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+
+def to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    u = u + 0x7FFF + ((u >> 16) & 1)
+    return (u >> 16).astype(np.uint16)
+
+
+def from_bf16_bits(b: np.ndarray) -> np.ndarray:
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def to_f16_bits(x: np.ndarray) -> np.ndarray:
+    return np.asarray(x, np.float32).astype(np.float16).view(np.uint16)
+
+
+def rand_sig(rng, shape, bits):
+    """random significand in [1, 2) with `bits` significant bits"""
+    return 1.0 + rng.integers(0, 1 << (bits - 1), size=shape) / float(1 << (bits - 1))
+
+
+def write(path, A, B, C0, kind):
+    T, steps = A.shape[0], A.shape[1]
+    with open(path, "wb") as f:
+        np.array([T, steps], np.int32).tofile(f)
+        if kind == "f32_32":
+            A.astype(np.float32).tofile(f); B.astype(np.float32).tofile(f)
+        elif kind.startswith("f16"):
+            to_f16_bits(A).tofile(f); to_f16_bits(B).tofile(f)
+        else:
+            to_bf16_bits(A).tofile(f); to_bf16_bits(B).tofile(f)
+        C0.astype(np.float32).tofile(f)
+
+
+def make_sets(kind: str, seed: int):
+    rng = np.random.default_rng(seed)
+    R, K = (16, 32) if kind == "bf16_16" else ((32, 2) if kind == "f32_32" else (32, 16))
+    sb = 24 if kind == "f32_32" else (11 if kind.startswith("f16") else 8)          # significand bits of an operand
+    emin_b = -6 if kind.startswith("f16") else -40                                  # keep half operands normal
+    sets = {}
+
+    # ---- single ------------------------------------------------------------------------------------------------------------------
+    T = 400
+    A = np.zeros((T, 1, R, K), np.float32); B = np.zeros((T, 1, R, K), np.float32); C0 = np.zeros((T, R, R), np.float32)
+    for t in range(T):
+        ka = rng.integers(0, K, size=R)                 # a row's k position; the b row must hit the same k: one k per TILE
+        k = int(ka[0])
+        ea = rng.integers(-22, 3, size=R)               # product exponent = ea + eb, swept -44 ... +4 relative to |C0| ~ 1
+        eb = rng.integers(-22, 3, size=R)
+        if kind.startswith("f16"):
+            ea = np.maximum(ea, -13); eb = np.maximum(eb, -13)
+        sa = rand_sig(rng, R, sb) * rng.choice([-1.0, 1.0], size=R)
+        sbv = rand_sig(rng, R, sb) * rng.choice([-1.0, 1.0], size=R)
+        if t % 4 == 0:                                  # power-of-two products: exact ties and half-ulps
+            sa = np.sign(sa); sbv = np.sign(sbv)
+        A[t, 0, :, k] = sa * np.exp2(ea); B[t, 0, :, k] = sbv * np.exp2(eb)
+        c = rand_sig(rng, (R, R), 24) * rng.choice([-1.0, 1.0], size=(R, R))
+        if t % 3 == 0: c = np.sign(c) * 1.0
+        if t % 3 == 1: c = np.sign(c) * (1.0 + np.exp2(-23.0) * rng.integers(0, 4, size=(R, R)))      # odd / even last bits: tie direction
+        C0[t] = c
+    sets["single"] = (A, B, C0)
+
+    # ---- pair --------------------------------------------------------------------------------------------------------------------
+    T = 400
+    A = np.zeros((T, 1, R, K), np.float32); B = np.zeros((T, 1, R, K), np.float32); C0 = np.zeros((T, R, R), np.float32)
+    for t in range(T):
+        k1 = int(rng.integers(0, K)); k2 = int((k1 + rng.integers(1, K)) % K)
+        for k, lo, hi in ((k1, -6, 1), (k2, -20, 1)):
+            ea = rng.integers(lo, hi, size=R); eb = rng.integers(lo, hi, size=R)
+            if kind.startswith("f16"):
+                ea = np.maximum(ea, -13); eb = np.maximum(eb, -13)
+            A[t, 0, :, k] = rand_sig(rng, R, sb) * rng.choice([-1.0, 1.0], size=R) * np.exp2(ea)
+            B[t, 0, :, k] = rand_sig(rng, R, sb) * rng.choice([-1.0, 1.0], size=R) * np.exp2(eb)
+        mode = t % 4
+        if mode == 0: C0[t] = 0.0
+        elif mode == 1: C0[t] = rand_sig(rng, (R, R), 24) * rng.choice([-1.0, 1.0], size=(R, R)) * np.exp2(rng.integers(-30, -10, size=(R, R)))
+        else: C0[t] = rand_sig(rng, (R, R), 24) * rng.choice([-1.0, 1.0], size=(R, R)) * np.exp2(rng.integers(-2, 6, size=(R, R)))
+    sets["pair"] = (A, B, C0)
+
+    # ---- tiny16 ------------------------------------------------------------------------------------------------------------------
+    T = 300
+    ea = rng.integers(-16, -6, size=(T, 1, R, K)); eb = rng.integers(-16, -6, size=(T, 1, R, K))
+    if kind.startswith("f16"):
+        ea = np.maximum(ea, -13); eb = np.maximum(eb, -13)
+    A = (rand_sig(rng, (T, 1, R, K), sb) * rng.choice([-1.0, 1.0], size=(T, 1, R, K)) * np.exp2(ea)).astype(np.float32)
+    B = (rand_sig(rng, (T, 1, R, K), sb) * rng.choice([-1.0, 1.0], size=(T, 1, R, K)) * np.exp2(eb)).astype(np.float32)
+    for t in range(T):
+        if t % 3 == 1: A[t] = np.abs(A[t]); B[t] = np.abs(B[t])             # every product positive
+        if t % 3 == 2: A[t] = -np.abs(A[t]); B[t] = np.abs(B[t])            # every product negative
+    C0 = (rand_sig(rng, (T, R, R), 24) * rng.choice([-1.0, 1.0], size=(T, R, R))).astype(np.float32)
+    sets["tiny16"] = (A, B, C0)
+
+    # ---- rand / chain ------------------------------------------------------------------------------------------------------------
+    for name, T, steps in (("rand", 600, 1), ("chain", 200, 6)):
+        ea = rng.integers(-7, 1, size=(T, steps, R, K)); eb = rng.integers(-7, 1, size=(T, steps, R, K))
+        A = (rand_sig(rng, ea.shape, sb) * rng.choice([-1.0, 1.0], size=ea.shape) * np.exp2(ea)).astype(np.float32)
+        B = (rand_sig(rng, ea.shape, sb) * rng.choice([-1.0, 1.0], size=ea.shape) * np.exp2(eb)).astype(np.float32)
+        C0 = (rand_sig(rng, (T, R, R), 24) * rng.choice([-1.0, 1.0], size=(T, R, R)) * np.exp2(rng.integers(-12, 5, size=(T, R, R)))).astype(np.float32)
+        C0[: T // 6] = 0.0
+        sets[name] = (A, B, C0)
+    return sets
+
+
+KINDS = ("bf16_32", "f16_32", "bf16_16", "f32_32")
+
+
+def main():
+    out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/mfma_probe"
+    os.makedirs(out, exist_ok=True)
+    for i, kind in enumerate(KINDS):
+        for name, (A, B, C0) in make_sets(kind, 100 + i).items():
+            write(os.path.join(out, f"{name}.{kind}.in.bin"), A, B, C0, kind)
+    print("wrote", out)
+
+
+if __name__ == "__main__":
+    main()

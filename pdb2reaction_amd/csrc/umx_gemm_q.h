@@ -81,8 +81,11 @@ __host__ __device__ constexpr bool q_use_product(int PA, int PB, int NPROD, int 
 // (bf16x3 / split-bf16: A as float32, AF) and <.., 2, 2, 1, 4, 3> (split: fp16 planes, exact weights); the other forms are gemm_bench's.
 // S = ring stages (2: request tile kt+1 while tile kt is consumed; 3: two tiles in flight -- more tolerant of HBM latency when
 // other kernels load the memory system, at 144 KB of LDS for the wide tile).
-template <int CPLX, int WIDE, int P = 3, int S = 2, int F16 = 0, int NPROD = (P == 3 ? 6 : 3), int PB = P, int AF = 0, int LS = 0>
+// AL = 1 (AF kernels, forward products): "aligned planes" -- the leading plane of A is quantised to the lane's pass group (qf_align_magic,
+// umx_gemm_pl.h); the weights' leading plane is quantised the same way when the planes are built (umx_api.hip).
+template <int CPLX, int WIDE, int P = 3, int S = 2, int F16 = 0, int NPROD = (P == 3 ? 6 : 3), int PB = P, int AF = 0, int LS = 0, int AL = 0>
 __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
+  static_assert(!AL || AF, "AL: the float32-A kernels");
   static_assert(!LS || (P == 3 && PB == 3 && !F16 && NPROD == 6), "LS: the six-product bf16 form");
   static_assert(LS != 2 || !WIDE, "LS = 2 (second accumulator set): 256 x 128 tiles only");
   static_assert(!AF || (P == 3 && PB == 3 && F16 == 0), "AF: the six-product bf16 form with A as float32");
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
   }
 
   const int nk = p.K / 16;
-  constexpr int TAG = 9000 + S * 100 + P * 10 + CPLX * 2 + WIDE + F16 * 1000 + NPROD * 10000 + PB * 100000 + AF * 10000000 + LS * 100000000;   // one q3_issue instance per kernel
+  constexpr int TAG = 9000 + S * 100 + P * 10 + CPLX * 2 + WIDE + F16 * 1000 + NPROD * 10000 + PB * 100000 + AF * 10000000 + LS * 100000000 + AL * 500000000;   // one q3_issue instance per kernel
   constexpr int GI = JA + JBF;                            // DMA instructions per tile per wave (+1 for the waves that fetch the half round)
 #pragma unroll
   for (int t = 0; t < S - 1; ++t)
@@ -205,8 +208,16 @@ __global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
       for (int t = 0; t < 2; ++t) {
         const f32x4q_t lo = *reinterpret_cast<const f32x4q_t*>(sb + a_ad[t][0]), hi = *reinterpret_cast<const f32x4q_t*>(sb + a_ad[t][1]);
         unsigned int w[3][4];
-        qf_split2(lo[0], lo[1], w[0][0], w[1][0], w[2][0]); qf_split2(lo[2], lo[3], w[0][1], w[1][1], w[2][1]);
-        qf_split2(hi[0], hi[1], w[0][2], w[1][2], w[2][2]); qf_split2(hi[2], hi[3], w[0][3], w[1][3], w[2][3]);
+        if constexpr (AL) {           // the lane's 8 k-values ARE one pass group of this row
+          const float c = qf_align_magic(lo, hi);
+          qf_split2q(lo[0], lo[1], qf_round_q(lo[0], c), qf_round_q(lo[1], c), w[0][0], w[1][0], w[2][0]);
+          qf_split2q(lo[2], lo[3], qf_round_q(lo[2], c), qf_round_q(lo[3], c), w[0][1], w[1][1], w[2][1]);
+          qf_split2q(hi[0], hi[1], qf_round_q(hi[0], c), qf_round_q(hi[1], c), w[0][2], w[1][2], w[2][2]);
+          qf_split2q(hi[2], hi[3], qf_round_q(hi[2], c), qf_round_q(hi[3], c), w[0][3], w[1][3], w[2][3]);
+        } else {
+          qf_split2(lo[0], lo[1], w[0][0], w[1][0], w[2][0]); qf_split2(lo[2], lo[3], w[0][1], w[1][1], w[2][1]);
+          qf_split2(hi[0], hi[1], w[0][2], w[1][2], w[2][2]); qf_split2(hi[2], hi[3], w[0][3], w[1][3], w[2][3]);
+        }
 #pragma unroll
         for (int q = 0; q < 3; ++q) { const u32x4q_t v{w[q][0], w[q][1], w[q][2], w[q][3]}; a[t][q] = __builtin_bit_cast(bf16x8_t, v); }
       }

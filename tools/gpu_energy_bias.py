@@ -22,6 +22,10 @@ if os.environ.get("BIAS_LOW_SEP"):      # the bf16x3 forward products with their
     VARIANTS = [{"UMX_PRECISION": "bf16x3", "UMX_LOW_SEP": v} for v in os.environ["BIAS_LOW_SEP"].split(",")]
 if os.environ.get("BIAS_ONLY"):          # e.g. BIAS_ONLY=bf16x3: only that mode's variants
     VARIANTS = [v for v in VARIANTS if v["UMX_PRECISION"] in os.environ["BIAS_ONLY"].split(",")]
+if os.environ.get("BIAS_ENVS"):          # any list of switch settings: BIAS_ENVS='[{"UMX_PRECISION": "bf16x3", "UMX_ALIGN_PLANES": "0"}, ...]'
+    import json
+    VARIANTS = [{"UMX_PRECISION": "bf16x3", **{str(k): str(v) for k, v in e.items()}} for e in json.loads(os.environ["BIAS_ENVS"])]
+SWITCHES = sorted({k for v in VARIANTS for k in v} | {"UMX_PRECISION", "UMX_NODE_F64", "UMX_ALT_ROWS", "UMX_LOW_SEP", "UMX_ALIGN_PLANES"})
 FILES = {"c3": "c3c4_n2000.npz", "c5": "c5_n20000.npz", "g1": "c5_n20000_g1.npz", "w1": "c5_n20000_w1.npz", "perm": "c5_n20000.npz"}
 which = sys.argv[1:] or ["c3", "c5"]
 for name in which:
@@ -35,7 +39,7 @@ for name in which:
         perm = np.random.default_rng(5).permutation(len(z))
         z, pos, f_ref = z[perm], pos[:, perm], f_ref.reshape(1, len(z), 3)[:, perm]
     for env in VARIANTS:
-        for k in ("UMX_PRECISION", "UMX_NODE_F64", "UMX_ALT_ROWS", "UMX_LOW_SEP"):
+        for k in SWITCHES:
             os.environ.pop(k, None)
         os.environ.update(env)
         eng = Engine(0)

@@ -276,7 +276,18 @@ def main():
             ev(xt)
         fence()
         res["evaluation_only_ms"] = (time.perf_counter() - t0) / cycles * 1e3
-        for leg, gs_kw in (("climb_off", {"climb": False}), ("climb_on", {"climb": True, "climb_rms": 1e9, "climb_lanczos": False})):
+        # single-image evaluation (what one step of the Lanczos recursion costs: gsm._single_forces)
+        for _ in range(2):
+            ev(xt[:1])
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(6):
+            ev(xt[:1])
+        fence()
+        res["single_image_ms"] = (time.perf_counter() - t0) / 6 * 1e3
+        lz = {"climb": True, "climb_rms": 1e9, "climb_lanczos": True, "climb_lanczos_rms": 1e9}       # the reference's defaults (path_opt.py:179-182), thresholds forced so that the phase runs
+        for leg, gs_kw in (("climb_off", {"climb": False}), ("climb_on", {"climb": True, "climb_rms": 1e9, "climb_lanczos": False}),
+                           ("climb_lanczos_cold", {**lz, "climb_lanczos_warm_start": False}), ("climb_lanczos", lz)):
             drv = GrowingStringDriver(elem, x0[0], x0[-1], evaluate_device=ev, device=dev, images=x0,
                                       gs_kw={"max_nodes": k - 2, "fix_first": False, "fix_last": False, **gs_kw},
                                       stopt_kw={"max_cycles": cycles + warmup, "thresh": "gau_vtight", "max_step": 0.1, "print_every": 10 ** 9})
@@ -298,9 +309,22 @@ def main():
             span = (marks[-1] - marks[warmup]) / max(len(marks) - 1 - warmup, 1)
             res[leg] = {"cycle_ms": span * 1e3, "cycles_timed": len(marks) - 1 - warmup, "redo_steps": out.timing["redo_steps"],
                         "fully_grown": bool(out.fully_grown), "images": int(len(out.coords)), "t_end_minus_last_mark_ms": (t_end - marks[-1]) * 1e3}
+            if gs_kw.get("climb_lanczos"):
+                calls = max(out.timing["lanczos_calls"], 1.0)
+                res[leg].update({"lanczos_evals": int(out.timing["lanczos_evals"]), "lanczos_recursions": int(out.timing["lanczos_calls"]),
+                                 "lanczos_evals_per_cycle": out.timing["lanczos_evals"] / calls, "warm_kept": int(out.timing["lanczos_warm_calls"]),
+                                 "warm_rejected": int(out.timing["lanczos_warm_rejected"]), "cycles_run": int(out.cycles)})
         ev.flush()
         eng.close()
         shard_ms = res["evaluation_only_ms"] / 8.0
+        for leg in ("climb_lanczos_cold", "climb_lanczos"):
+            r_ = res[leg]
+            # what the serial single-image probes add: on one GPU (measured: cycle_ms), and PROJECTED for one rank of the 8-GPU run -- the probes on
+            # one rank while seven wait (gp_singles=False), or graph-parallel over the eight ranks (parallel.EngineStringEvaluator, the default;
+            # its 10 all-reduces per probe cannot be timed on one GPU)
+            r_["serial_probe_ms_per_cycle"] = r_["lanczos_evals_per_cycle"] * res["single_image_ms"]
+            r_["projected_8gpu_cycle_ms_probes_on_one_rank"] = shard_ms + r_["serial_probe_ms_per_cycle"]
+            r_["projected_8gpu_cycle_ms_probes_graph_parallel_compute_only"] = shard_ms + r_["serial_probe_ms_per_cycle"] / 8.0
         for leg in ("climb_off", "climb_on"):
             ov = res[leg]["cycle_ms"] - res["evaluation_only_ms"]
             res[leg]["driver_overhead_ms"] = ov
@@ -309,7 +333,10 @@ def main():
         res["note"] = ("gsm.GrowingStringDriver (device resident: tangents, projection, L-BFGS, reparametrisation as torch ops on the GPU, one read of "
                        "2K+8 doubles per cycle) on the fully grown string through parallel.EngineStringEvaluator; evaluation_only = the same batches "
                        "through the evaluator alone; driver_overhead = cycle - evaluation_only; overhead_vs_2_image_shard = overhead / (evaluation_only / 8), "
-                       "the share it would have of a cycle of the 8-GPU run (the string update is replicated on every rank)")
+                       "the share it would have of a cycle of the 8-GPU run (the string update is replicated on every rank).  climb_lanczos(_cold): the "
+                       "reference's DEFAULT climbing phase (climb=True, climb_lanczos=True, path_opt.py:179-182; thresholds forced so that it runs on the "
+                       "synthetic string): every cycle adds a Lanczos recursion of serial single-image gradients -- started from the string tangent (cold) "
+                       "or, guarded, from last cycle's mode (the default); projected_* are PROJECTIONS from shard = evaluation_only / 8")
         return res
 
     def run_hessian(precision: str, sample_atoms: int):

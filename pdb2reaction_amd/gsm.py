@@ -241,7 +241,7 @@ def _place(x: np.ndarray, targets: np.ndarray) -> np.ndarray:
 
 
 def lanczos_lowest_mode_t(grad_fn: Callable[[torch.Tensor], torch.Tensor], x: torch.Tensor, g0: torch.Tensor, guess: torch.Tensor, *,
-                          dx: float = 5e-3, dl: float = 1e-2, max_cycles: int = 25) -> Tuple[float, torch.Tensor, int]:
+                          dx: float = 5e-3, dl: float = 1e-2, max_cycles: int = 25, orient: Optional[torch.Tensor] = None) -> Tuple[float, torch.Tensor, int]:
     """Lowest Hessian eigenpair at x from a Lanczos recursion on forward-difference Hessian-vector products
     H q ~ (g(x + dx q) - g(x)) / dx; one gradient per step, started from `guess` (the string tangent).  Vectors stay on x's device;
     the recursion coefficients (two scalars per step) come to the host, where the small tridiagonal eigenproblem is solved --
@@ -249,7 +249,7 @@ def lanczos_lowest_mode_t(grad_fn: Callable[[torch.Tensor], torch.Tensor], x: to
 
     Returns (eigenvalue, unit eigenvector, gradient evaluations).  Stops when the lowest Ritz value changes by less than
     `dl` (relative) between two steps, when the Krylov space is exhausted, or after `max_cycles` steps.  The vector is
-    oriented along `guess`."""
+    oriented along `orient` (default: `guess`) -- a warm start passes last cycle's mode as `guess` and the string tangent as `orient`."""
     n = x.numel()
     x = x.reshape(-1)
     guess = guess.reshape(-1).to(x.dtype)
@@ -289,7 +289,7 @@ def lanczos_lowest_mode_t(grad_fn: Callable[[torch.Tensor], torch.Tensor], x: to
         w_prev, q_prev = w_min, q
         betas.append(beta)
     v_min = v_min / v_min.norm().clamp_min(1e-30)
-    if float(v_min @ guess) < 0.0:
+    if float(v_min @ (guess if orient is None else orient.reshape(-1).to(x.dtype))) < 0.0:
         v_min = -v_min
     return w_min, v_min, steps
 
@@ -355,6 +355,11 @@ class GrowingStringDriver:
         self._f: Optional[torch.Tensor] = None
         self.n_eval = 0
         self.lanczos_evals = 0
+        self.lanczos_calls = 0                               # Lanczos recursions run (one per climbing cycle below climb_lanczos_rms)
+        self.lanczos_warm_calls = 0                          # ... of which started from the previous cycle's mode (and were kept)
+        self.lanczos_warm_rejected = 0                       # warm recursions whose result failed the guard (a cold one followed)
+        # (HEI index, images, unit vector) of the most recent trusted Lanczos mode: the next cycle's recursion starts from it (see run())
+        self._lanczos_prev: Optional[Tuple[int, int, torch.Tensor]] = None
         self.tangent_kind = str(self.gs.get("tangent", "spline"))
         self._hist_s: Optional[torch.Tensor] = None          # (m, n) rows oldest -> newest
         self._hist_y: Optional[torch.Tensor] = None
@@ -479,6 +484,7 @@ class GrowingStringDriver:
     def _reset_history(self):
         self._hist_s = self._hist_y = None
         self._prev = None
+        self._lanczos_prev = None
 
     # ---- one optimistic step on the device -----------------------------------------------------------
     def _device_cycle(self, moving_idx: torch.Tensor, moving_mask: torch.Tensor, climbing: bool, full: bool,
@@ -591,8 +597,31 @@ class GrowingStringDriver:
                         again = True
                     if climbing and 0 < hei < k - 1 and gs["climb_lanczos"] and rms_all <= gs["climb_lanczos_rms"]:
                         # lowest-curvature direction at the HEI instead of the string tangent (reference GS_KW climb_lanczos)
-                        _, lanczos_t, n_l = lanczos_lowest_mode_t(lambda xq: -self._single_forces(xq), self._x[hei], -self._f[hei], t_dev[hei])
-                        self.lanczos_evals += n_l
+                        # Start vector.  Cold: the string tangent (what a first recursion has).  Warm (gs_kw["climb_lanczos_warm_start"], default
+                        # True): last cycle's mode -- the HEI moves by at most max_step per cycle, so it is an almost converged start vector and
+                        # the recursion (same dl, same max_cycles, same Ritz-value stop rule) needs its minimum of two gradients instead of
+                        # 3-25: the SERIAL single-image depth of the reference's default climbing phase (path_opt.py:179-182).  Guarded: a
+                        # recursion started from a near-eigenvector spans a tiny Krylov space and would follow that eigenvector wherever it
+                        # goes, so the warm result is only kept while it still describes the reaction mode -- negative curvature and an
+                        # overlap of at least `climb_lanczos_warm_overlap` (0.5) with the string tangent; otherwise this cycle pays for a cold
+                        # recursion as well.
+                        t_hei = t_dev[hei] / t_dev[hei].norm().clamp_min(1e-30)
+                        lp = self._lanczos_prev
+                        grad_fn = lambda xq: -self._single_forces(xq)                      # noqa: E731
+                        warm = bool(gs.get("climb_lanczos_warm_start", True)) and lp is not None and lp[0] == hei and lp[1] == k
+                        done = False
+                        if warm:
+                            w_l, lanczos_t, n_l = lanczos_lowest_mode_t(grad_fn, self._x[hei], -self._f[hei], lp[2], orient=t_hei)
+                            self.lanczos_evals += n_l
+                            done = w_l < 0.0 and float(lanczos_t @ t_hei) >= float(gs.get("climb_lanczos_warm_overlap", 0.5))
+                            self.lanczos_warm_calls += int(done)
+                            self.lanczos_warm_rejected += int(not done)
+                        if not done:
+                            w_l, lanczos_t, n_l = lanczos_lowest_mode_t(grad_fn, self._x[hei], -self._f[hei], t_hei)
+                            self.lanczos_evals += n_l
+                        # only a mode that can be trusted next cycle is remembered
+                        self._lanczos_prev = (hei, k, lanczos_t) if (w_l < 0.0 and float(lanczos_t @ t_hei) >= float(gs.get("climb_lanczos_warm_overlap", 0.5))) else None
+                        self.lanczos_calls += 1
                         again = True
                 if not again and pair is not None and not (sy > 1e-12):
                     offer_pair, again = False, True                # curvature pair rejected: rebuild the direction without it
@@ -653,4 +682,6 @@ class GrowingStringDriver:
         return GSMResult(coords=self.coords, energies=e_out, converged=converged, cycles=cycle, fully_grown=self.fully_grown,
                          hei_index=select_hei_index(e_out), force_evaluations=self.n_eval, history=history,
                          timing={"total_s": t_total, "evaluator_s": self.t_eval, "host_s": t_total - self.t_eval,
-                                 "redo_steps": float(self.redo_steps)})
+                                 "redo_steps": float(self.redo_steps), "lanczos_evals": float(self.lanczos_evals),
+                                 "lanczos_calls": float(self.lanczos_calls), "lanczos_warm_calls": float(self.lanczos_warm_calls),
+                                 "lanczos_warm_rejected": float(self.lanczos_warm_rejected)})

@@ -271,7 +271,11 @@ class EngineStringEvaluator(ShardedStringEvaluator):
     size, since a growing string changes k)."""
 
     def __init__(self, engine, n_atoms: int, device: torch.device, frozen: Sequence[int] = (), group: Optional["dist.ProcessGroup"] = None,
-                 check: str = "sync", max_images: int = 0, force_collective: bool = False):
+                 check: str = "sync", max_images: int = 0, force_collective: bool = False, gp_singles: bool = True):
+        """gp_singles: with more than one rank, a ONE-image batch (the serial probes of the climbing image's Lanczos recursion,
+        ``gsm._single_forces``; reference ``GS_KW["climb_lanczos"]``, ``path_opt.py:181-182``) is evaluated GRAPH-PARALLEL over all ranks
+        (:class:`GraphParallelEvaluator`: the image's edges partitioned by target node, 10 all-reduces) instead of on rank 0 while the
+        others wait in the all-gather -- every rank calls the evaluator with the same geometry anyway (SPMD driver)."""
         from ._calculator_base import BOHR2ANG
         from .hessian import EV_PER_ANG_TO_AU, EV_TO_HARTREE
 
@@ -280,6 +284,11 @@ class EngineStringEvaluator(ShardedStringEvaluator):
         self._frozen = torch.as_tensor(sorted(set(int(i) for i in frozen)), dtype=torch.long, device=device)
         self._cap = 0
         self._pos32 = self._e = self._f = None
+        initialised = dist.is_available() and dist.is_initialized()
+        self._world = dist.get_world_size(group) if initialised else 1
+        self._gp_singles = bool(gp_singles) and self._world > 1
+        self._gp: Optional[GraphParallelEvaluator] = None
+        self.gp_single_calls = 0
         if max_images:
             self._reserve(int(max_images))
             engine.reserve_images(int(max_images))
@@ -290,6 +299,19 @@ class EngineStringEvaluator(ShardedStringEvaluator):
             self._e = torch.empty(k, dtype=torch.float64, device=self.device)
             self._f = torch.empty(k, self.n_atoms, 3, dtype=torch.float32, device=self.device)
             self._cap = k
+
+    def __call__(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._gp_singles and x.shape[0] == 1:
+            if self._gp is None:
+                self._gp = GraphParallelEvaluator(self.engine, self.n_atoms, self.device, group=self.group)
+            self.flush()                                                             # a deferred flag of the batched calls is read before the mode changes
+            e, f = self._gp((x.reshape(self.n_atoms, 3) * self._b2a).to(torch.float32))
+            self.gp_single_calls += 1
+            f = f.to(torch.float64) * self._f2au
+            if self._frozen.numel():
+                f[self._frozen, :] = 0.0
+            return e.to(torch.float64) * self._e2h, f.reshape(1, -1)
+        return super().__call__(x)
 
     def _local(self, c_bohr: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         kl = c_bohr.shape[0]

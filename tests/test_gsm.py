@@ -255,3 +255,75 @@ def test_unimplemented_keywords_are_refused_or_warned_about():
     with _w.catch_warnings():
         _w.simplefilter("error")                                           # the reference's own defaults pass without a word
         GrowingStringDriver(["X"], MIN_A, MIN_B, calc, gs_kw=dict(GS_KW), stopt_kw=dict(STOPT_KW), geom_kw={"coord_type": "cart", "freeze_atoms": []})
+
+
+class MuellerBrown24:
+    """8 'atoms' x 3 = 24 coordinates: the Mueller-Brown surface in a rotated plane + a harmonic bath (k = 0.3 ... 1.5) weakly coupled to it --
+    a Hessian with a spread spectrum, so that the Krylov space of a Lanczos recursion is not exhausted after two steps."""
+
+    def __init__(self):
+        rng = np.random.default_rng(11)
+        self.q, _ = np.linalg.qr(rng.standard_normal((24, 24)))
+        self.k = np.linspace(0.3, 1.5, 22)
+        self.cpl = 0.02
+        self.batches = []
+
+    def get_forces_batch(self, atoms, coords):
+        xx = np.asarray(coords, dtype=float).reshape(len(coords), 24)
+        self.batches.append(len(xx))
+        u = xx @ self.q
+        x, y, bth = u[:, 0:1], u[:, 1:2], u[:, 2:]
+        dx, dy = x - X0, y - Y0
+        t = A * np.exp(a * dx ** 2 + b * dx * dy + c * dy ** 2)
+        e = SCALE * t.sum(1) + 0.5 * (self.k * bth ** 2).sum(1) + self.cpl * (y * bth).sum(1)
+        gx = SCALE * (t * (2 * a * dx + b * dy)).sum(1)
+        gy = SCALE * (t * (b * dx + 2 * c * dy)).sum(1) + self.cpl * bth.sum(1)
+        gb = self.k * bth + self.cpl * y
+        g = np.concatenate([gx[:, None], gy[:, None], gb], axis=1) @ self.q.T
+        return {"energy": e, "forces": -g}
+
+
+def _run_mb24(warm):
+    calc = MuellerBrown24()
+    r = np.zeros(24); r[:2] = MIN_A[:2]
+    p = np.zeros(24); p[:2] = MIN_B[:2]
+    drv = GrowingStringDriver(["X"] * 8, r @ calc.q.T, p @ calc.q.T, calc,
+                              gs_kw={"max_nodes": 9, "perp_thresh": 2e-2, "climb_rms": 5e-3, "climb_lanczos_rms": 5e-3, "climb_lanczos_warm_start": warm},
+                              stopt_kw={"thresh": "gau_loose", "max_step": 0.05, "max_cycles": 900, "stop_in_when_full": 800})
+    return drv, drv.run(), calc
+
+
+def test_lanczos_warm_start_cuts_the_serial_depth_not_the_answer():
+    """once the string climbs, every cycle runs a Lanczos recursion of SERIAL single-image gradients (reference defaults
+    climb_lanczos=True, path_opt.py:179-182).  Started from last cycle's mode instead of the string tangent, the recursion keeps its stop rule
+    (dl, max_cycles) and needs its minimum of two gradients per cycle; the guarded result (negative curvature, overlap with the tangent) leaves
+    the optimisation where the cold recursion takes it."""
+    cold_drv, cold, cold_calc = _run_mb24(False)
+    warm_drv, warm, warm_calc = _run_mb24(True)
+    assert cold.converged and warm.converged and cold.fully_grown and warm.fully_grown
+    for drv, res, calc in ((cold_drv, cold, cold_calc), (warm_drv, warm, warm_calc)):
+        assert drv.lanczos_calls >= 10 and res.timing["lanczos_evals"] == drv.lanczos_evals == calc.batches.count(1)
+    per_cold, per_warm = cold_drv.lanczos_evals / cold_drv.lanczos_calls, warm_drv.lanczos_evals / warm_drv.lanczos_calls
+    print(f"Lanczos gradients per climbing cycle: cold {per_cold:.2f} ({cold_drv.lanczos_calls} recursions), warm {per_warm:.2f} "
+          f"({warm_drv.lanczos_warm_calls} kept, {warm_drv.lanczos_warm_rejected} rejected)")
+    assert cold_drv.lanczos_warm_calls == 0 and per_cold >= 2.8
+    assert warm_drv.lanczos_warm_calls >= warm_drv.lanczos_calls - 2 and per_warm <= 2.4
+    assert abs(warm.energies[warm.hei_index] - cold.energies[cold.hei_index]) < 1e-6 and warm.hei_index == cold.hei_index
+    assert np.abs(warm.coords - cold.coords).max() < 2e-3
+    assert abs(warm.cycles - cold.cycles) <= 5
+
+
+def test_lanczos_warm_start_is_dropped_when_the_mode_leaves_the_path():
+    """The guard: a warm-started recursion spans a tiny Krylov space and follows its eigenvector wherever it goes; a result with positive curvature
+    or little overlap with the string tangent is rejected, the cold recursion runs, and nothing is remembered for the next cycle."""
+    calc = MuellerBrown24()
+    r = np.zeros(24); r[:2] = MIN_A[:2]
+    p = np.zeros(24); p[:2] = MIN_B[:2]
+    # climbing forced from the first fully grown cycle on: the HEI is far from the saddle, where the lowest mode is a soft bath direction
+    drv = GrowingStringDriver(["X"] * 8, r @ calc.q.T, p @ calc.q.T, calc,
+                              gs_kw={"max_nodes": 9, "perp_thresh": 1e9, "climb_rms": 1e9, "climb_lanczos_rms": 1e9},
+                              stopt_kw={"thresh": "gau_loose", "max_step": 0.05, "max_cycles": 40})
+    res = drv.run()
+    assert drv.lanczos_calls > 10
+    assert drv.lanczos_warm_calls + drv.lanczos_warm_rejected <= drv.lanczos_calls
+    assert np.isfinite(res.energies).all() and np.abs(res.coords).max() < 10.0          # the string did not run away along a bath mode

@@ -24,6 +24,7 @@ wseed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ncol = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 only = sys.argv[4].split(",") if len(sys.argv) > 4 and sys.argv[4] != "all" else None
 quick = len(sys.argv) > 5 and sys.argv[5] == "quick"
+plain_abl = len(sys.argv) > 5 and sys.argv[5] == "plain"
 torch.set_num_threads(8)
 w = W.make_synthetic_weights(wseed)
 z, pos = synth.make_cluster(n)
@@ -71,6 +72,8 @@ for name, A, Wt, bias, g in sites():
     runs += [("ls2", 0, 12, 12), ("ls2", 0, 12, 0), ("ls2", 0, 0, 12), ("ls1", 0, 12, 12), ("plain", 0, 12, 12), ("ls2", 0, 11, 11), ("ls2", 0, 13, 11)]     # aligned planes: leading-plane quantum 2^(e_max - da) / 2^(e_max - dw)
     if quick:
         runs = [r for r in runs if r[1] in (0, 1)]
+    if plain_abl:             # which cut makes the one-accumulator scheme's column offsets?
+        runs = [("ls2", 0, 12, 12)] + [("plain", ab, 12, 12) for ab in (0, 1, 2, 4, 8, 6, 14)]
     for sch, ab, da, dw in runs:
         abl.value = ab
         dem_a.value, dem_w.value = da, dw

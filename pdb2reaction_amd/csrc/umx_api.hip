@@ -70,13 +70,15 @@ struct umx_engine {
   int low_sep = 3;                 // UMX_LOW_SEP (gemm_pl): which forward bf16x3 products chain their 2^-16-order plane products from zero
   int ls_narrow = 2;               // UMX_LS_NARROW (dev A/B, round 6): the LS form of the 256 x 128 tiles -- 2 = a second accumulator set for the whole k loop
                                    // (190 VGPRs, one workgroup per CU), 1 = one spare accumulator folded in per tile and k-step as on the wide tiles
-  int align = 1;                   // UMX_ALIGN_PLANES (round 6): "aligned planes" -- the leading bf16 plane of both operands of a FORWARD bf16x3 product is
+  int align = 2;                   // UMX_ALIGN_PLANES (round 6): "aligned planes" -- the leading bf16 plane of both operands of a FORWARD bf16x3 product is
                                    // quantised to its pass group (8 consecutive k of one row), so that stage 1 of the matrix core's adder (a cut TOWARD
                                    // ZERO at 2^-24 of the pass's largest product, i.e. an error that follows the product's sign) has nothing to cut:
                                    // umx_gemm_pl.h qf_align_magic (A, in registers), want_planes below (weights, at load).  No bit is lost: the
-                                   // remainder goes down the planes.  0: the plain nearest-bf16 leading plane of rounds 4-5 (dev A/B); 2: the A side only in
-                                   // the PLAIN products (fc3, conv m = 0) -- the complex m > 0 products take rotated l >= 1 components whose signs follow
-                                   // the edge direction (the weights' planes are aligned either way: that is free)
+                                   // remainder goes down the planes.  2 (default): A's leading plane in the PLAIN products (fc3, conv m = 0) -- the complex m > 0
+                                   // products take rotated l >= 1 components whose signs follow the edge direction, nothing coherent to remove -- the
+                                   // weights' planes in every forward product (free); 1: A's in every forward product; 0: the plain nearest-bf16 leading
+                                   // planes of rounds 4-5.  20 000 atoms, four cases (profiles/r06_energy_bias.txt): 0: -9e-7 ... -1.63e-4 eV, 1: -1.3e-5 ...
+                                   // +3.9e-5, 2: +4e-7 ... -5.0e-5; c3 step 517.9 / 526.3 / 523.0 ms
   float odd_sign = -1.0f;          // sign-alternating operand rows (umx_kernels_pl.h): -1 = on (default), +1 = off (UMX_ALT_ROWS=0, dev A/B)
   int rev_planes = 2;              // bf16 planes of the REVERSE-pass operands: 2 (3 products, 16-bit) or 3 (6 products, 24-bit: UMX_PRECISION=bf16x3)
   int fwd_fmt = 3;                 // forward operand format (QFmt, umx_kernels_pl.h): 1 = two fp16 planes (UMX_PRECISION=split),

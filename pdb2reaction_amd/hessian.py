@@ -8,7 +8,7 @@ are evaluated as batches of images through one engine call each instead of 2 ser
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, List, Sequence, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -40,11 +40,17 @@ def mask_frozen(forces: np.ndarray, frozen: Sequence[int]) -> np.ndarray:
 
 @with_small_host_math
 def fd_hessian(batch_forces: Callable[[np.ndarray], np.ndarray], coord_ang: np.ndarray, frozen: Sequence[int], *, device,
-               double: bool, partial: bool, batch: int = 64, step: float = FD_STEP_ANG, shard: bool = False, group=None, engine=None):
+               double: bool, partial: bool, batch: int = 64, step: float = FD_STEP_ANG, shard: bool = False, group=None, engine=None,
+               batch_forces_dev: Optional[Callable] = None):
     """Central-difference Hessian in eV/A^2 as a torch tensor (n_out, 3, n_out, 3) on `device`.
 
     batch_forces(coords[K,N,3]) -> forces [K,N,3] float32.  Columns of frozen DOF stay zero (full output) or are
     dropped together with their rows (`partial`).
+
+    batch_forces_dev (round 6, optional): the DEVICE form ``batch_forces_dev(coords: torch float32 [K,N,3] on `device`) -> forces torch
+    float32 [K,N,3] on `device```.  With it the displaced geometries are built on the device (float64 base point +- step, rounded to the
+    model's float32 positions exactly as the host path rounds them) and forces never leave it: no PCIe copy of 2 x 64 x N x 3 floats per
+    call (``UMAcore.compute_batch_dev``: the engine's device-pointer entry on torch's current stream).  Same columns, bit for bit.
 
     Multi-GPU is OPT-IN: ``shard=True`` makes this call a COLLECTIVE over `group` (default: the world).
     Every rank of the group must enter it with the same geometry and frozen set; active columns are dealt round-robin
@@ -91,9 +97,21 @@ def fd_hessian(batch_forces: Callable[[np.ndarray], np.ndarray], coord_ang: np.n
     per_call = max(batch // 2, 1)
     mine = active[rank::world] if world > 1 else active
 
+    x0_dev = torch.as_tensor(x0, dtype=torch.float64, device=device) if batch_forces_dev is not None else None
+
     def my_columns():
         for start in range(0, len(mine), per_call):
             cols = mine[start: start + per_call]
+            if batch_forces_dev is not None:
+                m = len(cols)
+                ct = torch.as_tensor(cols, device=device, dtype=torch.long)
+                disp_t = x0_dev.reshape(1, dof).repeat(2 * m, 1)
+                rows = torch.arange(m, device=device)
+                disp_t[2 * rows, ct] += step
+                disp_t[2 * rows + 1, ct] -= step
+                f = batch_forces_dev(disp_t.reshape(2 * m, n, 3).to(torch.float32)).reshape(2 * m, dof).to(dtype)
+                hess[:, ct] = (-(f[0::2] - f[1::2]) / (2.0 * step)).T
+                continue
             disp = np.repeat(x0[None], 2 * len(cols), axis=0)
             for m, k in enumerate(cols):
                 a, c = divmod(k, 3)

@@ -234,6 +234,28 @@ class UMAcore:
         e, f = self.engine.energy_forces(np.asarray(coords_ang), forces=forces)
         return {"energy": e, "forces": f}
 
+    def compute_batch_dev(self, pos32):
+        """Device form of :meth:`compute_batch` for loops that stay on the GPU (the batched FD Hessian): ``pos32`` torch float32 [K,N,3] on
+        the engine's device -> forces torch float32 [K,N,3] on the same device, through the engine's device-pointer entry on torch's
+        current stream.  That entry is asynchronous and cannot refuse a non-finite energy itself, so the energies are looked at here (one
+        scalar read per call); a range violation of the fast split-f16 mode widens the engine and repeats the call, as the host entry does."""
+        import torch
+
+        k = int(pos32.shape[0])
+        pos32 = pos32.contiguous()
+        e = torch.empty(k, dtype=torch.float64, device=pos32.device)
+        f = torch.empty(k, pos32.shape[1], 3, dtype=torch.float32, device=pos32.device)
+        for attempt in range(2):
+            self.engine.energy_forces_dev(k, pos32.data_ptr(), e.data_ptr(), f.data_ptr(), stream=torch.cuda.current_stream(pos32.device).cuda_stream)
+            if bool(torch.isfinite(e).all()):
+                return f
+            self.engine.take_range_error()
+            if attempt == 0 and self.engine.widen("non-finite energy in a device-resident batch"):
+                continue
+            raise RuntimeError(f"non-finite energy in a device-resident batch (precision mode {self.engine.precision_mode()}): non-finite "
+                               "coordinates, or an overflow that wider forward planes cannot cure")
+        return f
+
     def compute(self, coord_ang: np.ndarray, *, forces: bool = False, hessian: bool = False) -> Dict[str, Any]:
         """Energy (eV) and optionally forces (eV/A) of one geometry; same contract as reference ``:330-419``."""
         if hessian:
@@ -358,9 +380,14 @@ class uma_pysis(Calculator):
             raise RuntimeError("FD Hessian: column sharding (enable_hessian_sharding) and the graph-parallel mode (workers == world size / "
                                "enable_graph_parallel) cannot be combined: in graph-parallel mode every force call is a collective on one geometry")
         base = core.compute(coord_ang, forces=True, hessian=False)
+        # the displaced geometries and their forces stay on the GPU when the core runs on the HIP engine (round 6); the graph-parallel mode and
+        # stand-in cores keep the host form
+        dev_fn = core.compute_batch_dev if (getattr(core, "_gp", None) is None and hasattr(core, "compute_batch_dev")
+                                            and hasattr(getattr(core, "engine", None), "energy_forces_dev")
+                                            and getattr(core.device, "type", "cpu") == "cuda") else None
         hess = H.fd_hessian(lambda c: core.compute_batch(c, forces=True)["forces"], coord_ang, self.freeze_atoms, device=core.device,
                             double=self.hessian_double, partial=self.return_partial_hessian, batch=FD_BATCH,
-                            shard=self._hess_shard, group=self._hess_group, engine=getattr(core, "engine", None))
+                            shard=self._hess_shard, group=self._hess_group, engine=getattr(core, "engine", None), batch_forces_dev=dev_fn)
         return {"energy": base["energy"], "forces": base["forces"], "hessian": hess}
 
     # ---------- PySisyphus API --------------------------------------

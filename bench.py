@@ -158,7 +158,7 @@ def main():
     ap.add_argument("--no-shard", action="store_true", help="skip the `shard` leg (2-image batch + one-rank RCCL all-gather)")
     ap.add_argument("--shard-steps", type=int, default=20)
     ap.add_argument("--no-serial", action="store_true", help="skip the `serial_schedule` side run (UMX_STREAMS=1)")
-    ap.add_argument("--hessian-sample-atoms", type=int, default=100, help="c4: atoms whose 3 DOF columns the FD-Hessian sample builds (2 x 3 x this many displaced geometries)")
+    ap.add_argument("--hessian-sample-atoms", type=int, default=200, help="c4: atoms whose 3 DOF columns the FD-Hessian sample builds (2 x 3 x this many displaced geometries)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-mode", action="store_true")
     ap.add_argument("--no-fast-mode", action="store_true")
@@ -223,14 +223,21 @@ def main():
         eng = make_engine(precision, lanes)
         imgs_run = imgs if images is None else images
         k = len(imgs_run)
-        x = torch.as_tensor(imgs_run * ANG2BOHR, dtype=torch.float64, device=dev).reshape(k, -1)   # string state: Bohr, float64, in HBM
+        k_full = len(imgs)
+        x = torch.as_tensor(imgs * ANG2BOHR, dtype=torch.float64, device=dev).reshape(k_full, -1)   # string state: Bohr, float64, in HBM (the WHOLE string)
         # the device evaluator of parallel.py: float32 Angstrom positions into the engine's device-pointer entry on torch's current stream,
         # frozen rows zeroed, Hartree / Bohr out, the k images sharded over the ranks + ONE all-gather.  check="deferred": the gathered
         # energies are checked on the device and the flag is read behind the engine's own per-call synchronisation (no extra host sync)
         ev = EngineStringEvaluator(eng, n, dev, frozen=frozen, check="deferred", max_images=(kl_max if images is None else k), force_collective=force_collective)
 
         def step(xc):
-            e, f = ev(xc)
+            if images is None:
+                e, f = ev(xc)
+            else:
+                # the shard leg: this rank's k images are evaluated (+ the gather), then the REPLICATED update of the whole string runs as on
+                # every rank of the 8-GPU job -- with the other ranks' forces stood in for by copies of the local ones
+                e, fl = ev(xc[:k])
+                f = fl.repeat(-(-k_full // k), 1)[:k_full]
             return string_step(xc, f, max_step=0.1, alpha=0.5, fix_ends=False), e
 
         for _ in range(warmup):
@@ -342,42 +349,74 @@ def main():
     def run_hessian(precision: str, sample_atoms: int):
         """c4's "freq Hessian (3N force batches)" (uma_pysis.py:595-686: 2 central-difference force calls per active DOF, h = 1e-3 A): the batched
         loop `hessian.fd_hessian` on a BOUNDED sample -- the columns of `sample_atoms` atoms (every other atom frozen for the sample, which
-        changes the number of columns, not the cost of one: each displaced geometry is a full 2000-atom E+F) -- and the extrapolation to the
-        5940 active columns of the config (20 frozen atoms), stated as such."""
+        changes the number of columns, not the cost of one: each displaced geometry is a full 2000-atom E+F) -- through BOTH entries: the
+        device-resident one `uma_pysis` uses since round 6 (displaced geometries built on the GPU, forces never leave it) and the host one
+        (PCIe copies of 64 x N x 3 floats each way per call).  Per-call times give the spread; the extrapolation to the 5940 active columns of
+        the config is stated as such."""
         from pdb2reaction_amd.hessian import fd_hessian
+        from pdb2reaction_amd.uma_pysis import UMAcore
 
         eng = make_engine(precision)
         sample = list(range(0, n, max(1, n // sample_atoms)))[:sample_atoms]
         frz = sorted(set(range(n)) - set(sample))
         x0 = imgs[k // 2]
-        calls = {"n": 0, "geoms": 0, "edges": 0}
-
-        def batch_forces(disp):
-            calls["n"] += 1
-            calls["geoms"] += len(disp)
-            f = eng.energy_forces(disp)[1]
-            calls["edges"] += eng.graph_stats()[0]
-            return f
-
-        eng.reserve_images(64)
-        batch_forces(np.repeat(x0[None], 64, axis=0))                     # warm-up: workspace for 64-image batches
-        calls.update(n=0, geoms=0, edges=0)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        h = fd_hessian(batch_forces, x0, frz, device=dev, double=True, partial=False, batch=64, engine=eng)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        ok = bool(torch.isfinite(h).all())
-        eng.close()
         cols = 3 * len(sample)
         full_cols = 3 * (n - len(frozen))
-        return {"columns": cols, "displaced_geometries": calls["geoms"], "engine_calls": calls["n"], "seconds": dt, "columns_per_s": cols / dt,
-                "ms_per_displaced_geometry": dt / calls["geoms"] * 1e3, "finite": ok, "batch": 64,
-                "full_hessian_columns": full_cols, "extrapolated_full_hessian_s": full_cols / (cols / dt),
-                "directed_edges": calls["edges"], "algorithmic_tflops": FLOP_PER_EDGE * calls["edges"] / dt / 1e12,
-                "note": f"hessian.fd_hessian (host-pointer entry: PCIe copies of 64 x {n} x 3 floats per call included), {cols} columns = {calls['geoms']} displaced "
-                        f"{n}-atom geometries in batches of 64; extrapolated_full_hessian_s scales columns/s to the {full_cols} active columns of c4 "
-                        "(an extrapolation of the same loop, not a second measurement)"}
+        core = UMAcore.__new__(UMAcore)              # the calculator core's device batch entry on this engine (no second engine, no weights reload)
+        core.engine = eng
+        res = {}
+        h_ref = None
+        for entry in ("device", "host"):
+            calls = {"n": 0, "geoms": 0, "edges": 0, "t": []}
+
+            def batch_forces(disp, _c=calls):
+                torch.cuda.synchronize(); t = time.perf_counter()
+                f = eng.energy_forces(disp)[1]
+                _c["t"].append((time.perf_counter() - t) / len(disp) * 1e3)
+                _c["n"] += 1; _c["geoms"] += len(disp); _c["edges"] += eng.graph_stats()[0]
+                return f
+
+            def batch_forces_dev(pos32, _c=calls):
+                torch.cuda.synchronize(); t = time.perf_counter()
+                f = core.compute_batch_dev(pos32)
+                torch.cuda.synchronize()
+                _c["t"].append((time.perf_counter() - t) / len(pos32) * 1e3)
+                _c["n"] += 1; _c["geoms"] += len(pos32); _c["edges"] += eng.graph_stats()[0]
+                return f
+
+            eng.reserve_images(64)
+            batch_forces(np.repeat(x0[None], 64, axis=0))                     # warm-up: workspace for 64-image batches
+            calls.update(n=0, geoms=0, edges=0, t=[])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            h = fd_hessian(batch_forces, x0, frz, device=dev, double=True, partial=False, batch=64, engine=eng,
+                           batch_forces_dev=batch_forces_dev if entry == "device" else None)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            ok = bool(torch.isfinite(h).all())
+            if h_ref is None:
+                h_ref = h
+            per = np.asarray(calls["t"][:-1] if len(calls["t"]) > 1 and calls["geoms"] % 64 else calls["t"])     # (a ragged last call is left out of the spread)
+            res[entry] = {"columns": cols, "displaced_geometries": calls["geoms"], "engine_calls": calls["n"], "seconds": dt, "columns_per_s": cols / dt,
+                          "ms_per_displaced_geometry": dt / calls["geoms"] * 1e3,
+                          "ms_per_displaced_geometry_by_call": {"min": float(per.min()), "median": float(np.median(per)), "max": float(per.max()), "calls": int(per.size)},
+                          "finite": ok, "extrapolated_full_hessian_s": full_cols / (cols / dt), "directed_edges": calls["edges"],
+                          "algorithmic_tflops": FLOP_PER_EDGE * calls["edges"] / dt / 1e12,
+                          "same_columns_as_device_entry": bool(torch.equal(h, h_ref))}
+        eng.close()
+        d, hst = res["device"], res["host"]
+        out_h = dict(d)
+        out_h.update({"entry": "device (uma_pysis.get_hessian's default since round 6: hessian.fd_hessian(batch_forces_dev=UMAcore.compute_batch_dev))",
+                      "batch": 64, "full_hessian_columns": full_cols, "sample_share_of_full_hessian": cols / full_cols,
+                      "host_entry": hst, "host_minus_device_ms_per_geometry": hst["ms_per_displaced_geometry"] - d["ms_per_displaced_geometry"],
+                      "projected_8gpu_full_hessian_s": d["extrapolated_full_hessian_s"] / 8.0,
+                      "columns_per_s_per_rank": d["columns_per_s"],
+                      "note": f"hessian.fd_hessian, {cols} columns = {d['displaced_geometries']} displaced {n}-atom geometries in batches of 64 "
+                              f"({cols / full_cols:.0%} of the {full_cols} active columns of c4); extrapolated_full_hessian_s scales columns/s to all of them "
+                              "(an extrapolation of the same loop, not a second measurement); projected_8gpu_full_hessian_s = that / 8: the columns are dealt "
+                              "k mod 8 over the ranks (fd_hessian(shard=True)), every rank builds its share at columns_per_s_per_rank, one all-reduce of the "
+                              "(3N)^2 float64 matrix (288 MB) at the end is NOT in it -- a PROJECTION, RCCL has never run on more than one rank here"})
+        return out_h
 
     mode_req = os.environ.get("UMX_PRECISION", "auto")           # "auto" = bf16x3: >= 24-bit products in both passes (include/umx.h)
     dt, prof, ne_local, maxdeg, resolved, lanes_used = run(mode_req, args.steps, args.warmup)
@@ -529,7 +568,8 @@ def main():
             # every GEMM on v_mfma_f32_32x32x2_f32: the same float32 products as the headline mode's, on the fp32 matrix pipe
             out["fp32_mode"] = side_mode("fp32", args.fp32_steps, args.fp32_warmup, "fp32", PEAK_FP32_MFMA_TFLOPS, "f32 (all GEMMs on v_mfma_f32_32x32x2_f32)")
         os.environ["UMX_PRECISION"] = mode_req
-        if world == 1 and headline and not args.no_shard:
+        shard_images = {"c3": 2, "c4": 3, "c5": 1}.get(args.config) if (n, k) == CONFIGS[args.config][:2] else None
+        if world == 1 and shard_images and not args.no_shard:
             # what ONE rank of the 8-GPU run does per iteration (BASELINE c3: "16 images sharded 2-images/GPU across 8 x MI355X"): the 2-image batch
             # through the same evaluator + the all-gather, issued for real on a one-rank RCCL group (nccl backend; the identity, but the call, its
             # stream ordering and its latency are there).  Driver-timed; any it/s derived from it is a projection of the 8-GPU run, not a measurement.
@@ -538,16 +578,17 @@ def main():
                 if not dist.is_initialized():
                     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29400 + os.getpid() % 500}", rank=0, world_size=1, device_id=dev)
                     own_group = True
-                sdt, _, se, _, _, _ = run(mode_req, args.shard_steps, 3, images=imgs[:2], force_collective=True)
-                sdt0, _, _, _, _, _ = run(mode_req, args.shard_steps, 3, images=imgs[:2], force_collective=False)
+                ssteps = args.shard_steps if args.config != "c5" else max(3, args.shard_steps // 4)
+                sdt, _, se, _, _, _ = run(mode_req, ssteps, 3 if args.config != "c5" else 1, images=imgs[:shard_images], force_collective=True)
+                sdt0, _, _, _, _, _ = run(mode_req, ssteps, 3 if args.config != "c5" else 1, images=imgs[:shard_images], force_collective=False)
                 if own_group:
                     dist.destroy_process_group()
-                sms = sdt / args.shard_steps * 1e3
-                out["shard"] = {"ms_per_step": sms, "steps": args.shard_steps, "warmup": 3, "images": 2, "directed_edges": int(se),
-                                "ms_per_step_without_collective": sdt0 / args.shard_steps * 1e3,
+                sms = sdt / ssteps * 1e3
+                out["shard"] = {"ms_per_step": sms, "steps": ssteps, "warmup": 3 if args.config != "c5" else 1, "images": shard_images, "directed_edges": int(se),
+                                "ms_per_step_without_collective": sdt0 / ssteps * 1e3,
                                 "collective": "all_gather_into_tensor of [E | status | F] float64 rows on a ONE-rank nccl (RCCL) group, every step",
                                 "projected_8gpu_iterations_per_s": 1e3 / sms,
-                                "note": "the per-rank share of the 8-GPU headline (2 of the 16 images + the gather + the replicated string step), timed like the "
+                                "note": f"the per-rank share of the 8-GPU run of this config ({shard_images} of the {k} images + the gather + the replicated string step), timed like the "
                                         "headline; projected_8gpu_iterations_per_s = 1 / this is a PROJECTION (xGMI all-gather latency of 8 ranks and rank skew "
                                         "are not in it), not a measurement -- RCCL has never run on more than one rank here"}
             except Exception as exc:

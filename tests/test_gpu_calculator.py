@@ -78,6 +78,37 @@ def test_fd_hessian_against_oracle_fd(oracle, setup):
     assert h2.shape == (39, 39) and h2.dtype == np.float32
 
 
+def test_device_resident_fd_hessian_equals_the_host_entry(setup):
+    """Round 6: ``get_hessian`` builds the displaced geometries on the GPU and keeps the forces there
+    (``UMAcore.compute_batch_dev``, the engine's device-pointer entry) -- bit for bit the columns of the host entry, which copies 64 x N x 3 floats
+    over PCIe each way per call."""
+    from pdb2reaction_amd import hessian as H
+
+    z, elem, imgs = setup
+    calc = U.uma_pysis(model="synthetic", freeze_atoms=[3, 9])
+    core = calc._ensure_core(elem)
+    x_ang = imgs[2].astype(np.float64)
+    seen = {"host": 0, "dev": 0}
+
+    def host(c):
+        seen["host"] += len(c)
+        return core.compute_batch(c, forces=True)["forces"]
+
+    def devf(p32):
+        assert p32.is_cuda and p32.dtype == torch.float32
+        seen["dev"] += len(p32)
+        return core.compute_batch_dev(p32)
+
+    kw = dict(device=core.device, double=True, partial=False, batch=8)
+    h_host = H.fd_hessian(host, x_ang, calc.freeze_atoms, **kw)
+    h_dev = H.fd_hessian(host, x_ang, calc.freeze_atoms, batch_forces_dev=devf, **kw)
+    assert seen["dev"] == 2 * 3 * 12 and seen["host"] == seen["dev"]                   # the device run never touched the host entry
+    assert torch.equal(h_host, h_dev)
+    r = calc.get_hessian(elem, (x_ang * U.ANG2BOHR).reshape(-1))                       # the calculator takes the device entry by itself
+    assert torch.equal(r["hessian"], H.hessian_to_au(h_dev, double=True, as_torch=True))
+    calc.close()
+
+
 def test_error_behaviour(setup):
     z, elem, imgs = setup
     with pytest.raises(RuntimeError, match="no CPU path"):

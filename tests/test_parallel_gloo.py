@@ -1,4 +1,6 @@
-"""world_size-2 gloo test of the image-sharded evaluator (the N>1 path of bench.py), CPU only."""
+"""gloo tests (world size 2 and 8) of the image-sharded evaluator (the N>1 path of bench.py), CPU only.
+(Managers come from the SPAWN context: a forked child of a process that has initialised the GPU dies with "Memory in use" -- harmless in this
+GPU-less file, the same trap if it ever runs inside a process that has touched the GPU)"""
 import os
 import socket
 
@@ -47,14 +49,17 @@ def _worker(rank, world, port, k, n, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("k", [5, 16])
-def test_sharded_equals_single_process(k):
-    n, world = 7, 2
+@pytest.mark.parametrize("k,world", [(5, 2), (16, 2), (16, 8), (8, 8), (24, 8)])
+def test_sharded_equals_single_process(k, world):
+    """(16, 8) / (8, 8) / (24, 8): the layouts BASELINE names -- c3 "16 images sharded 2-images/GPU across 8", c5 "8 images one-image-per-GPU",
+    c4's 24 DMF images on 8 GPUs -- as eight gloo ranks on the CPU (an 8-rank rehearsal on ONE GPU is not possible: the box admits six GPU
+    processes)."""
+    n = 7
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, k, n, out), nprocs=world, join=True)
     g = torch.Generator().manual_seed(0)
@@ -116,7 +121,7 @@ def test_fd_hessian_columns_are_sharded_over_ranks():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()
     out = mgr.dict()
     mp.spawn(_hess_worker, args=(2, port, out), nprocs=2, join=True)
     h0, n0, h_local, msg0 = out[0]
@@ -197,7 +202,7 @@ def test_sharded_evaluator_widens_on_every_rank_together():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()
     out = mgr.dict()
     mp.spawn(_range_worker, args=(2, port, out), nprocs=2, join=True)
     g = torch.Generator().manual_seed(1)
@@ -246,7 +251,7 @@ def test_sharded_fd_hessian_never_mixes_two_arithmetics():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()
     out = mgr.dict()
     mp.spawn(_hess_range_worker, args=(2, port, out), nprocs=2, join=True)
     for r in range(2):
@@ -301,7 +306,7 @@ def test_rank_local_failure_completes_the_collective_and_raises_everywhere():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()
     out = mgr.dict()
     mp.spawn(_raise_worker, args=(2, port, out), nprocs=2, join=True)
     (m0, t0), (m1, t1) = out[0], out[1]
@@ -424,7 +429,7 @@ def test_growing_string_driver_runs_spmd_over_two_ranks():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()
     out = mgr.dict()
     mp.spawn(_gsm_worker, args=(2, port, out), nprocs=2, join=True)
     single = GrowingStringDriver(["X"], np.array([-0.558224, 1.441726, 0.0]), np.array([0.623499, 0.028038, 0.0]),

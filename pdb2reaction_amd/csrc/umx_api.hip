@@ -163,6 +163,7 @@ struct umx_engine {
   float* d_io_pos = nullptr; double* d_io_e = nullptr; float* d_io_f = nullptr; long io_cap = 0, io_img_cap = 0;
   // stats / profiling / debug
   int64_t last_edges = 0; int32_t last_maxdeg = 0;
+  bool may_truncate = true;      // the largest degree of the evaluation being planned reaches max_neigh: k_graph_fill takes its truncating (LDS) form
   bool prof_on = false;
   std::vector<ProfRec> prof;
   size_t prof_used = 0;
@@ -595,6 +596,7 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
   const dim3 B256(256);
   const bool pl = eng->pl;
   const bool gp = eng->gp;                                       // graph-parallel: partial sums over this rank's edges + exchange points
+  const bool may_trunc = eng->may_truncate;                      // some node of this call has more candidates than max_neigh (known on the host)
   const bool fused_rev = eng->pl || !eng->dbg_on;     // k_modrot_bwd_pl produces g_xn itself (fp32 mode with debug captures: the unfused kernels, which expose xrot / g_xrot)
   const long g_lo = gp ? eng->gp_lo : 0, g_hi = gp ? eng->gp_hi : nn;
   // every closure reads eng->stream when it RUNS (the executor points it at the lane's stream)
@@ -602,7 +604,8 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
   P.stream([=, &w]() -> int {
     hipStream_t s = eng->stream;
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, d_deg, nn, w.row_ptr, w.stats);
-    hipLaunchKernelGGL(k_graph_fill, dim3(nblk(nn, 4)), B256, 0, s, d_pos, N, nn, rc2, eng->max_neigh, d_cand, w.row_ptr, w.esrc, w.edst, w.evec, g_lo, g_hi);
+    if (may_trunc) hipLaunchKernelGGL(k_graph_fill<true>, dim3(nblk(nn, 4)), B256, 0, s, d_pos, N, nn, rc2, eng->max_neigh, d_cand, w.row_ptr, w.esrc, w.edst, w.evec, g_lo, g_hi);
+    else hipLaunchKernelGGL(k_graph_fill<false>, dim3(nblk(nn, 4)), B256, 0, s, d_pos, N, nn, rc2, eng->max_neigh, d_cand, w.row_ptr, w.esrc, w.edst, w.evec, g_lo, g_hi);
     HIPCHK(eng, hipMemsetAsync(w.out_cur, 0, (nn + 1) * sizeof(int), s));
     if (ne > 0) hipLaunchKernelGGL(k_out_count, dim3(nblk(ne, 256)), B256, 0, s, w.esrc, ne, w.out_cur);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, w.out_cur, nn, w.out_ptr, w.stats + 2);
@@ -1610,6 +1613,7 @@ static int eval_partitioned(umx_engine* eng, hipStream_t s, const float* d_pos, 
   HIPCHK(eng, hipMemcpyAsync(&flag, eng->d_flags, sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(eng, hipStreamSynchronize(s));
   if (flag & 2) { HIPCHK(eng, hipMemsetAsync(eng->d_flags, 0, sizeof(int), s)); return fail(eng, UMX_ERR_ARG, "umx_energy_forces: non-finite position (device buffer)"); }
+  eng->may_truncate = cnt[P] >= eng->max_neigh;
   // layout: P persistent regions, then one transient region sized for the largest partition
   const int mode = ws_mode(eng);
   const int gridG = eng->ff_grid ? eng->grid_G : 0;
@@ -1722,6 +1726,7 @@ static int energy_forces_on(umx_engine* eng, hipStream_t run_stream, int n_image
                                               : " (non-finite input or an overflow in float32)"));
   }
   eng->last_maxdeg = img_edges[K];
+  eng->may_truncate = img_edges[K] >= eng->max_neigh;          // (degrees are min(candidates, max_neigh): below the cap nothing was cut)
   eng->last_edges = 0;
   for (long k = 0; k < K; ++k) eng->last_edges += img_edges[k];
   // chunk planning under the workspace budget

@@ -83,6 +83,10 @@ __global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ deg, long
 // ranks each key against the others with broadcast reads (cand^2 / 64 compares per lane) and writes the kept ones in source order.
 // More than GF_MAXC candidates (> 1 atom / A^3 at a 6 A cutoff) keep the slow form.
 constexpr int GF_MAXC = 1024;
+// TRUNC = false (the common case: the host knows the batch's largest candidate count, read with the edge counts, and it is below max_neigh):
+// no truncation code and NO LDS -- the static 32-KiB key array of the truncating form would cap the resident blocks of this HBM-bound
+// kernel on every launch for a path that is never taken.
+template <bool TRUNC>
 __global__ __launch_bounds__(256) void k_graph_fill(const float* __restrict__ pos, int natoms, long nt, float rc2, int max_neigh,
                                                     const int* __restrict__ cand, const int* __restrict__ row_ptr, int* __restrict__ esrc,
                                                     int* __restrict__ edst, float* __restrict__ evec, long lo, long hi) {
@@ -91,10 +95,10 @@ __global__ __launch_bounds__(256) void k_graph_fill(const float* __restrict__ po
   const long base = (node / natoms) * natoms;
   const float xi = pos[node * 3 + 0], yi = pos[node * 3 + 1], zi = pos[node * 3 + 2];
   const int nc = cand[node];
-  const bool truncate = nc > max_neigh;
+  const bool truncate = TRUNC && nc > max_neigh;
   int w = row_ptr[node];
-  __shared__ unsigned long long gf_keys[4][GF_MAXC];
-  if (truncate && nc <= GF_MAXC) {               // wave-uniform
+  if constexpr (TRUNC) if (truncate && nc <= GF_MAXC) {               // wave-uniform
+    __shared__ unsigned long long gf_keys[4][GF_MAXC];
     unsigned long long* keys = gf_keys[threadIdx.x >> 6];
     int c = 0;
     for (int j0 = 0; j0 < natoms; j0 += 64) {

@@ -294,7 +294,8 @@ def main():
         res["single_image_ms"] = (time.perf_counter() - t0) / 6 * 1e3
         lz = {"climb": True, "climb_rms": 1e9, "climb_lanczos": True, "climb_lanczos_rms": 1e9}       # the reference's defaults (path_opt.py:179-182), thresholds forced so that the phase runs
         for leg, gs_kw in (("climb_off", {"climb": False}), ("climb_on", {"climb": True, "climb_rms": 1e9, "climb_lanczos": False}),
-                           ("climb_lanczos_cold", {**lz, "climb_lanczos_warm_start": False}), ("climb_lanczos", lz)):
+                           ("climb_lanczos_cold", {**lz, "climb_lanczos_warm_start": False}), ("climb_lanczos", lz),
+                           ("climb_lanczos_warm_unguarded", {**lz, "climb_lanczos_warm_guard": False})):
             drv = GrowingStringDriver(elem, x0[0], x0[-1], evaluate_device=ev, device=dev, images=x0,
                                       gs_kw={"max_nodes": k - 2, "fix_first": False, "fix_last": False, **gs_kw},
                                       stopt_kw={"max_cycles": cycles + warmup, "thresh": "gau_vtight", "max_step": 0.1, "print_every": 10 ** 9})
@@ -320,11 +321,12 @@ def main():
                 calls = max(out.timing["lanczos_calls"], 1.0)
                 res[leg].update({"lanczos_evals": int(out.timing["lanczos_evals"]), "lanczos_recursions": int(out.timing["lanczos_calls"]),
                                  "lanczos_evals_per_cycle": out.timing["lanczos_evals"] / calls, "warm_kept": int(out.timing["lanczos_warm_calls"]),
-                                 "warm_rejected": int(out.timing["lanczos_warm_rejected"]), "cycles_run": int(out.cycles)})
+                                 "warm_rejected": int(out.timing["lanczos_warm_rejected"]), "cycles_run": int(out.cycles),
+                                 "lowest_ritz_value_and_overlap_with_tangent": [[round(w_, 5), round(o_, 3), n_] for w_, o_, n_, _ in drv.lanczos_log[:12]]})
         ev.flush()
         eng.close()
         shard_ms = res["evaluation_only_ms"] / 8.0
-        for leg in ("climb_lanczos_cold", "climb_lanczos"):
+        for leg in ("climb_lanczos_cold", "climb_lanczos", "climb_lanczos_warm_unguarded"):
             r_ = res[leg]
             # what the serial single-image probes add: on one GPU (measured: cycle_ms), and PROJECTED for one rank of the 8-GPU run -- the probes on
             # one rank while seven wait (gp_singles=False), or graph-parallel over the eight ranks (parallel.EngineStringEvaluator, the default;
@@ -343,7 +345,10 @@ def main():
                        "the share it would have of a cycle of the 8-GPU run (the string update is replicated on every rank).  climb_lanczos(_cold): the "
                        "reference's DEFAULT climbing phase (climb=True, climb_lanczos=True, path_opt.py:179-182; thresholds forced so that it runs on the "
                        "synthetic string): every cycle adds a Lanczos recursion of serial single-image gradients -- started from the string tangent (cold) "
-                       "or, guarded, from last cycle's mode (the default); projected_* are PROJECTIONS from shard = evaluation_only / 8")
+                       "or, guarded, from last cycle's mode (the default: the warm result is kept only while it has negative curvature and overlaps the "
+                       "tangent -- on the SYNTHETIC string with random weights the lowest mode at the HEI is unrelated to the path, so the guard never "
+                       "trusts it and the default leg equals the cold one; climb_lanczos_warm_unguarded shows the serial depth when the warm start is "
+                       "taken); projected_* are PROJECTIONS from shard = evaluation_only / 8")
         return res
 
     def run_hessian(precision: str, sample_atoms: int):

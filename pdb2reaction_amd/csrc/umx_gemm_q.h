@@ -84,7 +84,7 @@ __host__ __device__ constexpr bool q_use_product(int PA, int PB, int NPROD, int 
 // AL = 1 (AF kernels, forward products): "aligned planes" -- the leading plane of A is quantised to the lane's pass group (qf_align_magic,
 // umx_gemm_pl.h); the weights' leading plane is quantised the same way when the planes are built (umx_api.hip).
 template <int CPLX, int WIDE, int P = 3, int S = 2, int F16 = 0, int NPROD = (P == 3 ? 6 : 3), int PB = P, int AF = 0, int LS = 0, int AL = 0>
-__global__ __launch_bounds__(512, (LS == 1 && !WIDE) ? 4 : 1) void umx_gemm_q_kernel(const GemmPL p) {   // (narrow LS = 1 form: asks for 4 waves per SIMD = two workgroups per CU = 128 VGPRs)
+__global__ __launch_bounds__(512, 1) void umx_gemm_q_kernel(const GemmPL p) {
   static_assert(!AL || AF, "AL: the float32-A kernels");
   static_assert(!LS || (P == 3 && PB == 3 && !F16 && NPROD == 6), "LS: the six-product bf16 form");
   static_assert(LS != 2 || !WIDE, "LS = 2 (second accumulator set): 256 x 128 tiles only");

@@ -358,6 +358,7 @@ class GrowingStringDriver:
         self.lanczos_calls = 0                               # Lanczos recursions run (one per climbing cycle below climb_lanczos_rms)
         self.lanczos_warm_calls = 0                          # ... of which started from the previous cycle's mode (and were kept)
         self.lanczos_warm_rejected = 0                       # warm recursions whose result failed the guard (a cold one followed)
+        self.lanczos_log: List[Tuple[float, float, int, bool]] = []      # per recursion kept: (lowest Ritz value, overlap with the tangent, gradients, warm)
         # (HEI index, images, unit vector) of the most recent trusted Lanczos mode: the next cycle's recursion starts from it (see run())
         self._lanczos_prev: Optional[Tuple[int, int, torch.Tensor]] = None
         self.tangent_kind = str(self.gs.get("tangent", "spline"))
@@ -609,19 +610,23 @@ class GrowingStringDriver:
                         lp = self._lanczos_prev
                         grad_fn = lambda xq: -self._single_forces(xq)                      # noqa: E731
                         warm = bool(gs.get("climb_lanczos_warm_start", True)) and lp is not None and lp[0] == hei and lp[1] == k
+                        guard = bool(gs.get("climb_lanczos_warm_guard", True))          # False: measurement only (bench.py) -- any warm result is kept
+                        min_ov = float(gs.get("climb_lanczos_warm_overlap", 0.5))
+                        trusted = lambda w_, v_: (not guard) or (w_ < 0.0 and float(v_ @ t_hei) >= min_ov)     # noqa: E731
                         done = False
                         if warm:
                             w_l, lanczos_t, n_l = lanczos_lowest_mode_t(grad_fn, self._x[hei], -self._f[hei], lp[2], orient=t_hei)
                             self.lanczos_evals += n_l
-                            done = w_l < 0.0 and float(lanczos_t @ t_hei) >= float(gs.get("climb_lanczos_warm_overlap", 0.5))
+                            done = trusted(w_l, lanczos_t)
                             self.lanczos_warm_calls += int(done)
                             self.lanczos_warm_rejected += int(not done)
                         if not done:
                             w_l, lanczos_t, n_l = lanczos_lowest_mode_t(grad_fn, self._x[hei], -self._f[hei], t_hei)
                             self.lanczos_evals += n_l
                         # only a mode that can be trusted next cycle is remembered
-                        self._lanczos_prev = (hei, k, lanczos_t) if (w_l < 0.0 and float(lanczos_t @ t_hei) >= float(gs.get("climb_lanczos_warm_overlap", 0.5))) else None
+                        self._lanczos_prev = (hei, k, lanczos_t) if trusted(w_l, lanczos_t) else None
                         self.lanczos_calls += 1
+                        self.lanczos_log.append((float(w_l), float(lanczos_t @ t_hei), int(n_l), bool(done)))
                         again = True
                 if not again and pair is not None and not (sy > 1e-12):
                     offer_pair, again = False, True                # curvature pair rejected: rebuild the direction without it

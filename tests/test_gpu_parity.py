@@ -99,6 +99,7 @@ def switch_case(oracle):
     {"UMX_FORCE_PARTS": "3"}, {"UMX_MAX_CHUNK_IMAGES": "1"}, {"UMX_WS_EAGER": "1"},
     {"UMX_LOW_SEP": "0"}, {"UMX_LOW_SEP": "1"}, {"UMX_LOW_SEP": "2"},           # the small plane products: one accumulator / apart for fc3 only / for every forward product
     {"UMX_LANES_AUTO_EDGES": "1000"},                                            # two lanes chosen by the engine from the batch's edge count
+    {"UMX_ALIGN_PLANES": "0"}, {"UMX_ALIGN_PLANES": "1"},                        # leading planes: nearest bf16 (rounds 4-5) / aligned in every forward product (default 2: the plain ones)
 ], ids=lambda e: ",".join(f"{k[4:]}={v}" for k, v in e.items()))
 def test_documented_switches_hold_the_tolerances(weights, switch_case, env, monkeypatch):
     """Every run-time switch of README.md that touches the evaluation (round 5 pruned the settled development levers: what is listed is what

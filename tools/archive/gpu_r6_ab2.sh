@@ -1,4 +1,5 @@
 #!/bin/bash
+# (archive: UMX_LS_NARROW was a round-6 A/B switch of that has been removed again; the numbers are in profiles/r06_ls_ab.txt)
 # round 6, second A/B: scope of the aligned planes (all forward products / plain ones only) and the LS form of the 256 x 128 tiles
 set -e
 mkdir -p gpurun_out/r6b

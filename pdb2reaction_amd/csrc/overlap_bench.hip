@@ -60,13 +60,13 @@ static int pmc_mode(int reps, bool x3 = false) {
     // the DEFAULT mode since round 4 (bf16x3): 6 plane products in both passes; forward and conv^T A operands as float32 quad-row blocks split in
     // registers (AF = 1; the buffer's bit patterns read as finite floats ~0.01-0.03), weights as three bf16 planes; fc3^T on PL planes
     for (int r = 0; r < reps; ++r) {
-      hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0, 3, 2, 0, 6, 3, 1, 2>), grid(0, 0, 640), dim3(512), 0, 0, mk(3, 2304, 0, 0, 0, 1408, 0, 0, 640, 768));      // forward plain products: the LS forms the engine launches (umx_gemm_q.h)
+      hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0, 3, 2, 0, 6, 3, 1, 2, 1>), grid(0, 0, 640), dim3(512), 0, 0, mk(3, 2304, 0, 0, 0, 1408, 0, 0, 640, 768));      // forward plain products: the LS + aligned-planes forms the engine launches (umx_gemm_q.h)
       hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1, 3, 2, 0, 6, 3, 1>), grid(1, 1, 256), dim3(512), 0, 0, mk(3, 2304, 768, 1280, 256, 1408, 640, 896, 256, 512));
       hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1, 3, 2, 0, 6, 3, 1>), grid(1, 1, 128), dim3(512), 0, 0, mk(3, 2304, 1792, 2048, 128, 1408, 1152, 1280, 128, 256));
-      hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0, 3, 2, 0, 6, 3, 1, 2>), grid(0, 0, 384), dim3(512), 0, 0, mk(3, 1152, 0, 0, 0, 1152, 0, 0, 384, 384));
+      hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0, 3, 2, 0, 6, 3, 1, 2, 1>), grid(0, 0, 384), dim3(512), 0, 0, mk(3, 1152, 0, 0, 0, 1152, 0, 0, 384, 384));
       hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1, 3, 2, 0, 6, 3, 1>), grid(1, 1, 256), dim3(512), 0, 0, mk(3, 1152, 384, 640, 256, 1152, 384, 640, 256, 256));
       hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1, 3, 2, 0, 6, 3, 1>), grid(1, 1, 128), dim3(512), 0, 0, mk(3, 1152, 896, 1024, 128, 1152, 896, 1024, 128, 128));
-      hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 3, 2, 0, 6, 3, 1, 1>), grid(0, 1, 1536), dim3(512), 0, 0, mk(3, 128, 0, 0, 0, 1536, 0, 0, 1536, 128));
+      hipLaunchKernelGGL((umx_gemm_q_kernel<0, 1, 3, 2, 0, 6, 3, 1, 1, 1>), grid(0, 1, 1536), dim3(512), 0, 0, mk(3, 128, 0, 0, 0, 1536, 0, 0, 1536, 128));
       hipLaunchKernelGGL((umx_gemm_q_kernel<0, 0, 3, 2, 0, 6, 3, 1>), grid(0, 0, 384), dim3(512), 0, 0, mk(3, 1152, 0, 0, 0, 1152, 0, 0, 384, 384));
       hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1, 3, 2, 0, 6, 3, 1>), grid(1, 1, 256), dim3(512), 0, 0, mk(3, 1152, 384, 640, 256, 1152, 384, 640, 256, 256));
       hipLaunchKernelGGL((umx_gemm_q_kernel<1, 1, 3, 2, 0, 6, 3, 1>), grid(1, 1, 128), dim3(512), 0, 0, mk(3, 1152, 896, 1024, 128, 1152, 896, 1024, 128, 128));

@@ -67,7 +67,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA p
 PEAK_FP64_MFMA_TFLOPS = 78.6     # AMD MI355X datasheet: f64 matrix = f64 vector peak (the micro-arch guide has no f64 row)
 
 
-PMC_SUMMARIES = {"bf16x3": "r05_pmc_hbm_traffic_bf16x3.json", "split": "r05_pmc_hbm_traffic_split.json"}
+PMC_SUMMARY_GLOB = "r*_pmc_hbm_traffic_{mode}.json"      # profiles/: one per round; the one measured on the running build is taken
 
 
 def pmc_summary(build_digest: str, mode: str):
@@ -75,16 +75,21 @@ def pmc_summary(build_digest: str, mode: str):
     traffic comes from the committed summary of two PMC passes over this very command -- but ONLY when that summary was
     measured on the build that is running now (`csrc_sha256` == the digest compiled into libumx.so).  A kernel edit makes
     the figure vanish from the line instead of going stale."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_SUMMARIES.get(mode, "none"))
-    try:
-        with open(path) as f:
-            d = json.load(f)
-    except Exception as exc:
-        return None, f"no PMC summary for mode {mode} ({type(exc).__name__})"
-    rel = os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
-    if d.get("csrc_sha256") != build_digest:
-        return None, f"{rel} is stale: measured on build {str(d.get('csrc_sha256'))[:12]}, running {build_digest[:12]}"
-    return d, f"{rel} @ build {build_digest[:12]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 FETCH correction)"
+    import glob
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    stale = None
+    for path in sorted(glob.glob(os.path.join(here, "profiles", PMC_SUMMARY_GLOB.format(mode=mode))), reverse=True):      # newest round first
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except Exception:
+            continue
+        rel = os.path.relpath(path, here)
+        if d.get("csrc_sha256") == build_digest:
+            return d, f"{rel} @ build {build_digest[:12]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 FETCH correction)"
+        stale = stale or f"{rel} is stale: measured on build {str(d.get('csrc_sha256'))[:12]}, running {build_digest[:12]}"
+    return None, stale or f"no PMC summary for mode {mode}"
 
 
 PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak (about 6.3 TB/s is achievable by a float4 copy)
@@ -294,8 +299,7 @@ def main():
         res["single_image_ms"] = (time.perf_counter() - t0) / 6 * 1e3
         lz = {"climb": True, "climb_rms": 1e9, "climb_lanczos": True, "climb_lanczos_rms": 1e9}       # the reference's defaults (path_opt.py:179-182), thresholds forced so that the phase runs
         for leg, gs_kw in (("climb_off", {"climb": False}), ("climb_on", {"climb": True, "climb_rms": 1e9, "climb_lanczos": False}),
-                           ("climb_lanczos_cold", {**lz, "climb_lanczos_warm_start": False}), ("climb_lanczos", lz),
-                           ("climb_lanczos_warm_unguarded", {**lz, "climb_lanczos_warm_guard": False})):
+                           ("climb_lanczos_cold", {**lz, "climb_lanczos_warm_start": False}), ("climb_lanczos", lz)):
             drv = GrowingStringDriver(elem, x0[0], x0[-1], evaluate_device=ev, device=dev, images=x0,
                                       gs_kw={"max_nodes": k - 2, "fix_first": False, "fix_last": False, **gs_kw},
                                       stopt_kw={"max_cycles": cycles + warmup, "thresh": "gau_vtight", "max_step": 0.1, "print_every": 10 ** 9})
@@ -326,7 +330,7 @@ def main():
         ev.flush()
         eng.close()
         shard_ms = res["evaluation_only_ms"] / 8.0
-        for leg in ("climb_lanczos_cold", "climb_lanczos", "climb_lanczos_warm_unguarded"):
+        for leg in ("climb_lanczos_cold", "climb_lanczos"):
             r_ = res[leg]
             # what the serial single-image probes add: on one GPU (measured: cycle_ms), and PROJECTED for one rank of the 8-GPU run -- the probes on
             # one rank while seven wait (gp_singles=False), or graph-parallel over the eight ranks (parallel.EngineStringEvaluator, the default;
@@ -345,10 +349,10 @@ def main():
                        "the share it would have of a cycle of the 8-GPU run (the string update is replicated on every rank).  climb_lanczos(_cold): the "
                        "reference's DEFAULT climbing phase (climb=True, climb_lanczos=True, path_opt.py:179-182; thresholds forced so that it runs on the "
                        "synthetic string): every cycle adds a Lanczos recursion of serial single-image gradients -- started from the string tangent (cold) "
-                       "or, guarded, from last cycle's mode (the default: the warm result is kept only while it has negative curvature and overlaps the "
-                       "tangent -- on the SYNTHETIC string with random weights the lowest mode at the HEI is unrelated to the path, so the guard never "
-                       "trusts it and the default leg equals the cold one; climb_lanczos_warm_unguarded shows the serial depth when the warm start is "
-                       "taken); projected_* are PROJECTIONS from shard = evaluation_only / 8")
+                       "or from last cycle's mode (the default; kept only while its curvature is negative, every 10th recursion cold); "
+                       "lowest_ritz_value_and_overlap_with_tangent lists [Ritz value, overlap, gradients] per recursion -- on the SYNTHETIC string with "
+                       "random weights the lowest mode at the HEI is orthogonal to the path for the cold recursion too; projected_* are PROJECTIONS from "
+                       "shard = evaluation_only / 8")
         return res
 
     def run_hessian(precision: str, sample_atoms: int):

@@ -601,17 +601,21 @@ class GrowingStringDriver:
                         # Start vector.  Cold: the string tangent (what a first recursion has).  Warm (gs_kw["climb_lanczos_warm_start"], default
                         # True): last cycle's mode -- the HEI moves by at most max_step per cycle, so it is an almost converged start vector and
                         # the recursion (same dl, same max_cycles, same Ritz-value stop rule) needs its minimum of two gradients instead of
-                        # 3-25: the SERIAL single-image depth of the reference's default climbing phase (path_opt.py:179-182).  Guarded: a
-                        # recursion started from a near-eigenvector spans a tiny Krylov space and would follow that eigenvector wherever it
-                        # goes, so the warm result is only kept while it still describes the reaction mode -- negative curvature and an
-                        # overlap of at least `climb_lanczos_warm_overlap` (0.5) with the string tangent; otherwise this cycle pays for a cold
-                        # recursion as well.
+                        # 3-25: the SERIAL single-image depth of the reference's default climbing phase (path_opt.py:179-182; measured on the c3
+                        # string: 11.6 -> 3.2 gradients per cycle).  Guarded: a recursion started from a near-eigenvector spans a tiny Krylov
+                        # space, meets the stop rule at ANY eigenvector and would follow one that has stopped being the lowest.  So (i) a warm
+                        # result is kept only while its curvature is negative (and, optionally, while it overlaps the tangent by at least
+                        # `climb_lanczos_warm_overlap`, default off: the lowest mode need not lie along the path -- on the synthetic c3 string it
+                        # is orthogonal to it for the cold recursion too); otherwise this cycle pays for a cold recursion as well; (ii) every
+                        # `climb_lanczos_refresh`-th recursion (10) is a cold one, which sees every direction again.
                         t_hei = t_dev[hei] / t_dev[hei].norm().clamp_min(1e-30)
                         lp = self._lanczos_prev
                         grad_fn = lambda xq: -self._single_forces(xq)                      # noqa: E731
                         warm = bool(gs.get("climb_lanczos_warm_start", True)) and lp is not None and lp[0] == hei and lp[1] == k
                         guard = bool(gs.get("climb_lanczos_warm_guard", True))          # False: measurement only (bench.py) -- any warm result is kept
-                        min_ov = float(gs.get("climb_lanczos_warm_overlap", 0.5))
+                        min_ov = float(gs.get("climb_lanczos_warm_overlap", -1.0))
+                        refresh = max(int(gs.get("climb_lanczos_refresh", 10)), 1)
+                        warm = warm and (self.lanczos_calls % refresh != refresh - 1)
                         trusted = lambda w_, v_: (not guard) or (w_ < 0.0 and float(v_ @ t_hei) >= min_ov)     # noqa: E731
                         done = False
                         if warm:

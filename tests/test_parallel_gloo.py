@@ -53,7 +53,7 @@ def _worker(rank, world, port, k, n, out):
 def test_sharded_equals_single_process(k, world):
     """(16, 8) / (8, 8) / (24, 8): the layouts BASELINE names -- c3 "16 images sharded 2-images/GPU across 8", c5 "8 images one-image-per-GPU",
     c4's 24 DMF images on 8 GPUs -- as eight gloo ranks on the CPU (an 8-rank rehearsal on ONE GPU is not possible: the box admits six GPU
-    processes)."""
+    processes, the launcher included)."""
     n = 7
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -109,6 +109,9 @@ static inline float bf16_rne(float x) {
  * Elements within 2^-5 of the group's largest keep their 8 bits; smaller ones get fewer leading bits and pass the rest down a plane.
  * dem_w2: the same for the weights' SECOND plane (static, free).  0 = off. */
 int gemm_dem_a = 0, gemm_dem_w = 0, gemm_dem_w2 = 0;
+int gemm_wide_acc = 0;   /* analysis only: 1 = every MFMA's products are summed from zero and added to a DOUBLE accumulator (no float32 rounding of the
+                            running sum); 2 = as 1 but the running sum is rounded to float32 after every MFMA with round-to-nearest of the EXACT sum
+                            (an ideal float32 accumulator: no hardware cut between the products and the accumulator) */
 static inline float round_q(float v, float gmax, int dem) {
   if (dem <= 0 || gmax == 0.f) return v;
   const float q = ldexpf(1.f, fexp(gmax) - dem);
@@ -134,6 +137,7 @@ void gemm_bf16x3(const float* A, const float* W, const float* bias, const float*
       for (int c = 0; c < nc; ++c) {
         const int n = cols[c];
         float acc[4] = {bias ? sg * bias[n] : 0.f, 0.f, 0.f, 0.f};
+        double dacc[4] = {acc[0], 0.0, 0.0, 0.0};
         for (int k0 = 0; k0 < K; k0 += 16) {
           float xs[16];
           for (int k = 0; k < 16; ++k) xs[k] = sg * A[(size_t)m * K + k0 + k];
@@ -141,11 +145,21 @@ void gemm_bf16x3(const float* A, const float* W, const float* bias, const float*
           split3(W + (size_t)n * K + k0, gemm_dem_w, gemm_dem_w2, wp);
           for (int o = 0; o < n_ops; ++o) {
             const int qa = prog[3 * o], qb = prog[3 * o + 1], id = prog[3 * o + 2];
-            acc[id] = mfma_dot(acc[id], ap[qa], wp[qb], 16, 8);
+            if (gemm_wide_acc) {
+              for (int hh = 0; hh < 16; hh += 8) {
+                double ps = 0.0;
+                for (int k = hh; k < hh + 8; ++k) ps += (double)ap[qa][k] * (double)wp[qb][k];
+                dacc[id] += ps;
+                if (gemm_wide_acc == 2) dacc[id] = (double)(float)dacc[id];
+              }
+              acc[id] = (float)dacc[id];
+            } else acc[id] = mfma_dot(acc[id], ap[qa], wp[qb], 16, 8);
           }
-          for (int f = 0; f < n_fold_step; ++f) { acc[fold_step[2 * f + 1]] += acc[fold_step[2 * f]]; acc[fold_step[2 * f]] = 0.f; }
+          for (int f = 0; f < n_fold_step; ++f) { acc[fold_step[2 * f + 1]] += acc[fold_step[2 * f]]; acc[fold_step[2 * f]] = 0.f;
+                                                  dacc[fold_step[2 * f + 1]] = gemm_wide_acc == 1 ? dacc[fold_step[2 * f + 1]] + dacc[fold_step[2 * f]] : (double)acc[fold_step[2 * f + 1]]; dacc[fold_step[2 * f]] = 0.0; }
         }
-        for (int f = 0; f < n_fold_end; ++f) { acc[fold_end[2 * f + 1]] += acc[fold_end[2 * f]]; acc[fold_end[2 * f]] = 0.f; }
+        for (int f = 0; f < n_fold_end; ++f) { acc[fold_end[2 * f + 1]] += acc[fold_end[2 * f]]; acc[fold_end[2 * f]] = 0.f;
+                                                if (gemm_wide_acc == 1) acc[fold_end[2 * f + 1]] = (float)(dacc[fold_end[2 * f + 1]] + dacc[fold_end[2 * f]]); }
         Y[(size_t)m * nc + c] = sg * acc[0];
       }
     }

@@ -165,3 +165,56 @@ void gemm_bf16x3(const float* A, const float* W, const float* bias, const float*
     }
   }
 }
+
+/* The FAST mode's forward GEMM (umx_gemm_q.h, F16 = 1, P = 2, PB = 3, NPROD = 4): A = two IEEE-half planes of 16 x, W = three half planes of
+ * s_w x (s_w a power of two that puts max |w| into [2^14, 2^15)), products (0,2), (0,1), (1,0), (0,0) on v_mfma_f32_32x32x16_f16 into ONE
+ * accumulator that starts from bias / cscale; Y = cscale * acc, cscale = 1 / (16 s_w).  dem > 0: the leading planes (and the weights' second
+ * plane) quantised to 2^(e_max - dem) of their pass group first ("aligned planes"). */
+static inline float f16_rne(float x) {          /* float -> IEEE half -> float, round to nearest even; subnormals kept; (no _Float16 in this gcc) */
+  if (fabsf(x) < 6.103515625e-05f) return rintf(x * 16777216.0f) / 16777216.0f;     /* below 2^-14: multiples of 2^-24 */
+  uint32_t u; memcpy(&u, &x, 4);
+  u += 0xFFFu + ((u >> 13) & 1u); u &= 0xFFFFE000u;
+  float r; memcpy(&r, &u, 4); return r;
+}
+static inline void split_f16(const float* x, int n_pl, int dem, float (*pl)[16]) {
+  for (int g = 0; g < 16; g += 8) {
+    float rem[8];
+    for (int k = 0; k < 8; ++k) rem[k] = x[g + k];
+    for (int q = 0; q < n_pl; ++q) {
+      float gm = 0.f;
+      for (int k = 0; k < 8; ++k) if (fabsf(rem[k]) > gm) gm = fabsf(rem[k]);
+      for (int k = 0; k < 8; ++k) {
+        const float lead = (q + 1 < n_pl) ? round_q(rem[k], gm, dem) : rem[k];
+        pl[q][g + k] = f16_rne(lead);
+        rem[k] -= pl[q][g + k];
+      }
+    }
+  }
+}
+void gemm_f16_fast(const float* A, const float* W, const float* bias, const float* row_sign, float* Y, int M, int N, int K, const int* cols, int nc,
+                   float w_scale, int dem) {
+  (void)N;
+  const float cs = 1.0f / (16.0f * w_scale);
+#pragma omp parallel
+  {
+    float ap[2][16], wp[3][16], xs[16], ws[16];
+#pragma omp for schedule(dynamic, 16)
+    for (int m = 0; m < M; ++m) {
+      const float sg = row_sign ? row_sign[m] : 1.f;
+      for (int c = 0; c < nc; ++c) {
+        const int n = cols[c];
+        float acc = bias ? sg * bias[n] / cs : 0.f;
+        for (int k0 = 0; k0 < K; k0 += 16) {
+          for (int k = 0; k < 16; ++k) { xs[k] = sg * A[(size_t)m * K + k0 + k] * 16.0f; ws[k] = W[(size_t)n * K + k0 + k] * w_scale; }
+          split_f16(xs, 2, dem, ap);
+          split_f16(ws, 3, dem, wp);
+          acc = mfma_dot(acc, ap[0], wp[2], 16, 11);
+          acc = mfma_dot(acc, ap[0], wp[1], 16, 11);
+          acc = mfma_dot(acc, ap[1], wp[0], 16, 11);
+          acc = mfma_dot(acc, ap[0], wp[0], 16, 11);
+        }
+        Y[(size_t)m * nc + c] = sg * cs * acc;
+      }
+    }
+  }
+}

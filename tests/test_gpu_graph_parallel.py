@@ -205,7 +205,7 @@ def test_rccl_all_reduce_in_place_on_engine_memory():
     assert out["backend"] == "nccl" and out["n_exchanges"] == 10 and out["bitwise"] is True and out["close"] is True
 
 
-def _gsm_run(group_world, gp_singles, out_key, out):
+def _gsm_run(group_world, gp_singles, out_key, out, warm=False):
     """The SPMD growing-string driver on a fully grown 6-image string with the reference's default climbing phase forced on (climb +
     climb_lanczos, path_opt.py:179-182): every cycle = one sharded batched evaluation + a Lanczos recursion of single-image gradients."""
     from pdb2reaction_amd.engine import Engine
@@ -224,39 +224,43 @@ def _gsm_run(group_world, gp_singles, out_key, out):
     elem = [synth.SYMBOLS[int(q)] for q in z]
     drv = GrowingStringDriver(elem, x0[0], x0[-1], evaluate_device=ev, device=dev, images=x0,
                               gs_kw={"max_nodes": k - 2, "fix_first": False, "fix_last": False, "climb": True, "climb_rms": 1e9, "climb_lanczos": True,
-                                     "climb_lanczos_rms": 1e9},
+                                     "climb_lanczos_rms": 1e9, "climb_lanczos_warm_start": warm},
                               stopt_kw={"max_cycles": 5, "thresh": "gau_vtight", "max_step": 0.05, "print_every": 10 ** 9})
     res = drv.run()
     out[out_key] = (res.coords, res.energies, drv.lanczos_evals, drv.lanczos_calls, ev.gp_single_calls, group_world)
     eng.close()
 
 
-def _gsm_worker(rank, world, port, out):
+def _gsm_worker(rank, world, port, out, warm):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        _gsm_run(world, True, rank, out)
+        _gsm_run(world, True, rank, out, warm)
     finally:
         dist.destroy_process_group()
 
 
-def _gsm_single(rank, out):
-    _gsm_run(1, True, "single", out)
+def _gsm_single(rank, out, warm):
+    _gsm_run(1, True, "single", out, warm)
 
 
-def test_spmd_driver_evaluates_the_lanczos_probes_graph_parallel():
+@pytest.mark.parametrize("warm", [False, True])
+def test_spmd_driver_evaluates_the_lanczos_probes_graph_parallel(warm):
     """in the sharded run the serial single-image probes of the climbing image's Lanczos recursion no longer run on one
     rank while the others wait -- a one-image batch goes through the graph-parallel evaluator over ALL ranks (row a12: built for K < G).
     Two gloo ranks on the one GPU: both ranks end with the same string bit for bit, every probe was a graph-parallel evaluation, and the
-    string agrees with the single-process run to the float32 summation-order differences of the partial edge sums."""
+    string agrees with the single-process run to the float32 summation-order differences of the partial edge sums -- tightly with converged
+    (cold) recursions; with the default warm-started two-step recursions the 2e-6 eV/A differences of the probes pass through a finite-difference
+    Hessian (dx = 5e-3) and five climbing steps, so only the looser bound is asserted there."""
     mgr = mp.get_context("spawn").Manager()   # (never FORK a process that has initialised the GPU)
     out = mgr.dict()
-    mp.spawn(_gsm_single, args=(out,), nprocs=1, join=True)
-    mp.spawn(_gsm_worker, args=(2, _port(), out), nprocs=2, join=True)
+    mp.spawn(_gsm_single, args=(out, warm), nprocs=1, join=True)
+    mp.spawn(_gsm_worker, args=(2, _port(), out, warm), nprocs=2, join=True)
     c1, e1, evals1, calls1, gp1, _ = out["single"]
     assert evals1 > 0 and calls1 >= 3 and gp1 == 0                                     # one process: no graph-parallel evaluation
     for r in (0, 1):
         c, e, evals, calls, gp_calls, world = out[r]
         assert world == 2 and gp_calls == evals > 0 and calls == calls1               # every probe went through the graph-parallel evaluator
-        assert np.abs(c - c1).max() < 2e-3 and np.abs(e - e1).max() < 2e-5, (np.abs(c - c1).max(), np.abs(e - e1).max())
+        tol_c, tol_e = (5e-3, 1e-3) if warm else (2e-3, 2e-5)
+        assert np.abs(c - c1).max() < tol_c and np.abs(e - e1).max() < tol_e, (np.abs(c - c1).max(), np.abs(e - e1).max())
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])  # the replicated update stays replicated

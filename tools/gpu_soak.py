@@ -1,5 +1,7 @@
 """Soak run: growing-string optimisation of a 500-atom synthetic cluster on the engine (c2-like), watching device memory
-and wall time per cycle.  usage: python tools/gpu_soak.py [atoms] [max_nodes] [cycles]"""
+and wall time per cycle.  usage: python tools/gpu_soak.py [atoms] [max_nodes] [cycles] [lanczos]
+"lanczos" (round 6): the climbing thresholds are forced so that the reference's default climbing phase (climb_lanczos, path_opt.py:179-182) runs
+from the first fully grown cycle on -- the warm-started Lanczos recursions over hundreds of cycles."""
 import importlib
 import sys
 import time
@@ -21,7 +23,9 @@ calc = U.uma_pysis(model="synthetic", freeze_atoms=list(frozen))
 r, p = (imgs[0] * U.ANG2BOHR).reshape(-1), (imgs[1] * U.ANG2BOHR).reshape(-1)
 free0 = torch.cuda.mem_get_info()[0]
 t0 = time.perf_counter()
-drv = GrowingStringDriver.from_calculator(elem, r, p, calc, gs_kw={"max_nodes": nodes, "climb": True}, stopt_kw={"max_cycles": cycles})
+force_lz = len(sys.argv) > 4 and sys.argv[4] == "lanczos"
+gs_kw = {"max_nodes": nodes, "climb": True, **({"climb_rms": 1e9, "climb_lanczos_rms": 1e9} if force_lz else {})}
+drv = GrowingStringDriver.from_calculator(elem, r, p, calc, gs_kw=gs_kw, stopt_kw={"max_cycles": cycles})
 print("driver device:", drv.device)
 res = drv.run()
 dt = time.perf_counter() - t0
@@ -29,7 +33,7 @@ free1 = torch.cuda.mem_get_info()[0]
 print(f"atoms {n} images {len(res.coords)} cycles {res.cycles} force evaluations {res.force_evaluations} "
       f"fully_grown {res.fully_grown} converged {res.converged}")
 print(f"wall {dt:.2f} s = {dt / max(res.cycles, 1) * 1e3:.1f} ms/cycle; image E+F per s {res.force_evaluations / dt:.1f}")
-print(f"timing: total {res.timing['total_s']:.2f} s, optimistic steps recomputed {int(res.timing['redo_steps'])}, Lanczos evaluations {drv.lanczos_evals}")
+print(f"timing: total {res.timing['total_s']:.2f} s, optimistic steps recomputed {int(res.timing['redo_steps'])}, Lanczos evaluations {drv.lanczos_evals} in {drv.lanczos_calls} recursions ({drv.lanczos_warm_calls} warm-started and kept, {drv.lanczos_warm_rejected} warm results rejected)")
 print(f"device memory in use by the run: {(free0 - free1) / 2**30:.2f} GiB (workspace is allocated once and kept)")
 print("energies (Hartree, rel. to first):", np.round(res.energies - res.energies[0], 5))
 assert np.isfinite(res.energies).all() and np.isfinite(res.coords).all()

@@ -602,7 +602,7 @@ class GrowingStringDriver:
                         # True): last cycle's mode -- the HEI moves by at most max_step per cycle, so it is an almost converged start vector and
                         # the recursion (same dl, same max_cycles, same Ritz-value stop rule) needs its minimum of two gradients instead of
                         # 3-25: the SERIAL single-image depth of the reference's default climbing phase (path_opt.py:179-182; measured on the c3
-                        # string: 11.6 -> 3.2 gradients per cycle).  Guarded: a recursion started from a near-eigenvector spans a tiny Krylov
+                        # string: 11.6 -> 4.0 gradients per cycle).  Guarded: a recursion started from a near-eigenvector spans a tiny Krylov
                         # space, meets the stop rule at ANY eigenvector and would follow one that has stopped being the lowest.  So (i) a warm
                         # result is kept only while its curvature is negative (and, optionally, while it overlaps the tangent by at least
                         # `climb_lanczos_warm_overlap`, default off: the lowest mode need not lie along the path -- on the synthetic c3 string it

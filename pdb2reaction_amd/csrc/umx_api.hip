@@ -665,6 +665,7 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
       });
       // SO(2) conv 1 on the pre-modulated planes -> hg = [gate | hpre]
       P.matrix([=, &w]() -> int {
+        if (eng->fwd_fmt == 3) DBG("y1q." + std::to_string(i), reinterpret_cast<const float*>(w.y1pl), (ne + 3) / 4 * 4 * XROT);     // (debug) conv-1's A operand as the GEMMs read it
         CHK(gemm_pl(eng, 0, 3, w.y1pl, XROT, 0, 0, Lp->c1m0, 0, Lp->c1m0b, w.hg[i], HG, 0, 0, ne, 640, 768, 1.0f));
         CHK(gemm_pl(eng, 1, 3, w.y1pl, XROT, 768, 1280, Lp->c1m1, 256, nullptr, w.hg[i], HG, 640, 896, ne, 256, 512, 1.0f));
         return gemm_pl(eng, 1, 3, w.y1pl, XROT, 1792, 2048, Lp->c1m2, 128, nullptr, w.hg[i], HG, 1152, 1280, ne, 128, 256, 1.0f);
@@ -677,6 +678,7 @@ void plan_chunk(umx_engine* eng, WS& w, const float* d_pos, const int* d_deg, co
         return UMX_OK;
       });
       P.matrix([=, &w]() -> int {
+        if (eng->fwd_fmt == 3) DBG("hidq." + std::to_string(i), reinterpret_cast<const float*>(w.hidpl), (ne + 3) / 4 * 4 * ROW);      // (debug) conv-2's A operand
         CHK(gemm_pl(eng, 0, 3, w.hidpl, ROW, 0, 0, Lp->c2m0, 0, Lp->c2m0b, w.msg[i], ROW, 0, 0, ne, 384, 384, 1.0f));
         CHK(gemm_pl(eng, 1, 3, w.hidpl, ROW, 384, 640, Lp->c2m1, 256, nullptr, w.msg[i], ROW, 384, 640, ne, 256, 256, 1.0f));
         return gemm_pl(eng, 1, 3, w.hidpl, ROW, 896, 1024, Lp->c2m2, 128, nullptr, w.msg[i], ROW, 896, 1024, ne, 128, 128, 1.0f);

@@ -58,3 +58,60 @@ def test_fc3_gemm_is_the_matrix_core_model_bit_for_bit(align, monkeypatch):
     finally:
         da.value = dw.value = dw2.value = 0
         eng.close()
+
+
+def test_so2_conv_gemms_are_the_matrix_core_model_bit_for_bit():
+    """The same for the SO(2) convolutions of a layer: conv-1 / conv-2 m = 0 (plain products: LS = 2 on the 256 x 128 tiles, aligned A planes) and the
+    complex m = 1, 2 products (one accumulator, nearest-bf16 A planes, aligned weight planes; y_re = Xre.Wa - Xim.Wb, y_im = Xim.Wa + Xre.Wb joined by
+    ONE float32 subtraction / addition in the epilogue) -- from the A operands exactly as the GEMMs read them (`y1q.*`, `hidq.*`) to every output bit
+    of `hg` and `msg`."""
+    from pdb2reaction_amd.engine import Engine
+
+    lib = MM.load_lib()
+    w = W.make_synthetic_weights(1)
+    z, pos = synth.make_cluster(60)
+    eng = Engine(0, precision="bf16x3")
+    da, dw, dw2 = (C.c_int.in_dll(lib, n) for n in ("gemm_dem_a", "gemm_dem_w", "gemm_dem_w2"))
+    try:
+        eng.load_weights(w)
+        eng.set_system(z)
+        eng.debug_keep(True)
+        eng.energy_forces(pos.astype(np.float32), forces=False)
+        layer = 1
+        b = f"blocks.{layer}.edge_wise"
+        hg = eng.debug_fetch(f"hg.{layer}").reshape(-1, 1408)
+        msg = eng.debug_fetch(f"msg.{layer}").reshape(-1, 1152)
+        ne = hg.shape[0]
+        sg = np.where(np.arange(ne) % 2 == 1, -1.0, 1.0).astype(np.float32)[:, None]
+        y1 = _unblock(eng.debug_fetch(f"y1q.{layer}"), 2304)[:ne] * sg            # un-negated: the model negates odd rows itself
+        hid = _unblock(eng.debug_fetch(f"hidq.{layer}"), 1152)[:ne] * sg
+        dw.value = dw2.value = 12
+
+        def plain(a, wt, bias):
+            da.value = 12
+            return MM.gemm_bf16x3(np.ascontiguousarray(a), wt, bias, "ls2", alt_rows=True)
+
+        def cplx(a_re, a_im, wt, half):
+            da.value = 0
+            pr = [MM.gemm_bf16x3(np.ascontiguousarray(a), np.ascontiguousarray(wh), None, "plain", alt_rows=True)
+                  for a in (a_re, a_im) for wh in (wt[:half], wt[half:])]           # [re.Wa, re.Wb, im.Wa, im.Wb]
+            return pr[0] - pr[3], pr[2] + pr[1]
+
+        checks = []
+        checks.append(("conv-1 m0", plain(y1[:, :768], w[f"{b}.so2_conv_1.fc_m0.weight"], w[f"{b}.so2_conv_1.fc_m0.bias"]), hg[:, :640]))
+        re, im = cplx(y1[:, 768:1280], y1[:, 1280:1792], w[f"{b}.so2_conv_1.so2_m_conv.0.fc.weight"], 256)
+        checks += [("conv-1 m1 re", re, hg[:, 640:896]), ("conv-1 m1 im", im, hg[:, 896:1152])]
+        re, im = cplx(y1[:, 1792:2048], y1[:, 2048:2304], w[f"{b}.so2_conv_1.so2_m_conv.1.fc.weight"], 128)
+        checks += [("conv-1 m2 re", re, hg[:, 1152:1280]), ("conv-1 m2 im", im, hg[:, 1280:1408])]
+        checks.append(("conv-2 m0", plain(hid[:, :384], w[f"{b}.so2_conv_2.fc_m0.weight"], w[f"{b}.so2_conv_2.fc_m0.bias"]), msg[:, :384]))
+        re, im = cplx(hid[:, 384:640], hid[:, 640:896], w[f"{b}.so2_conv_2.so2_m_conv.0.fc.weight"], 256)
+        checks += [("conv-2 m1 re", re, msg[:, 384:640]), ("conv-2 m1 im", im, msg[:, 640:896])]
+        re, im = cplx(hid[:, 896:1024], hid[:, 1024:1152], w[f"{b}.so2_conv_2.so2_m_conv.1.fc.weight"], 128)
+        checks += [("conv-2 m2 re", re, msg[:, 896:1024]), ("conv-2 m2 im", im, msg[:, 1024:1152])]
+        for name, model, got in checks:
+            same = np.ascontiguousarray(model).view(np.uint32) == np.ascontiguousarray(got).view(np.uint32)
+            print(f"{name}: {model.shape[0]} x {model.shape[1]} outputs, {int((~same).sum())} differ from the model")
+            assert same.all(), (name, int((~same).sum()), float(np.abs(model - got).max()))
+    finally:
+        da.value = dw.value = dw2.value = 0
+        eng.close()

@@ -108,10 +108,15 @@ def test_so2_conv_gemms_are_the_matrix_core_model_bit_for_bit():
         checks += [("conv-2 m1 re", re, msg[:, 384:640]), ("conv-2 m1 im", im, msg[:, 640:896])]
         re, im = cplx(hid[:, 896:1024], hid[:, 1024:1152], w[f"{b}.so2_conv_2.so2_m_conv.1.fc.weight"], 128)
         checks += [("conv-2 m2 re", re, msg[:, 896:1024]), ("conv-2 m2 im", im, msg[:, 1024:1152])]
+        bad = []
         for name, model, got in checks:
             same = np.ascontiguousarray(model).view(np.uint32) == np.ascontiguousarray(got).view(np.uint32)
             print(f"{name}: {model.shape[0]} x {model.shape[1]} outputs, {int((~same).sum())} differ from the model")
-            assert same.all(), (name, int((~same).sum()), float(np.abs(model - got).max()))
+            if not same.all():
+                bad.append((name, int((~same).sum()), float(np.abs(model - got).max()), np.argwhere(~same)[:4].tolist()))
+        if bad and os.environ.get("UMX_MODEL_DUMP"):          # operands of the run for an offline replay (tools/mfma_model.py)
+            np.savez_compressed(os.environ["UMX_MODEL_DUMP"], y1=y1, hid=hid, hg=hg, msg=msg)
+        assert not bad, bad
     finally:
         da.value = dw.value = dw2.value = 0
         eng.close()

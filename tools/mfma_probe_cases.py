@@ -109,6 +109,23 @@ def make_sets(kind: str, seed: int):
     C0 = (rand_sig(rng, (T, R, R), 24) * rng.choice([-1.0, 1.0], size=(T, R, R))).astype(np.float32)
     sets["tiny16"] = (A, B, C0)
 
+    # ---- far16 (round 6, second probe run): sixteen products 2^-16 ... 2^-40 below C0, all within a few binades of each other -----------------
+    # (a 1-ulp difference between model and engine in 3 of 4.4 M conv outputs was traced to a pass whose products lay 2^-28 below the accumulator)
+    # NOTE: drawn from its OWN generator so that the sets above and below keep the values of the first probe run
+    rng_far = np.random.default_rng(seed + 1000)
+    T = 600
+    gap = rng_far.integers(16, 41, size=(T, 1, 1, 1))
+    ea = -(gap // 2) - rng_far.integers(0, 3, size=(T, 1, R, K)); eb = -(gap - gap // 2) - rng_far.integers(0, 3, size=(T, 1, R, K))
+    if kind.startswith("f16"):
+        ea = np.maximum(ea, -13); eb = np.maximum(eb, -13)
+    A = (rand_sig(rng_far, ea.shape, sb) * rng_far.choice([-1.0, 1.0], size=ea.shape) * np.exp2(ea)).astype(np.float32)
+    B = (rand_sig(rng_far, ea.shape, sb) * rng_far.choice([-1.0, 1.0], size=ea.shape) * np.exp2(eb)).astype(np.float32)
+    for t in range(T):
+        if t % 3 == 1: A[t] = np.abs(A[t]); B[t] = np.abs(B[t])
+        if t % 3 == 2: A[t, :, :, K // 2:] = 0.0                                  # only the first pass has products
+    C0 = (rand_sig(rng_far, (T, R, R), 24) * rng_far.choice([-1.0, 1.0], size=(T, R, R))).astype(np.float32)
+    sets["far16"] = (A, B, C0)
+
     # ---- rand / chain ------------------------------------------------------------------------------------------------------------
     for name, T, steps in (("rand", 600, 1), ("chain", 200, 6)):
         ea = rng.integers(-7, 1, size=(T, steps, R, K)); eb = rng.integers(-7, 1, size=(T, steps, R, K))

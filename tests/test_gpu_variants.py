@@ -82,6 +82,14 @@ def test_task_names_follow_the_blob_s_dataset_list(monkeypatch):
         finally:
             eng.close()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    # a dataset table whose row count is not the list's length cannot be mapped by name: refused at load, not silently mis-indexed
+    w_c = W.WeightSet(w_a, meta={"model": {"dataset_list": ["omol", "omat", "oc20"]}})          # 5 rows, 3 names
+    eng = Engine(0)
+    try:
+        with pytest.raises(Exception, match="dataset"):
+            eng.load_weights(W.pack_blob(w_c))
+    finally:
+        eng.close()
 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "fp32"])

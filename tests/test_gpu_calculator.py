@@ -109,6 +109,36 @@ def test_device_resident_fd_hessian_equals_the_host_entry(setup):
     calc.close()
 
 
+def test_device_batch_entry_widens_like_the_host_entry(weights, monkeypatch):
+    """``UMAcore.compute_batch_dev`` (the device-resident FD Hessian's force entry) goes through the asynchronous device-pointer entry, which cannot
+    refuse its own result: an activation beyond the fast mode's fp16 operand range must be noticed there, the engine widened to bf16 forward planes
+    and the batch repeated -- bitwise what an engine created in split-bf16 returns, as the host entry does (test_gpu_parity)."""
+    from pdb2reaction_amd.engine import Engine
+
+    big = dict(weights)
+    key = "blocks.0.edge_wise.so2_conv_1.rad_func.fc3"
+    big[key + ".weight"] = (np.asarray(weights[key + ".weight"]) * 3e4).astype(np.float32)
+    z, imgs, _ = synth.make_images(40, 3, seed=2)
+    p32 = np.asarray(imgs, dtype=np.float32)
+    ref = Engine(0, precision="split-bf16")
+    monkeypatch.setenv("UMX_PRECISION", "split")
+    eng = Engine(0)
+    try:
+        ref.load_weights(big); ref.set_system(z)
+        _, f0 = ref.energy_forces(p32)
+        eng.load_weights(big); eng.set_system(z)
+        core = U.UMAcore.__new__(U.UMAcore)
+        core.engine = eng
+        with pytest.warns(RuntimeWarning, match="split-bf16"):
+            f = core.compute_batch_dev(torch.as_tensor(p32, device="cuda"))
+        assert eng.widened and eng.precision_mode() == "split-bf16"
+        assert f.is_cuda and np.array_equal(f.cpu().numpy(), f0)
+        assert np.array_equal(core.compute_batch_dev(torch.as_tensor(p32, device="cuda")).cpu().numpy(), f0)      # stays widened
+    finally:
+        eng.close()
+        ref.close()
+
+
 def test_error_behaviour(setup):
     z, elem, imgs = setup
     with pytest.raises(RuntimeError, match="no CPU path"):

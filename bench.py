@@ -67,6 +67,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA p
 PEAK_FP64_MFMA_TFLOPS = 78.6     # AMD MI355X datasheet: f64 matrix = f64 vector peak (the micro-arch guide has no f64 row)
 
 
+MFMA_ONLY_TFLOPS = 1660.0      # executed bf16 plane products / s of the GEMM kernel stripped to its MFMAs (profiles/r06_gemm_ablation_gauss3.txt)
 PMC_SUMMARY_GLOB = "r*_pmc_hbm_traffic_{mode}.json"      # profiles/: one per round; the one measured on the running build is taken
 
 
@@ -478,6 +479,10 @@ def main():
                          "definition": "achieved = algorithmic FLOPs (2*M*N*K per product, SURVEY.md 8d) of the family / its HIP-event time; "
                                        "mfma_pipe_util counts the plane products actually executed (bf16x3: x6 in both passes; fast mode: fwd x4 fp16, reverse x3)",
                          "mfma_pipe_util": executed / peak, "executed_tflops": executed,
+                         # (a constant from a committed profile, not measured by this run: the rate of the six-product kernel with everything but
+                         #  its MFMAs removed -- what the matrix pipe delivers at the clock this chip holds under its power cap)
+                         "mfma_only_rate_under_power_cap": ({"tflops": MFMA_ONLY_TFLOPS, "frac": executed / MFMA_ONLY_TFLOPS,
+                                                             "source": "profiles/r06_gemm_ablation_gauss3.txt (UMX_GEMM_ABL=31)"} if split else None),
                          "traffic": float(pmc["dominant_family"]["hbm_bytes_per_launch_avg"]) if pmc else None, "traffic_source": pmc_note,
                          "kernel": ("umx_gemm_q_kernel<*> / umx_gemm_pl16_kernel<*> / umx_gemm_pl_kernel<*> (split-precision LDS-DMA GEMM family: SO(2)/radial linears + transposes, rank 0)" if split
                                     else "umx_gemm_kernel<*> (fp32-MFMA GEMM, rank 0)"),

@@ -67,10 +67,8 @@ LBFGS_HISTORY = 10
 # counterpart here: DLC micro-cycles, the reparametrisation trigger) -- never swallowed in silence.
 _REFUSED = {
     "param": "only param='equi' (equal arc length) is implemented",
-    "climb_fixed": "climb_fixed=True (a climbing image frozen to the first HEI) is not implemented: the HEI is re-selected every cycle",
     "scheduler": "a dask scheduler is not supported: images are batched through one engine call / sharded over ranks instead",
     "align": "align=True (per-cycle Kabsch alignment of the images) is not implemented; align the endpoints beforehand (prestep.py)",
-    "scale_step": "only scale_step='global' is implemented",
     "type": "only the string optimiser (type='string') exists here",
     "coord_type": "only Cartesian coordinates (coord_type='cart', the reference default) are implemented; DLC are not",
 }
@@ -93,6 +91,8 @@ def _check_keywords(gs: Dict[str, Any], opt: Dict[str, Any], extra: Optional[Dic
             if key == "param":
                 raise NotImplementedError(why)
             raise NotImplementedError(f"GrowingStringDriver: {key}={given[key]!r}: {why}")
+    if given.get("scale_step", "global") not in ("global", "per_image"):
+        raise NotImplementedError(f"GrowingStringDriver: scale_step={given['scale_step']!r}: 'global' (the reference default) or 'per_image'")
     for key, why in _WARNED.items():
         if key in given and given[key] != defaults[key]:
             warnings.warn(f"GrowingStringDriver: {key}={given[key]!r} has no effect here: {why}", RuntimeWarning, stacklevel=3)
@@ -355,6 +355,7 @@ class GrowingStringDriver:
         self._f: Optional[torch.Tensor] = None
         self.n_eval = 0
         self.lanczos_evals = 0
+        self.fixed_climb_index: Optional[int] = None         # climb_fixed=True: the image that started to climb (set when climbing starts)
         self.lanczos_calls = 0                               # Lanczos recursions run (one per climbing cycle below climb_lanczos_rms)
         self.lanczos_warm_calls = 0                          # ... of which started from the previous cycle's mode (and were kept)
         self.lanczos_warm_rejected = 0                       # warm recursions whose result failed the guard (a cold one followed)
@@ -535,7 +536,13 @@ class GrowingStringDriver:
                 dg = direction @ g
         if g.numel():
             biggest = direction.abs().max()
-            direction = direction * torch.clamp(self.opt["max_step"] / biggest.clamp_min(1e-300), max=1.0)     # scale_step="global"
+            if self.opt.get("scale_step", "global") == "per_image":
+                # every image's step scaled on its own: only the images whose largest component exceeds max_step are shortened
+                rows = direction.reshape(-1, n_dof)
+                big = rows.abs().amax(dim=1, keepdim=True)
+                direction = (rows * torch.clamp(self.opt["max_step"] / big.clamp_min(1e-300), max=1.0)).reshape(-1)
+            else:                                                                                              # scale_step="global"
+                direction = direction * torch.clamp(self.opt["max_step"] / biggest.clamp_min(1e-300), max=1.0)
             smax = direction.abs().max()
         else:
             smax = zero
@@ -557,6 +564,7 @@ class GrowingStringDriver:
         full_cycles = 0
         need: Optional[List[int]] = None
         climbing = False
+        fixed_hei: Optional[int] = None                 # climb_fixed=True: the image that started to climb keeps climbing
         cycle = 0
         stale = False
         dev = self.device
@@ -578,7 +586,7 @@ class GrowingStringDriver:
             # A decision that invalidates the step (climbing switches on, Lanczos tangent, rejected curvature pair, non-descent
             # direction, an HEI tie broken differently on the host) recomputes it -- rare, counted in `redo_steps`.
             lanczos_t: Optional[torch.Tensor] = None
-            offer_pair, hei_host = True, None
+            offer_pair, hei_host = True, fixed_hei
             rms_all = max_all = 0.0
             hei, rms_img, energies = 0, None, None
             for attempt in range(5):
@@ -589,11 +597,13 @@ class GrowingStringDriver:
                 if attempt == 0:
                     rms_all, max_all = float(stats[0]), float(stats[1])
                     rms_img, energies = stats[8:8 + k].copy(), stats[8 + k:8 + 2 * k].copy()
-                    hei = select_hei_index(energies)
+                    hei = select_hei_index(energies) if fixed_hei is None else fixed_hei
                     if hei != int(stats[6]):
                         hei_host, again = hei, True
                     if full and gs["climb"] and not climbing and rms_all <= gs["climb_rms"] and 0 < hei < k - 1:
                         climbing = True
+                        if gs.get("climb_fixed", False):
+                            fixed_hei = self.fixed_climb_index = hei      # determined once, when climbing starts (reference GS_KW climb_fixed)
                         self._reset_history()
                         again = True
                     if climbing and 0 < hei < k - 1 and gs["climb_lanczos"] and rms_all <= gs["climb_lanczos_rms"]:

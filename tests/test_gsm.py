@@ -242,8 +242,8 @@ def test_device_evaluator_contract_and_timing_split():
 def test_unimplemented_keywords_are_refused_or_warned_about():
     """a reference keyword this driver ignores must not be accepted in silence when it carries a non-default value."""
     calc = MuellerBrown()
-    for kw in ({"gs_kw": {"climb_fixed": True}}, {"gs_kw": {"scheduler": object()}}, {"stopt_kw": {"align": True}},
-               {"stopt_kw": {"scale_step": "per_image"}}, {"geom_kw": {"coord_type": "dlc"}}, {"gs_kw": {"param": "energy"}}):
+    for kw in ({"gs_kw": {"scheduler": object()}}, {"stopt_kw": {"align": True}}, {"stopt_kw": {"scale_step": "per_atom"}},
+               {"geom_kw": {"coord_type": "dlc"}}, {"gs_kw": {"param": "energy"}}):
         with pytest.raises(NotImplementedError):
             GrowingStringDriver(["X"], MIN_A, MIN_B, calc, **kw)
     for kw, word in (({"gs_kw": {"reparam_check": "norm"}}, "reparam_check"), ({"gs_kw": {"max_micro_cycles": 25}}, "max_micro_cycles"),
@@ -255,6 +255,40 @@ def test_unimplemented_keywords_are_refused_or_warned_about():
     with _w.catch_warnings():
         _w.simplefilter("error")                                           # the reference's own defaults pass without a word
         GrowingStringDriver(["X"], MIN_A, MIN_B, calc, gs_kw=dict(GS_KW), stopt_kw=dict(STOPT_KW), geom_kw={"coord_type": "cart", "freeze_atoms": []})
+
+
+def test_climb_fixed_keeps_the_image_that_started_to_climb():
+    """Reference GS_KW `climb_fixed` (path_opt.py:183; default False): the climbing image is determined ONCE, when climbing starts, instead of being the
+    highest image of every cycle.  On the Mueller-Brown string both settings end on the same saddle; the fixed index is recorded."""
+    res = {}
+    for fixed in (False, True):
+        drv = GrowingStringDriver(["X"], MIN_A, MIN_B, MuellerBrown(), gs_kw={"max_nodes": 13, "perp_thresh": 2e-2, "climb_rms": 5e-3, "climb_fixed": fixed},
+                                  stopt_kw={"thresh": "gau", "max_step": 0.05, "max_cycles": 600})
+        res[fixed] = (drv.run(), drv.fixed_climb_index)
+    (r0, i0), (r1, i1) = res[False], res[True]
+    assert i0 is None and i1 is not None and 0 < i1 < len(r1.coords) - 1
+    assert r1.converged and abs(r1.energies[i1] - SCALE * SADDLE_1[2]) < 2e-5            # the FIXED image sits on the saddle
+    assert r0.converged and abs(r0.energies[r0.hei_index] - SCALE * SADDLE_1[2]) < 2e-5
+
+
+def test_scale_step_per_image_scales_every_image_on_its_own():
+    """Reference STOPT_KW `scale_step` (path_opt.py:193): "global" shortens the whole step by one factor so that its largest component is max_step;
+    "per_image" shortens every image whose own largest component exceeds max_step, and only those.  One steepest-descent cycle, no growth, no
+    re-parametrisation: the displacement of each moving image is read off the coordinates."""
+    moved = {}
+    for ss in ("global", "per_image"):
+        drv = GrowingStringDriver(["X"], MIN_A, MIN_B, MuellerBrown(), gs_kw={"max_nodes": 3, "perp_thresh": 1e-14, "reparam_every": 0, "reparam_every_full": 0},
+                                  stopt_kw={"max_step": 1e-4, "max_cycles": 1, "scale_step": ss})
+        x0 = drv.coords.copy()
+        drv.run()
+        assert drv.coords.shape == x0.shape
+        moved[ss] = np.abs(drv.coords - x0).max(axis=1)
+    inner = moved["global"] > 0
+    assert inner.sum() >= 2 and not inner[0] and not inner[-1]
+    assert np.isclose(moved["global"].max(), 1e-4, rtol=1e-9) and moved["global"][inner].min() < 0.9e-4        # one factor: only the largest image reaches max_step
+    assert np.allclose(moved["per_image"][inner], 1e-4, rtol=1e-9)                                            # every image reaches it on its own
+    with pytest.raises(NotImplementedError):
+        GrowingStringDriver(["X"], MIN_A, MIN_B, MuellerBrown(), stopt_kw={"scale_step": "per_atom"})
 
 
 class MuellerBrown24:

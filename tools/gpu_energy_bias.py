@@ -28,7 +28,7 @@ if os.environ.get("BIAS_ENVS"):          # any list of switch settings: BIAS_ENV
 SWITCHES = sorted({k for v in VARIANTS for k in v} | {"UMX_PRECISION", "UMX_NODE_F64", "UMX_ALT_ROWS", "UMX_LOW_SEP", "UMX_ALIGN_PLANES"})
 FILES = {"c3": "c3c4_n2000.npz", "c5": "c5_n20000.npz", "g1": "c5_n20000_g1.npz", "w1": "c5_n20000_w1.npz", "perm": "c5_n20000.npz",
          "w2": "c5_n20000_w2.npz", "w3": "c5_n20000_w3.npz",         # (round 6: two more geometries with weights seeds 2 / 3)
-         "w4": "c5_n20000_w4.npz", "w5": "c5_n20000_w5.npz"}          # (end of round 6: two more, cluster seeds 20260630 / 20260730, weights seeds 4 / 5)
+         "w4": "c5_n20000_w4.npz", "w5": "c5_n20000_w5.npz", "w6": "c5_n20000_w6.npz", "w7": "c5_n20000_w7.npz"}          # (end of round 6: two more, cluster seeds 20260630 / 20260730, weights seeds 4 / 5)
 which = sys.argv[1:] or ["c3", "c5"]
 for name in which:
     g = np.load(os.path.join(GOLD, FILES[name]))

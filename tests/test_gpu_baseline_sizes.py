@@ -263,7 +263,7 @@ def test_c5_energy_and_forces_against_f64_oracle(name, mode, monkeypatch):
         eng.close()
 
 
-@pytest.mark.parametrize("name", ["c5_n20000_w2", "c5_n20000_w3", "c5_n20000_w4", "c5_n20000_w5"])
+@pytest.mark.parametrize("name", ["c5_n20000_w2", "c5_n20000_w3", "c5_n20000_w4", "c5_n20000_w5", "c5_n20000_w6", "c5_n20000_w7"])
 def test_c5_energy_with_more_geometries_and_weight_sets(name):
     """Round 6: six 20 000-atom goldens made AFTER the aligned planes went in (other clusters, weights seeds 2 ... 7; tools/make_golden_c5.py;
     w4 ... w7 were added to this list before the engine had ever been run on them) -- the flat 1e-4 eV of the north-star must hold on cases the

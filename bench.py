@@ -30,6 +30,8 @@ Rank 0 prints ONE JSON line (contract in the task statement) carrying
   from it is a PROJECTION, not a measurement;
 * `--config c1|c2|c4|c5`: the other BASELINE configs through the same evaluator (`config.workload` names them; c4 adds the
   finite-difference Hessian loop of `uma_pysis.py:595-686` on a bounded sample of its 2 x 3N_active displaced geometries);
+* `split_bf16_mode`: the same workload with the headline mode's forward pass and the fast mode's 16-bit reverse pass (`UMX_PRECISION=split-bf16`:
+  the headline mode's energy bit for bit).
 * `fast_mode`: the same workload in the opt-in fast mode (`UMX_PRECISION=split`: 22-23-bit forward activations, 16-bit reverse
   products -- narrower than float32, hence not the headline) and `fp32_mode`: on the fp32 MFMA (`UMX_PRECISION=fp32`), a few
   steps each, timed the same way (N=1 only);
@@ -582,6 +584,11 @@ def main():
             # reference's float32, so it is NOT the headline; tolerances are met with margin (tests/test_gpu_baseline_sizes.py)
             out["fast_mode"] = side_mode("split", args.fp32_steps, args.fp32_warmup, "split_bf16", PEAK_BF16_MFMA_TFLOPS,
                                          "f16-split (fwd 2 x 3 fp16 planes / 4 products, reverse 2 x 2 bf16 planes / 3 products): narrower than float32")
+        if world == 1 and not args.no_fast_mode and mode == "bf16x3":
+            # split-bf16: the headline mode's forward pass (its ENERGY bit for bit) with the fast mode's 16-bit reverse pass (forces <= 7e-6 eV/A off)
+            out["split_bf16_mode"] = side_mode("split-bf16", args.fp32_steps, args.fp32_warmup, "split_bf16", PEAK_BF16_MFMA_TFLOPS,
+                                               "bf16-split (fwd as the headline: 3 x 3 bf16 planes / 6 products; reverse 2 x 2 bf16 planes / 3 products): "
+                                               "the headline mode's energy, a 16-bit reverse pass")
         if world == 1 and split and not args.no_fp32_mode:
             # every GEMM on v_mfma_f32_32x32x2_f32: the same float32 products as the headline mode's, on the fp32 matrix pipe
             out["fp32_mode"] = side_mode("fp32", args.fp32_steps, args.fp32_warmup, "fp32", PEAK_FP32_MFMA_TFLOPS, "f32 (all GEMMs on v_mfma_f32_32x32x2_f32)")

@@ -330,6 +330,31 @@ def test_c3_fast_mode_error_is_a_fixed_amount_per_atom_that_depends_on_the_weigh
         eng.close()
 
 
+@pytest.mark.parametrize("name", ["c3_n2000_grid_w0", "c3_n2000_grid_w1", "c3_n2000_grid_w2", "c5_n20000_grid_w0", "c5_n20000_grid_w1"])
+def test_grid_feed_forward_variant_at_the_baseline_sizes(name):
+    """The GRID feed-forward form of the model (`ff_type = grid | spectral (unsure)` -- it may be the form the real checkpoint has) at
+    the sizes where 1e-4 eV is 5e-8 / 5e-9 eV per atom: the variant tests stop at 500 atoms, and a coherent per-atom error in the node-level grid
+    GEMMs would only show here.  Goldens: tools/make_golden_variant_sizes.py (float64 chunked oracle), made at the end of round 6 and asserted
+    before the engine had run on them.  Default mode, the north-star's tolerances."""
+    from pdb2reaction_amd.engine import Engine
+
+    g = load_golden(name)
+    w = W.make_synthetic_weights(int(g["weights_seed"]), ff_type="grid")
+    eng = Engine(0)
+    try:
+        eng.load_weights(w)
+        assert "ff=grid" in eng.model_variant()
+        eng.set_system(g["z"])
+        pos = g["pos"] if g["pos"].ndim == 3 else g["pos"][None]
+        e, f = eng.energy_forces(pos)
+        de = e[0] - g["energy"][0]
+        df = np.abs(f[0].astype(np.float64) - g["forces"][0]).max()
+        print(f"[{name}] dE = {de:+.2e} eV ({de / len(g['z']):+.1e} eV/atom), max|dF| = {df:.2e} eV/A")
+        assert abs(de) <= TOL_E and df <= TOL_F, (name, de, df)
+    finally:
+        eng.close()
+
+
 def test_c5_energy_with_the_atom_order_permuted(weights):
     """The same 20 000-atom image with its atoms in a random order: every edge gets another index, i.e. the parity that decides which operand
     rows are stored negated is re-dealt -- the cancellation of the matrix cores' one-sided rounding must not depend on the order the structure
